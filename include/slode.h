@@ -1,0 +1,163 @@
+/*
+ * slode.h -- C ABI of libslode.so: the MI355X (gfx950) engine for the latent-ODE solve + ELBO path of
+ * paidamoyo/structured_latent_ODEs.
+ *
+ * The reference has no FFI of its own (its only API is Python classes); every entry point below
+ * names the reference Python interface it replaces (file:line relative to the reference repo).  The Python host
+ * side (structured_latent_odes_amd/) binds these with ctypes; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - all tensors are fp32, device (HBM) pointers owned by the CALLER; the library never allocates device
+ *     memory, never synchronises the stream, and launches on the hipStream_t passed as `void* stream`;
+ *   - every call returns SLODE_OK (0) or a negative slode_status; slode_last_error() gives the text;
+ *   - all model parameters live in ONE flat fp32 vector whose segment offsets are given by slode_layout
+ *     (filled by slode_layout_init); gradients use the same layout;
+ *   - observations are addressed as the logical [B, C, T] tensor through explicit element strides, so the
+ *     reference's permuted view of a contiguous [B, T, C] batch (training_cvs.py:25) is consumed without a copy.
+ */
+#ifndef SLODE_H
+#define SLODE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLODE_VERSION 100 /* 0.1.0 */
+
+#define SLODE_MAX_GROUPS 4
+#define SLODE_MAX_HEADS 3
+
+typedef enum slode_status {
+  SLODE_OK = 0,
+  SLODE_EINVAL = -1, /* bad shape / stride / null pointer / unsupported dimension */
+  SLODE_EHIP = -2,   /* a HIP runtime call failed (text from hipGetErrorString)      */
+  SLODE_ENOSPC = -3  /* caller workspace too small                                   */
+} slode_status;
+
+/* torchdiffeq method strings accepted by OdeModel.init_with_params(solver=...), models/blackbox_ode.py:7-17,41-45 */
+typedef enum slode_method { SLODE_EULER = 0, SLODE_MIDPOINT = 1, SLODE_RK4 = 2, SLODE_DOPRI5 = 3 } slode_method;
+
+/* Decoder (models/decoders.py:8-54, asymmetric-Laplace, 3 heads q50/q75/q25) or GaussianDecoder (:57-91, 1 head) */
+typedef enum slode_likelihood { SLODE_ALD = 0, SLODE_GAUSS = 1 } slode_likelihood;
+
+/* One conditional prior net p(z_g | u_g): EncoderMLP([u_dim, [z_dim, z_dim]], [None, Exp]);
+ * models/mechanistic_cvs.py:88-100, mechanistic_proc.py:107-114, mechanistic_challenge.py:88-95 */
+typedef struct slode_group {
+  int32_t z_off, z_dim; /* latent dims [z_off, z_off + z_dim) */
+  int32_t u_off, u_dim; /* label columns [u_off, u_off + u_dim) of u[B, n_u] */
+} slode_group;
+
+typedef struct slode_shape {
+  int32_t B;  /* trajectories in this call (per GPU)                                   */
+  int32_t T;  /* time points (len(times))                                              */
+  int32_t C;  /* observed channels, config.obs_dim                                      */
+  int32_t L;  /* latent dim = sum of z_*_dim                                           */
+  int32_t S;  /* config.ode_state_dim                                                  */
+  int32_t H;  /* config.ode_hidden_dim                                                 */
+  int32_t F;  /* config.n_filters                                                      */
+  int32_t K;  /* config.filter_size                                                    */
+  int32_t P;  /* config.pool_size                                                      */
+  int32_t Hc; /* config.cnn_hidden_dim                                                 */
+  int32_t n_u;      /* label columns of u                                              */
+  int32_t n_groups; /* conditional prior groups; remaining latent dims are N(0, 1)     */
+  slode_group groups[SLODE_MAX_GROUPS];
+  int32_t method;     /* slode_method                                                  */
+  int32_t likelihood; /* slode_likelihood                                              */
+  float quantile_diff; /* config.quantile_diff (ALD only), data/cvs/config_cvs.py:48    */
+  float rtol, atol;    /* dopri5 only (torchdiffeq defaults 1e-7 / 1e-9)                */
+} slode_shape;
+
+/* Offsets (in floats) of each parameter tensor inside the flat parameter / gradient vector.
+ * Names are the reference state_dict keys they hold. */
+typedef struct slode_layout {
+  int32_t conv_w, conv_b;   /* encoder.conv.{weight[F,C,K], bias[F]}          encoder_conv.py:31 */
+  int32_t lin_w, lin_b;     /* encoder.lin.{weight[Hc,F*n_pool], bias[Hc]}    encoder_conv.py:34 */
+  int32_t zloc_w, zloc_b;   /* encoder.z_loc.{weight[L,Hc], bias[L]}          encoder_conv.py:37 */
+  int32_t zls_w, zls_b;     /* encoder.z_scale.0.{weight[L,Hc], bias[L]}      encoder_conv.py:38 */
+  int32_t ode_begin;        /* start of the segment the fused ODE/ELBO kernel differentiates      */
+  int32_t ploc_w[SLODE_MAX_GROUPS], ploc_b[SLODE_MAX_GROUPS]; /* <prior>.sequential_mlp.1.0.0.*      */
+  int32_t pls_w[SLODE_MAX_GROUPS], pls_b[SLODE_MAX_GROUPS];   /* <prior>.sequential_mlp.1.1.0.*      */
+  int32_t init_w1, init_b1; /* decoder.ode_model.latent_to_ode_net.0.{weight[H,L], bias[H]}          */
+  int32_t init_w2, init_b2; /* decoder.ode_model.latent_to_ode_net.2.{weight[S,H], bias[S]}          */
+  int32_t dyn_wh, dyn_bh;   /* ...dynamics.dynamics_hidden.{weight[H,1+L], bias[H]} (col 0 = time)   */
+  int32_t dyn_wg, dyn_bg;   /* ...dynamics.dyanamics_growth.{weight[S,H], bias[S]}                   */
+  int32_t dyn_wd, dyn_bd;   /* ...dynamics.dyanmics_degradation.{weight[S,H], bias[S]}               */
+  int32_t head_w[SLODE_MAX_HEADS]; /* decoder.output_{q50,q75,q25}.0.weight[C,S] | output_mean (Gauss) */
+  int32_t cstd;             /* decoder.constant_std[C,T]                                             */
+  int32_t ode_end;          /* end of that segment                                                   */
+  int32_t n_params;         /* total floats covered by this layout; callers may append their own      */
+} slode_layout;
+
+typedef struct slode_ctx* slode_handle;
+
+int slode_version(void);
+/* device_id >= 0: HIP device ordinal.  There is no CPU backend: a process without a gfx950 device gets SLODE_EHIP. */
+int slode_create(slode_handle* h, int device_id);
+int slode_destroy(slode_handle h);
+const char* slode_last_error(slode_handle h); /* valid until the next call on h; h may be NULL (global text) */
+
+/* Validates `s` (SLODE_EINVAL on unsupported dimensions) and fills the canonical layout. */
+int slode_layout_init(const slode_shape* s, slode_layout* lay);
+/* Number of stage times the fixed-grid method evaluates: R*(T-1)+1 (R = 1/2/3 for euler/midpoint/rk4). */
+int slode_num_stage_times(const slode_shape* s);
+/* Bytes of caller workspace needed by slode_elbo_step / the *_bwd ops for this shape. */
+size_t slode_workspace_bytes(slode_handle h, const slode_shape* s);
+
+/* Stage-time table: the distinct times at which the fixed-grid solver evaluates f, computed on device with the
+ * same fp32 arithmetic as torchdiffeq's step functions (t0 + dt/3, ...).  Replaces the time bookkeeping inside
+ * torchdiffeq.odeint for the call at models/blackbox_ode.py:41-45.  times[T] -> stage_t[slode_num_stage_times]. */
+int slode_stage_times(slode_handle h, const slode_shape* s, const float* times, float* stage_t, void* stream);
+
+/* EncoderCONV.forward (models/encoder_conv.py:43-51): obs (logical [B,C,T], strides in elements) -> loc, scale [B,L].
+ * `pooled` [B, F*n_pool] and `hid` [B, Hc] are saved for the backward (either may be NULL for inference). */
+int slode_encoder_conv_fwd(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params,
+                           const float* obs, const int64_t obs_strides[3], float* loc, float* scale,
+                           float* pooled, float* hid, void* stream);
+
+/* Backward of EncoderCONV.forward: (g_loc, g_scale) [B,L] -> grads[conv_w .. zls_b] (overwritten, not accumulated). */
+int slode_encoder_conv_bwd(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params,
+                           const float* obs, const int64_t obs_strides[3], const float* scale,
+                           const float* pooled, const float* hid, const float* g_loc, const float* g_scale,
+                           float* grads, void* workspace, size_t workspace_bytes, void* stream);
+
+/* OdeModel.solve_ODE (models/blackbox_ode.py:36-47): z[B,L] -> x[B,T,S] (contiguous; the reference returns the
+ * same logical tensor as a permuted view).  stage_t from slode_stage_times. */
+int slode_ode_solve_fwd(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params,
+                        const float* times, const float* stage_t, const float* z, float* x, void* stream);
+
+/* Exact discrete adjoint of slode_ode_solve_fwd (== autograd through torchdiffeq.odeint, adjoint_solver=False):
+ * g_x[B,T,S] -> g_z[B,L] and grads[init_w1 .. dyn_bd] (overwritten). */
+int slode_ode_solve_bwd(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params,
+                        const float* times, const float* stage_t, const float* z, const float* g_x,
+                        float* g_z, float* grads, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Decoder.forward / GaussianDecoder.forward heads (models/decoders.py:45-53, 86-89) on a given trajectory:
+ * x[B,T,S] -> mu[Q][B,C,T] (Q = 3: mu_50, mu_75, mu_25 in that order; Q = 1: mean) and std[C,T] = softplus(constant_std). */
+int slode_decode_heads(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params,
+                       const float* x, float* mu, float* std_ct, void* stream);
+
+/* One SVI step's arithmetic for the main loss (pyro SVI.step on (model, guide); call sites training_cvs.py:152,236;
+ * models/mechanistic_cvs.py:105-238 and the proc/challenge equivalents):
+ *   encoder -> z = loc + scale*eps -> log q, log p -> ODE solve -> heads -> ALD/Gauss likelihood -> -ELBO (summed
+ *   over the batch) -> exact gradient wrt every parameter of the layout.
+ * Outputs: loss_out[0] = -ELBO (float, device); grads[0 .. lay->n_params) overwritten.
+ * With grads == NULL only the loss is computed (SVI.evaluate_loss, training_cvs.py:81).
+ * Optional outputs (NULL to skip): x_out[B,T,S] latent trajectories, z_out[B,L]. */
+int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params,
+                    const float* times, const float* stage_t, const float* obs, const int64_t obs_strides[3],
+                    const float* u, const float* eps, float* loss_out, float* grads, float* x_out, float* z_out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* torch.optim.Adam step as pyro.optim.Adam applies it per parameter (training_cvs.py:226-227): in-place on flat
+ * buffers.  step = 1-based step count. */
+int slode_adam_step(slode_handle h, int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                    float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLODE_H */

@@ -1,0 +1,77 @@
+"""ctypes binding of libslode.so (include/slode.h).  The product path has NO fallback: if the shared library is
+missing or no gfx950 device is visible, importing the engine / creating a handle raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslode.so")
+
+MAX_GROUPS, MAX_HEADS = 4, 3
+EULER, MIDPOINT, RK4, DOPRI5 = 0, 1, 2, 3
+ALD, GAUSS = 0, 1
+METHODS = {"euler": EULER, "midpoint": MIDPOINT, "rk4": RK4, "dopri5": DOPRI5}
+
+
+class Group(C.Structure):
+    _fields_ = [("z_off", C.c_int32), ("z_dim", C.c_int32), ("u_off", C.c_int32), ("u_dim", C.c_int32)]
+
+
+class Shape(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "T", "C", "L", "S", "H", "F", "K", "P", "Hc", "n_u", "n_groups")] + [
+        ("groups", Group * MAX_GROUPS), ("method", C.c_int32), ("likelihood", C.c_int32),
+        ("quantile_diff", C.c_float), ("rtol", C.c_float), ("atol", C.c_float)]
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("conv_w", "conv_b", "lin_w", "lin_b", "zloc_w", "zloc_b", "zls_w", "zls_b",
+                                          "ode_begin")] + [
+        ("ploc_w", C.c_int32 * MAX_GROUPS), ("ploc_b", C.c_int32 * MAX_GROUPS),
+        ("pls_w", C.c_int32 * MAX_GROUPS), ("pls_b", C.c_int32 * MAX_GROUPS)] + [
+        (n, C.c_int32) for n in ("init_w1", "init_b1", "init_w2", "init_b2", "dyn_wh", "dyn_bh", "dyn_wg", "dyn_bg",
+                                 "dyn_wd", "dyn_bd")] + [
+        ("head_w", C.c_int32 * MAX_HEADS), ("cstd", C.c_int32), ("ode_end", C.c_int32), ("n_params", C.c_int32)]
+
+
+EXPORTS = ["slode_version", "slode_create", "slode_destroy", "slode_last_error", "slode_layout_init",
+           "slode_num_stage_times", "slode_workspace_bytes", "slode_stage_times", "slode_encoder_conv_fwd",
+           "slode_encoder_conv_bwd", "slode_ode_solve_fwd", "slode_ode_solve_bwd", "slode_decode_heads",
+           "slode_elbo_step", "slode_adam_step"]
+
+_lib = None
+
+
+class SlodeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libslode.so (built by ``__graft_entry__.build()`` / ``make -C structured_latent_odes_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SlodeError("libslode.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+                         "there is no CPU/PyTorch fallback for the hot path" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    P, VP, I64P = C.POINTER, C.c_void_p, C.POINTER(C.c_int64)
+    lib.slode_version.restype = C.c_int
+    lib.slode_create.argtypes = [P(VP), C.c_int]
+    lib.slode_destroy.argtypes = [VP]
+    lib.slode_last_error.argtypes = [VP]
+    lib.slode_last_error.restype = C.c_char_p
+    lib.slode_layout_init.argtypes = [P(Shape), P(Layout)]
+    lib.slode_num_stage_times.argtypes = [P(Shape)]
+    lib.slode_workspace_bytes.argtypes = [VP, P(Shape)]
+    lib.slode_workspace_bytes.restype = C.c_size_t
+    lib.slode_stage_times.argtypes = [VP, P(Shape), VP, VP, VP]
+    lib.slode_encoder_conv_fwd.argtypes = [VP, P(Shape), P(Layout), VP, VP, I64P, VP, VP, VP, VP, VP]
+    lib.slode_encoder_conv_bwd.argtypes = [VP, P(Shape), P(Layout), VP, VP, I64P, VP, VP, VP, VP, VP, VP, VP, C.c_size_t, VP]
+    lib.slode_ode_solve_fwd.argtypes = [VP, P(Shape), P(Layout), VP, VP, VP, VP, VP, VP]
+    lib.slode_ode_solve_bwd.argtypes = [VP, P(Shape), P(Layout), VP, VP, VP, VP, VP, VP, VP, VP, C.c_size_t, VP]
+    lib.slode_decode_heads.argtypes = [VP, P(Shape), P(Layout), VP, VP, VP, VP, VP]
+    lib.slode_elbo_step.argtypes = [VP, P(Shape), P(Layout), VP, VP, VP, VP, I64P, VP, VP, VP, VP, VP, VP, VP, C.c_size_t, VP]
+    lib.slode_adam_step.argtypes = [VP, C.c_int64, VP, VP, VP, VP, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, VP]
+    for name in EXPORTS:
+        getattr(lib, name)  # AttributeError here == the ABI in include/slode.h is not fully exported
+    _lib = lib
+    return lib

@@ -1,0 +1,425 @@
+// EncoderCONV forward / backward for gfx950 (MI355X).
+//
+// Replaces models/encoder_conv.py:43-51 (forward) and autograd's backward through it:
+//   conv1d(C->F, k=K, valid) -> avg_pool1d(P, stride 1) -> flatten (filter-major) -> Linear(F*n_pool -> Hc) -> tanh
+//   -> z_loc Linear(Hc -> L), z_scale = exp(Linear(Hc -> L)).
+//
+// Layout: observations are read through element strides of the logical [B,C,T] tensor, so the reference's
+// permuted view of a contiguous [B,T,C] batch (training_cvs.py:25) is consumed in place.  One workgroup owns a
+// tile of TBE trajectories; the observation tile, the conv output and the pooled features live in LDS; the
+// 374 KB lin.weight is streamed once per tile from L2 with coalesced row reads and shared by the TBE trajectories.
+// The backward's lin.weight gradient (the only real GEMM on the path: [Hc x B] x [B x F*n_pool]) runs on the
+// f32 MFMA (v_mfma_f32_32x32x2_f32) with operands loaded straight from HBM in their natural row-major layout.
+#include "slode_common.h"
+
+typedef const __attribute__((address_space(4))) float* cptr;
+
+namespace {
+
+constexpr int TBE = 4;       // trajectories per workgroup
+constexpr int ENC_NT = 512;  // threads per workgroup
+constexpr int RB = 4;        // lin rows per wave pass
+
+struct EncK {
+  int B, T, C, L, F, K, P, Hc, n_conv, n_pool, FQ;
+  const float *conv_w, *conv_b, *lin_w, *lin_b, *zloc_w, *zloc_b, *zls_w, *zls_b;
+  const float* obs;
+  long long sb, sc, st;
+  float *loc, *scale, *pooled, *hid;
+  // backward
+  const float *scale_in, *pooled_in, *hid_in, *g_loc, *g_scale;
+  float *g_pre, *slabs;
+  int small_stride;
+};
+
+__device__ __forceinline__ void load_obs_tile(const EncK& k, int b0, float* s_x) {
+  // s_x[tb][c][t]; iterate in memory order of the source for coalescing
+  const int CT = k.C * k.T;
+  for (int e = threadIdx.x; e < TBE * CT; e += blockDim.x) {
+    const int tb = e / CT, r = e - tb * CT;
+    int c, t;
+    if (k.sc < k.st) { t = r / k.C; c = r - t * k.C; } else { c = r / k.T; t = r - c * k.T; }
+    const int b = b0 + tb;
+    s_x[(tb * k.C + c) * k.T + t] = (b < k.B) ? k.obs[(long long)b * k.sb + (long long)c * k.sc + (long long)t * k.st] : 0.f;
+  }
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------
+template <int C, int K>
+__global__ void __launch_bounds__(ENC_NT) enc_fwd_kernel(const EncK k) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int T = k.T, F = k.F, n_conv = k.n_conv, n_pool = k.n_pool, FQ = k.FQ, Hc = k.Hc, L = k.L;
+  float* s_x = smem;                               // [TBE][C][T]
+  float* s_conv = s_x + TBE * C * T;               // [TBE][F][n_conv]
+  float* s_pool = s_conv + TBE * F * n_conv;       // [TBE][FQ]
+  float* s_hid = s_pool + TBE * FQ;                // [TBE][64]
+  const int b0 = blockIdx.x * TBE;
+
+  load_obs_tile(k, b0, s_x);
+  __syncthreads();
+  // conv: one thread per (tb, p); the K-window of every channel in registers, filter taps as SGPR operands
+  const cptr cw = (cptr)k.conv_w, cb = (cptr)k.conv_b;
+  for (int e = tid; e < TBE * n_conv; e += NT) {
+    const int tb = e / n_conv, p = e - tb * n_conv;
+    float xw[C][K];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) xw[c][kk] = s_x[(tb * C + c) * T + p + kk];
+    for (int f = 0; f < F; ++f) {
+      float acc = cb[f];
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) acc = fmaf(cw[(f * C + c) * K + kk], xw[c][kk], acc);
+      s_conv[(tb * F + f) * n_conv + p] = acc;
+    }
+  }
+  __syncthreads();
+  // average pool, stride 1 (sum / P as ATen's avg_pool does), filter-major flatten
+  const float fP = (float)k.P;
+  for (int e = tid; e < TBE * FQ; e += NT) {
+    const int tb = e / FQ, i = e - tb * FQ;
+    const int f = i / n_pool, q = i - f * n_pool;
+    float sum = 0.f;
+    for (int j = 0; j < k.P; ++j) sum += s_conv[(tb * F + f) * n_conv + q + j];
+    const float v = sum / fP;
+    s_pool[tb * FQ + i] = v;
+    if (k.pooled && b0 + tb < k.B) k.pooled[(long long)(b0 + tb) * FQ + i] = v;
+  }
+  __syncthreads();
+  // lin + tanh: each wave streams RB rows of lin.weight (coalesced) against the TBE pooled vectors in LDS
+  {
+    const int wave = tid >> 6, lane = tid & 63, nw = NT >> 6;
+    const int ngroups = (Hc + RB - 1) / RB;
+    for (int g = wave; g < ngroups; g += nw) {
+      const int m0 = g * RB;
+      float acc[RB][TBE];
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int tb = 0; tb < TBE; ++tb) acc[r][tb] = 0.f;
+      for (int i = lane; i < FQ; i += 64) {
+        float pv[TBE];
+#pragma unroll
+        for (int tb = 0; tb < TBE; ++tb) pv[tb] = s_pool[tb * FQ + i];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int m = min(m0 + r, Hc - 1);
+          const float w = k.lin_w[(long long)m * FQ + i];
+#pragma unroll
+          for (int tb = 0; tb < TBE; ++tb) acc[r][tb] = fmaf(w, pv[tb], acc[r][tb]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int tb = 0; tb < TBE; ++tb) {
+          const float v = wave_sum(acc[r][tb]);
+          if (lane == 0 && m0 + r < Hc) {
+            const float hv = tanhf(v + k.lin_b[m0 + r]);
+            s_hid[tb * 64 + m0 + r] = hv;
+            if (k.hid && b0 + tb < k.B) k.hid[(long long)(b0 + tb) * Hc + m0 + r] = hv;
+          }
+        }
+    }
+  }
+  __syncthreads();
+  // heads: z_loc, z_scale = exp(.)
+  for (int e = tid; e < TBE * L * 2; e += NT) {
+    const int which = e / (TBE * L), r = e - which * (TBE * L);
+    const int tb = r / L, l = r - tb * L;
+    const float* W = which ? k.zls_w : k.zloc_w;
+    float acc = which ? k.zls_b[l] : k.zloc_b[l];
+    for (int mm = 0; mm < Hc; ++mm) acc = fmaf(W[l * Hc + mm], s_hid[tb * 64 + mm], acc);
+    if (b0 + tb < k.B) {
+      if (which) k.scale[(long long)(b0 + tb) * L + l] = expf(acc);
+      else k.loc[(long long)(b0 + tb) * L + l] = acc;
+    }
+  }
+}
+
+// ---- backward, part 1: heads, tanh, lin^T, pool^T, conv weight gradient -----------------------------------
+// small slab layout: [conv_w F*C*K][conv_b F][lin_b Hc][zloc_w L*Hc][zloc_b L][zls_w L*Hc][zls_b L]
+template <int C, int K>
+__global__ void __launch_bounds__(ENC_NT) enc_bwd_kernel(const EncK k) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int T = k.T, F = k.F, n_conv = k.n_conv, n_pool = k.n_pool, FQ = k.FQ, Hc = k.Hc, L = k.L;
+  float* s_x = smem;                            // [TBE][C][T]
+  float* s_gpool = s_x + TBE * C * T;           // [TBE][FQ]     (later: cross-wave reduction scratch)
+  float* s_gconv = s_gpool + TBE * FQ;          // [TBE][F][n_conv]
+  float* s_gpre = s_gconv + TBE * F * n_conv;   // [64][TBE]     (m-major so one b128 read feeds the TBE FMAs)
+  float* s_hid = s_gpre + 64 * TBE;             // [TBE][64]
+  float* s_gl = s_hid + TBE * 64;               // [TBE][L]  g_loc
+  float* s_gs = s_gl + TBE * L;                 // [TBE][L]  g_scale * scale
+  const int b0 = blockIdx.x * TBE;
+  float* slab = k.slabs + (long long)blockIdx.x * k.small_stride;
+  const int o_convw = 0, o_convb = F * C * K, o_linb = o_convb + F, o_zlw = o_linb + Hc, o_zlb = o_zlw + L * Hc,
+            o_zsw = o_zlb + L, o_zsb = o_zsw + L * Hc;
+
+  load_obs_tile(k, b0, s_x);
+  for (int e = tid; e < TBE * L; e += NT) {
+    const int tb = e / L, l = e - tb * L, b = b0 + tb;
+    const bool ok = b < k.B;
+    s_gl[e] = ok ? k.g_loc[(long long)b * L + l] : 0.f;
+    s_gs[e] = ok ? k.g_scale[(long long)b * L + l] * k.scale_in[(long long)b * L + l] : 0.f;
+  }
+  for (int e = tid; e < TBE * 64; e += NT) {
+    const int tb = e >> 6, mm = e & 63, b = b0 + tb;
+    s_hid[e] = (b < k.B && mm < Hc) ? k.hid_in[(long long)b * Hc + mm] : 0.f;
+  }
+  __syncthreads();
+  // through the heads and tanh
+  for (int e = tid; e < TBE * 64; e += NT) {
+    const int tb = e >> 6, mm = e & 63;
+    float g = 0.f;
+    if (mm < Hc) {
+      for (int l = 0; l < L; ++l) {
+        g = fmaf(k.zloc_w[l * Hc + mm], s_gl[tb * L + l], g);
+        g = fmaf(k.zls_w[l * Hc + mm], s_gs[tb * L + l], g);
+      }
+      const float hv = s_hid[tb * 64 + mm];
+      g *= (1.f - hv * hv);
+    }
+    s_gpre[mm * TBE + tb] = g;
+    if (b0 + tb < k.B) k.g_pre[(long long)(b0 + tb) * 64 + mm] = g;
+  }
+  // head weight / bias partials (sum over the tile's trajectories)
+  for (int e = tid; e < L * Hc; e += NT) {
+    const int l = e / Hc, mm = e - l * Hc;
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int tb = 0; tb < TBE; ++tb) {
+      a1 = fmaf(s_gl[tb * L + l], s_hid[tb * 64 + mm], a1);
+      a2 = fmaf(s_gs[tb * L + l], s_hid[tb * 64 + mm], a2);
+    }
+    slab[o_zlw + e] = a1;
+    slab[o_zsw + e] = a2;
+  }
+  for (int l = tid; l < L; l += NT) {
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int tb = 0; tb < TBE; ++tb) { a1 += s_gl[tb * L + l]; a2 += s_gs[tb * L + l]; }
+    slab[o_zlb + l] = a1;
+    slab[o_zsb + l] = a2;
+  }
+  __syncthreads();
+  for (int mm = tid; mm < Hc; mm += NT) {
+    float a = 0.f;
+#pragma unroll
+    for (int tb = 0; tb < TBE; ++tb) a += s_gpre[mm * TBE + tb];
+    slab[o_linb + mm] = a;
+  }
+  // g_pooled[tb][i] = sum_m g_pre[tb][m] * lin_w[m][i]   (thread <-> i, coalesced rows of lin_w)
+  for (int i = tid; i < FQ; i += NT) {
+    float acc[TBE];
+#pragma unroll
+    for (int tb = 0; tb < TBE; ++tb) acc[tb] = 0.f;
+    for (int mm = 0; mm < Hc; ++mm) {
+      const float w = k.lin_w[(long long)mm * FQ + i];
+      const float4 g = *reinterpret_cast<const float4*>(s_gpre + mm * TBE);
+      acc[0] = fmaf(g.x, w, acc[0]); acc[1] = fmaf(g.y, w, acc[1]);
+      acc[2] = fmaf(g.z, w, acc[2]); acc[3] = fmaf(g.w, w, acc[3]);
+    }
+#pragma unroll
+    for (int tb = 0; tb < TBE; ++tb) s_gpool[tb * FQ + i] = acc[tb];
+  }
+  __syncthreads();
+  // pool^T: g_conv[p] = (1/P) * sum_{q in [p-P+1, p] ∩ [0, n_pool)} g_pooled[q]
+  const float fP = (float)k.P;
+  for (int e = tid; e < TBE * F * n_conv; e += NT) {
+    const int p = e % n_conv, tf = e / n_conv;  // tf = tb*F + f
+    const int tb = tf / F, f = tf - tb * F;
+    float sum = 0.f;
+    for (int j = 0; j < k.P; ++j) {
+      const int q = p - j;
+      if (q >= 0 && q < n_pool) sum += s_gpool[tb * FQ + f * n_pool + q];
+    }
+    s_gconv[e] = sum / fP;
+  }
+  __syncthreads();
+  // conv weight gradient: lane f = tid % 16, slot = tid / 16 walks (tb, block of 8 output positions)
+  {
+    constexpr int PB = 8;
+    const int f = tid & 15, slot = tid >> 4, nslot = NT >> 4;
+    const int nblk = (n_conv + PB - 1) / PB;
+    float acc[C][K], accb = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) acc[c][kk] = 0.f;
+    if (f < F) {
+      for (int it = slot; it < TBE * nblk; it += nslot) {
+        const int tb = it / nblk, p0 = (it - tb * nblk) * PB;
+        float G[PB];
+#pragma unroll
+        for (int dp = 0; dp < PB; ++dp) {
+          G[dp] = (p0 + dp < n_conv) ? s_gconv[(tb * F + f) * n_conv + p0 + dp] : 0.f;
+          accb += G[dp];
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          float X[PB + K - 1];
+#pragma unroll
+          for (int j = 0; j < PB + K - 1; ++j) X[j] = (p0 + j < T) ? s_x[(tb * C + c) * T + p0 + j] : 0.f;
+#pragma unroll
+          for (int kk = 0; kk < K; ++kk)
+#pragma unroll
+            for (int dp = 0; dp < PB; ++dp) acc[c][kk] = fmaf(G[dp], X[dp + kk], acc[c][kk]);
+        }
+      }
+    }
+    // lanes l, l^16, l^32 share f inside a wave; then a fixed-order sum over waves through LDS
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int kk = 0; kk < K; ++kk) {
+        float v = acc[c][kk];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        acc[c][kk] = v;
+      }
+    accb += __shfl_xor(accb, 16, 64);
+    accb += __shfl_xor(accb, 32, 64);
+    __syncthreads();  // s_gpool is free now
+    float* s_red = s_gpool;  // [nw][16][C*K+1]
+    const int wave = tid >> 6, lane = tid & 63, nw = NT >> 6;
+    if (lane < 16) {
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) s_red[(wave * 16 + lane) * (C * K + 1) + c * K + kk] = acc[c][kk];
+      s_red[(wave * 16 + lane) * (C * K + 1) + C * K] = accb;
+    }
+    __syncthreads();
+    for (int e = tid; e < F * (C * K + 1); e += NT) {
+      const int ff = e / (C * K + 1), r = e - ff * (C * K + 1);
+      float v = 0.f;
+      for (int w = 0; w < nw; ++w) v += s_red[(w * 16 + ff) * (C * K + 1) + r];
+      if (r < C * K) slab[o_convw + ff * C * K + r] = v;
+      else slab[o_convb + ff] = v;
+    }
+  }
+}
+
+// ---- backward, part 2: lin.weight gradient on the f32 matrix cores -----------------------------------------
+// g_W[m][i] = sum_b g_pre[b][m] * pooled[b][i].  v_mfma_f32_32x32x2_f32: A[i=m][k=b], B[k=b][j=i]; both operands are
+// rows of row-major HBM arrays, so lane (l&31, l>>5) loads element [b0 + (l>>5)][base + (l&31)] directly (coalesced).
+// Workgroup = 4 waves = 4 K-splits of one 64(m) x 32(i) output tile, reduced in LDS; grid = (i-tiles, splitk_grid).
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restrict__ g_pre, const float* __restrict__ pooled,
+                                                          float* __restrict__ slabs, int B, int Hc, int FQ, int per_wave) {
+  __shared__ float s_part[4 * 32 * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i0 = blockIdx.x * 32;
+  const int ks = blockIdx.y * 4 + wave;
+  const int bbeg = ks * per_wave, bend = min(B, bbeg + per_wave);
+  const int col = lane & 31, kh = lane >> 5;
+  const bool col_ok = i0 + col < FQ;
+  f32x16 acc0 = {0}, acc1 = {0};
+  for (int bb = bbeg; bb < bend; bb += 2) {
+    const int b = bb + kh;
+    const bool ok = b < bend;
+    const float a0 = ok ? g_pre[(long long)b * 64 + col] : 0.f;
+    const float a1 = ok ? g_pre[(long long)b * 64 + 32 + col] : 0.f;
+    const float bv = (ok && col_ok) ? pooled[(long long)b * FQ + i0 + col] : 0.f;
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    s_part[(wave * 32 + r) * 64 + lane] = acc0[r];
+    s_part[(wave * 32 + 16 + r) * 64 + lane] = acc1[r];
+  }
+  __syncthreads();
+  float* slab = slabs + (long long)blockIdx.y * Hc * FQ;
+  for (int e = tid; e < 32 * 64; e += 256) {
+    const int reg = e >> 6, ln = e & 63;
+    const float v = (s_part[(0 * 32 + reg) * 64 + ln] + s_part[(1 * 32 + reg) * 64 + ln]) +
+                    (s_part[(2 * 32 + reg) * 64 + ln] + s_part[(3 * 32 + reg) * 64 + ln]);
+    const int r16 = reg & 15, tile = reg >> 4;
+    const int m = tile * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (ln >> 5);  // C/D map of the 32x32 MFMA
+    const int i = i0 + (ln & 31);
+    if (m < Hc && i < FQ) slab[(long long)m * FQ + i] = v;
+  }
+}
+
+EncK make_enck(const slode_shape& s, const slode_layout& lay, const float* p) {
+  EncK k{};
+  k.B = s.B; k.T = s.T; k.C = s.C; k.L = s.L; k.F = s.F; k.K = s.K; k.P = s.P; k.Hc = s.Hc;
+  k.n_conv = s.T - s.K + 1; k.n_pool = k.n_conv - s.P + 1; k.FQ = s.F * k.n_pool;
+  k.conv_w = p + lay.conv_w; k.conv_b = p + lay.conv_b; k.lin_w = p + lay.lin_w; k.lin_b = p + lay.lin_b;
+  k.zloc_w = p + lay.zloc_w; k.zloc_b = p + lay.zloc_b; k.zls_w = p + lay.zls_w; k.zls_b = p + lay.zls_b;
+  return k;
+}
+
+size_t enc_fwd_lds(const EncK& k) {
+  return sizeof(float) * ((size_t)TBE * k.C * k.T + (size_t)TBE * k.F * k.n_conv + (size_t)TBE * k.FQ + TBE * 64);
+}
+size_t enc_bwd_lds(const EncK& k) {
+  size_t gpool = (size_t)TBE * k.FQ;
+  const size_t red = (size_t)(ENC_NT / 64) * 16 * (k.C * k.K + 1);
+  if (red > gpool) gpool = red;
+  return sizeof(float) * ((size_t)TBE * k.C * k.T + gpool + (size_t)TBE * k.F * k.n_conv + 64 * TBE + TBE * 64 +
+                          2 * (size_t)TBE * k.L);
+}
+
+}  // namespace
+
+int slode_enc_small_count(const slode_shape& s) { return s.F * s.C * s.K + s.F + s.Hc + 2 * (s.L * s.Hc + s.L); }
+int slode_enc_bwd_grid(const slode_shape& s) { return (s.B + TBE - 1) / TBE; }
+int slode_enc_lin_splitk(const slode_shape& s) {
+  int g = (s.B + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 16) g = 16;
+  return g;
+}
+
+hipError_t slode_launch_enc_fwd(const EncLaunch& a, hipStream_t stream) {
+  EncK k = make_enck(a.s, a.lay, a.params);
+  k.obs = a.obs; k.sb = a.sb; k.sc = a.sc; k.st = a.st;
+  k.loc = a.loc; k.scale = a.scale; k.pooled = a.pooled; k.hid = a.hid;
+  const size_t lds = enc_fwd_lds(k);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const int grid = (a.s.B + TBE - 1) / TBE;
+  if (a.s.C == 3 && a.s.K == 10) {
+    hipFuncSetAttribute((const void*)enc_fwd_kernel<3, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((enc_fwd_kernel<3, 10>), dim3(grid), dim3(ENC_NT), lds, stream, k);
+  } else if (a.s.C == 4 && a.s.K == 10) {
+    hipFuncSetAttribute((const void*)enc_fwd_kernel<4, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((enc_fwd_kernel<4, 10>), dim3(grid), dim3(ENC_NT), lds, stream, k);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream) {
+  EncK k = make_enck(a.s, a.lay, a.params);
+  k.obs = a.obs; k.sb = a.sb; k.sc = a.sc; k.st = a.st;
+  k.scale_in = a.scale; k.pooled_in = a.pooled; k.hid_in = a.hid; k.g_loc = a.g_loc; k.g_scale = a.g_scale;
+  k.g_pre = a.g_pre; k.slabs = a.slabs_small; k.small_stride = a.small_stride;
+  const size_t lds = enc_bwd_lds(k);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (a.s.C == 3 && a.s.K == 10) {
+    hipFuncSetAttribute((const void*)enc_bwd_kernel<3, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((enc_bwd_kernel<3, 10>), dim3(a.grid_small), dim3(ENC_NT), lds, stream, k);
+  } else if (a.s.C == 4 && a.s.K == 10) {
+    hipFuncSetAttribute((const void*)enc_bwd_kernel<4, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((enc_bwd_kernel<4, 10>), dim3(a.grid_small), dim3(ENC_NT), lds, stream, k);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  // lin.weight gradient (MFMA split-K); consumes g_pre written by the kernel above (same stream => ordered)
+  const int total_splits = a.splitk * 4;
+  int per_wave = (a.s.B + total_splits - 1) / total_splits;
+  per_wave = (per_wave + 1) & ~1;
+  hipLaunchKernelGGL(enc_bwd_lin_kernel, dim3((k.FQ + 31) / 32, a.splitk), dim3(256), 0, stream, a.g_pre, a.pooled,
+                     a.slabs_lin, a.s.B, a.s.Hc, k.FQ, per_wave);
+  return hipGetLastError();
+}

@@ -1,0 +1,154 @@
+// Small kernels around the hot path: stage-time table, fixed-order slab reduction, decoder heads, Adam.
+#include "slode_common.h"
+
+namespace {
+
+// Times at which the fixed-grid solvers evaluate f, with torchdiffeq's fp32 arithmetic (t0 + dt * c, separate
+// multiply and add: no FMA contraction).  Call site replaced: models/blackbox_ode.py:41-45.
+__global__ void stage_times_kernel(const float* __restrict__ times, float* __restrict__ out, int T, int method) {
+  const int R = method == SLODE_EULER ? 1 : (method == SLODE_MIDPOINT ? 2 : 3);
+  const int nt = R * (T - 1) + 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nt) return;
+  if (i == nt - 1) { out[i] = times[T - 1]; return; }
+  const int n = i / R, r = i - n * R;
+  const float t0 = times[n], dt = __fsub_rn(times[n + 1], t0);
+  float c = 0.f;
+  if (method == SLODE_MIDPOINT) c = 0.5f;
+  else if (method == SLODE_RK4) c = (r == 1) ? (float)(1.0 / 3.0) : (float)(2.0 / 3.0);
+  out[i] = (r == 0) ? t0 : __fadd_rn(t0, __fmul_rn(dt, c));
+}
+
+struct ReduceK {
+  const float* ode_slabs; int ode_stride, ode_n, nseg, ode_begin;
+  const float* small_slabs; int small_stride, small_n, small_count, n_conv_part, lin_b_off;
+  const float* lin_slabs; int lin_n, lin_count, lin_w_off;
+  float* grads; float* loss_out;
+  int n_params, zero_rest;
+};
+
+__device__ __forceinline__ float strided_sum(const float* p, int stride, int n) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int w = 0;
+  for (; w + 3 < n; w += 4) {
+    a0 += p[(long long)w * stride];
+    a1 += p[(long long)(w + 1) * stride];
+    a2 += p[(long long)(w + 2) * stride];
+    a3 += p[(long long)(w + 3) * stride];
+  }
+  for (; w < n; ++w) a0 += p[(long long)w * stride];
+  return (a0 + a1) + (a2 + a3);
+}
+
+// One thread per flat-gradient element; fixed summation order over slabs => bitwise reproducible.
+__global__ void reduce_kernel(const ReduceK k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && k.loss_out && k.ode_slabs) {
+    double acc = 0.0;
+    for (int w = 0; w < k.ode_n; ++w) acc += (double)k.ode_slabs[(long long)w * k.ode_stride];
+    k.loss_out[0] = (float)acc;
+  }
+  if (i >= k.n_params || k.grads == nullptr) return;
+  // which family owns flat element i?
+  if (k.ode_slabs && i >= k.ode_begin && i < k.ode_begin + k.nseg) {
+    k.grads[i] = strided_sum(k.ode_slabs + 1 + (i - k.ode_begin), k.ode_stride, k.ode_n);
+    return;
+  }
+  if (k.lin_slabs && i >= k.lin_w_off && i < k.lin_w_off + k.lin_count) {
+    k.grads[i] = strided_sum(k.lin_slabs + (i - k.lin_w_off), k.lin_count, k.lin_n);
+    return;
+  }
+  if (k.small_slabs) {
+    int j = -1;
+    if (i < k.n_conv_part) j = i;                                                       // conv_w, conv_b
+    else if (i >= k.lin_b_off && i < k.lin_b_off + (k.small_count - k.n_conv_part)) j = k.n_conv_part + (i - k.lin_b_off);
+    if (j >= 0) {
+      k.grads[i] = strided_sum(k.small_slabs + j, k.small_stride, k.small_n);
+      return;
+    }
+  }
+  if (k.zero_rest) k.grads[i] = 0.f;
+}
+
+// Decoder heads on a given trajectory tensor: models/decoders.py:45-47 (ALD: q50, q75, q25) / :86 (Gauss: mean),
+// and std = softplus(constant_std) (:52-53).  mu layout [Q][B][C][T].
+__global__ void decode_heads_kernel(const float* __restrict__ x, const float* __restrict__ params, int B, int T, int C, int S,
+                                    int Q, int h0, int h1, int h2, int cstd_off, float* __restrict__ mu, float* __restrict__ std_ct) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (long long)C * T && std_ct) std_ct[i] = softplusf(params[cstd_off + i]);
+  const long long total = (long long)Q * B * C * T;
+  if (i >= total) return;
+  const int t = i % T;
+  long long r = i / T;
+  const int c = r % C; r /= C;
+  const int b = r % B;
+  const int q = r / B;
+  const float* W = params + (q == 0 ? h0 : (q == 1 ? h1 : h2)) + c * S;
+  const float* xs = x + ((long long)b * T + t) * S;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc = fmaf(W[s], xs[s], acc);
+  mu[i] = acc;
+}
+
+// torch.optim.Adam single-tensor update (amsgrad=False, weight_decay=0, maximize=False) as applied per parameter by
+// pyro.optim.Adam (training_cvs.py:226-227): exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v + (1-b2) g*g;
+// denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m/denom.
+__global__ void adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, float step_size, float one_minus_b1, float b2, float one_minus_b2,
+                            float sqrt_bc2, float eps) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  float mi = m[i], vi = v[i];
+  mi = mi + one_minus_b1 * (gi - mi);
+  vi = vi * b2 + one_minus_b2 * gi * gi;
+  const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+  p[i] = p[i] - step_size * (mi / denom);
+  m[i] = mi;
+  v[i] = vi;
+}
+
+}  // namespace
+
+hipError_t slode_launch_stage_times(const slode_shape& s, const float* times, float* stage_t, hipStream_t stream) {
+  const int R = s.method == SLODE_EULER ? 1 : (s.method == SLODE_MIDPOINT ? 2 : 3);
+  const int nt = R * (s.T - 1) + 1;
+  hipLaunchKernelGGL(stage_times_kernel, dim3((nt + 255) / 256), dim3(256), 0, stream, times, stage_t, s.T, s.method);
+  return hipGetLastError();
+}
+
+hipError_t slode_launch_reduce(const ReduceLaunch& a, hipStream_t stream) {
+  ReduceK k{};
+  const slode_shape& s = a.s;
+  const int n_conv = s.T - s.K + 1, FQ = s.F * (n_conv - s.P + 1);
+  k.ode_slabs = a.ode_slabs; k.ode_stride = a.ode_stride; k.ode_n = a.ode_n;
+  k.nseg = a.lay.ode_end - a.lay.ode_begin; k.ode_begin = a.lay.ode_begin;
+  k.small_slabs = a.small_slabs; k.small_stride = a.small_stride; k.small_n = a.small_n;
+  k.small_count = slode_enc_small_count(s); k.n_conv_part = s.F * s.C * s.K + s.F; k.lin_b_off = a.lay.lin_b;
+  k.lin_slabs = a.lin_slabs; k.lin_n = a.lin_n; k.lin_count = s.Hc * FQ; k.lin_w_off = a.lay.lin_w;
+  k.grads = a.grads; k.loss_out = a.loss_out; k.n_params = a.lay.n_params; k.zero_rest = a.zero_rest;
+  const int n = a.grads ? a.lay.n_params : 1;
+  hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, k);
+  return hipGetLastError();
+}
+
+hipError_t slode_launch_decode_heads(const slode_shape& s, const slode_layout& lay, const float* params, const float* x,
+                                     float* mu, float* std_ct, hipStream_t stream) {
+  const int Q = s.likelihood == SLODE_GAUSS ? 1 : 3;
+  long long total = (long long)Q * s.B * s.C * s.T;
+  if (total < (long long)s.C * s.T) total = (long long)s.C * s.T;
+  hipLaunchKernelGGL(decode_heads_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, params, s.B, s.T,
+                     s.C, s.S, Q, lay.head_w[0], lay.head_w[1], lay.head_w[2], lay.cstd, mu, std_ct);
+  return hipGetLastError();
+}
+
+hipError_t slode_launch_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
+                             int64_t step, hipStream_t stream) {
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float sqrt_bc2 = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (long long)n, p, g, m, v, step_size,
+                     1.0f - b1, b2, 1.0f - b2, sqrt_bc2, eps);
+  return hipGetLastError();
+}

@@ -1,0 +1,743 @@
+// Fused latent-ODE solve + ELBO kernel for gfx950 (MI355X).
+//
+// Replaces, for one minibatch shard, the work the reference does in
+//   models/mechanistic_cvs.py:105-238 (model + guide: latent sample, priors, likelihood sites),
+//   models/decoders.py:42-54 / 84-91   (Decoder / GaussianDecoder forward),
+//   models/blackbox_ode.py:36-47,97-109 (OdeModel.solve_ODE over Dynamics.forward via torchdiffeq.odeint),
+// and autograd's backward through all of it (== adjoint_solver=False gradients).
+//
+// Design: ONE workgroup integrates ONE trajectory at a time (persistent loop over
+// b = blockIdx.x, += gridDim.x), with NT = roundup64(T) threads.
+//   * f(t,x) = a(t,z) - d(t,z) * x never reads the state inside the net (blackbox_ode.py:97-109), so a, d are
+//     evaluated for every stage time in PARALLEL (thread n owns grid step n: its R stage evaluations stay in
+//     registers from forward to backward), weights arriving as SGPR operands through the constant address space.
+//   * every fixed-grid step collapses to the affine map x' = A x + b; the T-1 long serial dependency chain is
+//     then one v_fma per step on S lanes (forward scan) and one v_fma per step for the adjoint (reverse scan).
+//   * the exact discrete adjoint of the step coefficients is evaluated back in the step-parallel layout; the
+//     weight-gradient contraction over (sample, hidden unit) runs in a hidden-unit-major layout (lane = hidden
+//     unit j, half-wave = chunk of samples) with register accumulators, staged through a 2S*T LDS buffer.
+//   * likelihood (asymmetric Laplace x3 quantile heads, or Gaussian), latent log-probs and all small-net
+//     gradients are fused in; per-workgroup partial gradients are accumulated in LDS across the workgroup's
+//     trajectories and written once as a slab (fixed-order reduction in misc_kernels.hip => bitwise reproducible).
+#include "slode_common.h"
+
+typedef const __attribute__((address_space(4))) float* cptr;  // uniform loads => s_load + SGPR operands
+
+namespace {
+
+struct OdeK {
+  int B, T, C, L, nu, ng, method, R, nt, Q, gauss;
+  int uses_next;  // rk4: k4 is evaluated at t1 == next step's first stage
+  slode_group grp[SLODE_MAX_GROUPS];
+  float tau[SLODE_MAX_HEADS];
+  const float *ploc_w[SLODE_MAX_GROUPS], *ploc_b[SLODE_MAX_GROUPS], *pls_w[SLODE_MAX_GROUPS], *pls_b[SLODE_MAX_GROUPS];
+  const float *w1, *b1, *w2, *b2, *wh, *bh, *wg, *bg, *wd, *bd, *head[SLODE_MAX_HEADS], *cstd;
+  // offsets relative to lay.ode_begin (accumulator / slab index = 1 + offset)
+  int o_ploc_w[SLODE_MAX_GROUPS], o_ploc_b[SLODE_MAX_GROUPS], o_pls_w[SLODE_MAX_GROUPS], o_pls_b[SLODE_MAX_GROUPS];
+  int o_w1, o_b1, o_w2, o_b2, o_wh, o_bh, o_wg, o_bg, o_wd, o_bd, o_head[SLODE_MAX_HEADS], o_cstd;
+  int nseg;
+  const float *times, *stage_t, *obs, *u, *eps, *loc, *scale, *z_in, *gx_in;
+  long long sb, sc, st;
+  float *x_out, *z_out, *g_loc, *g_scale, *slabs;
+  int slab_stride, backward, with_ll;
+};
+
+struct LdsMap {  // offsets in floats
+  int ts, dt, sig, A, x, lam, st, acc, z, gzl, gpl, gls, u, wt, pre0, hid0, x0, go, gp0, gu, gup, red, total;
+};
+
+__host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
+
+__host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int Q, int nt, int nseg, int nthreads) {
+  LdsMap m;
+  int o = 0;
+  m.ts = o; o += pad4(nt);
+  m.dt = o; o += pad4(T);
+  m.sig = o; o += pad4(C * T);
+  m.A = o; o += pad4(T * S);
+  m.x = o; o += pad4(T * S);
+  m.lam = o; o += pad4(T * S);
+  int stn = 2 * S * T; if (Q * C * T > stn) stn = Q * C * T;
+  const int eps_n = (nthreads / 32) * (2 * S + 1) * 32;  // epilogue chunk-reduction scratch
+  if (eps_n > stn) stn = eps_n;
+  m.st = o; o += pad4(stn);
+  m.acc = o; o += pad4(nseg + 1);
+  m.z = o; o += pad4(L);
+  m.gzl = o; o += pad4(L);
+  m.gpl = o; o += pad4(L);
+  m.gls = o; o += pad4(L);
+  m.u = o; o += 32;
+  m.wt = o; o += 32;
+  m.pre0 = o; o += 32;
+  m.hid0 = o; o += 32;
+  m.x0 = o; o += 8;
+  m.go = o; o += 8;
+  m.gp0 = o; o += 32;
+  m.gu = o; o += 32;
+  m.gup = o; o += (nthreads / 32) * 32;
+  m.red = o; o += 64;
+  m.total = o;
+  return m;
+}
+
+// a(t), d(t): models/blackbox_ode.py:97-109 with the z-part of the hidden pre-activation (s_u) hoisted.
+template <int S, int H>
+__device__ __forceinline__ void eval_ad(float t, const float* __restrict__ s_wt, const float* __restrict__ s_u,
+                                        cptr wg, cptr bg, cptr wd, cptr bd, float (&a)[S], float (&d)[S]) {
+  // keep the ~2*S*H weight s_loads local to this call: hoisting them across the trajectory loop costs >100 SGPRs
+  asm volatile("" : "+s"(wg), "+s"(wd), "+s"(bg), "+s"(bd));
+  const float* wt = (const float*)__builtin_assume_aligned(s_wt, 16);
+  const float* uu = (const float*)__builtin_assume_aligned(s_u, 16);
+  float h[H];
+#pragma unroll
+  for (int j = 0; j < H; ++j) h[j] = fmaxf(fmaf(wt[j], t, uu[j]), 0.f);
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    float xa = bg[s], xd = bd[s];
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      xa = fmaf(wg[s * H + j], h[j], xa);
+      xd = fmaf(wd[s * H + j], h[j], xd);
+    }
+    a[s] = sigmoidf_fast(xa);
+    d[s] = sigmoidf_fast(xd);
+  }
+}
+
+// Step coefficients x' = A x + b for one state component (tests/kernel_math.py::step_coeffs).
+// a*/d*: stage values; for rk4 index 3 is the next step's first stage.
+__device__ __forceinline__ void step_fwd(int method, float h, const float a[4], const float d[4], float& A, float& b) {
+  if (method == SLODE_EULER) {
+    A = 1.f - h * d[0];
+    b = h * a[0];
+  } else if (method == SLODE_MIDPOINT) {
+    const float m = 1.f - 0.5f * h * d[0], c = 0.5f * h * a[0];
+    A = 1.f - h * d[1] * m;
+    b = h * (a[1] - d[1] * c);
+  } else {
+    const float h3 = h * (1.0f / 3.0f);
+    const float p1 = a[0], q1 = -d[0];
+    const float c2 = h3 * p1, m2 = 1.f + h3 * q1;
+    const float p2 = a[1] - d[1] * c2, q2 = -d[1] * m2;
+    const float c3 = h * (p2 - p1 * (1.0f / 3.0f)), m3 = 1.f + h * (q2 - q1 * (1.0f / 3.0f));
+    const float p3 = a[2] - d[2] * c3, q3 = -d[2] * m3;
+    const float c4 = h * (p1 - p2 + p3), m4 = 1.f + h * (q1 - q2 + q3);
+    const float p4 = a[3] - d[3] * c4, q4 = -d[3] * m4;
+    const float G = h * 0.125f;
+    A = 1.f + G * (q1 + 3.f * (q2 + q3) + q4);
+    b = G * (p1 + 3.f * (p2 + p3) + p4);
+  }
+}
+
+// Reverse mode of step_fwd: (gA, gb) -> ga[r], gd[r] (tests/kernel_math.py::step_coeffs_bwd).
+__device__ __forceinline__ void step_bwd(int method, float h, const float a[4], const float d[4], float gA, float gb,
+                                         float ga[4], float gd[4]) {
+  if (method == SLODE_EULER) {
+    gd[0] = -h * gA;
+    ga[0] = h * gb;
+    ga[1] = gd[1] = ga[2] = gd[2] = ga[3] = gd[3] = 0.f;
+  } else if (method == SLODE_MIDPOINT) {
+    const float m = 1.f - 0.5f * h * d[0], c = 0.5f * h * a[0];
+    ga[1] = h * gb;
+    gd[1] = -h * (m * gA + c * gb);
+    const float gm = -h * d[1] * gA, gc = -h * d[1] * gb;
+    gd[0] = -0.5f * h * gm;
+    ga[0] = 0.5f * h * gc;
+    ga[2] = gd[2] = ga[3] = gd[3] = 0.f;
+  } else {
+    const float h3 = h * (1.0f / 3.0f), G = h * 0.125f;
+    const float p1 = a[0], q1 = -d[0];
+    const float c2 = h3 * p1, m2 = 1.f + h3 * q1;
+    const float p2 = a[1] - d[1] * c2, q2 = -d[1] * m2;
+    const float c3 = h * (p2 - p1 * (1.0f / 3.0f)), m3 = 1.f + h * (q2 - q1 * (1.0f / 3.0f));
+    const float p3 = a[2] - d[2] * c3, q3 = -d[2] * m3;
+    const float c4 = h * (p1 - p2 + p3), m4 = 1.f + h * (q1 - q2 + q3);
+    float gp1 = G * gb, gq1 = G * gA;
+    const float gp4 = G * gb, gq4 = G * gA;
+    float gp2 = 3.f * G * gb, gp3 = 3.f * G * gb, gq2 = 3.f * G * gA, gq3 = 3.f * G * gA;
+    ga[3] = gp4;
+    gd[3] = -c4 * gp4 - m4 * gq4;
+    const float gc4 = -d[3] * gp4, gm4 = -d[3] * gq4;
+    gp1 += h * gc4; gp2 -= h * gc4; gp3 += h * gc4;
+    gq1 += h * gm4; gq2 -= h * gm4; gq3 += h * gm4;
+    ga[2] = gp3;
+    gd[2] = -c3 * gp3 - m3 * gq3;
+    const float gc3 = -d[2] * gp3, gm3 = -d[2] * gq3;
+    gp2 += h * gc3; gp1 -= h3 * gc3;
+    gq2 += h * gm3; gq1 -= h3 * gm3;
+    ga[1] = gp2;
+    gd[1] = -c2 * gp2 - m2 * gq2;
+    const float gc2 = -d[1] * gp2, gm2 = -d[1] * gq2;
+    gp1 += h3 * gc2; gq1 += h3 * gm2;
+    ga[0] = gp1;
+    gd[0] = -gq1;
+  }
+}
+
+template <int S, int H, bool BWD>
+__global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int T = k.T, C = k.C, L = k.L, R = k.R, Q = k.Q;
+  const LdsMap m = lds_map(T, S, H, C, L, Q, k.nt, k.nseg, NT);
+  float* s_ts = smem + m.ts;
+  float* s_dt = smem + m.dt;
+  float* s_sig = smem + m.sig;
+  float* s_A = smem + m.A;
+  float* s_x = smem + m.x;
+  float* s_lam = smem + m.lam;
+  float* s_st = smem + m.st;
+  float* s_acc = smem + m.acc;
+  float* s_z = smem + m.z;
+  float* s_gzl = smem + m.gzl;
+  float* s_gpl = smem + m.gpl;
+  float* s_gls = smem + m.gls;
+  float* s_u = smem + m.u;
+  float* s_wt = smem + m.wt;
+  float* s_pre0 = smem + m.pre0;
+  float* s_hid0 = smem + m.hid0;
+  float* s_x0 = smem + m.x0;
+  float* s_go = smem + m.go;
+  float* s_gp0 = smem + m.gp0;
+  float* s_gu = smem + m.gu;
+  float* s_gup = smem + m.gup;
+  float* s_red = smem + m.red;
+
+  const cptr wg = (cptr)k.wg, bg = (cptr)k.bg, wd = (cptr)k.wd, bd = (cptr)k.bd;
+
+  // ---- per-workgroup setup (shared by all trajectories this workgroup integrates) ----------------------
+  for (int i = tid; i < k.nt; i += NT) s_ts[i] = k.stage_t[i];
+  for (int i = tid; i < T - 1; i += NT) s_dt[i] = k.times[i + 1] - k.times[i];
+  if (k.with_ll)
+    for (int i = tid; i < C * T; i += NT) s_sig[i] = softplusf(k.cstd[i]);
+  for (int i = tid; i < k.nseg + 1; i += NT) s_acc[i] = 0.f;
+  if (tid < 32) s_wt[tid] = (tid < H) ? k.wh[tid * (1 + L)] : 0.f;  // time column of dynamics_hidden (col 0)
+
+  // persistent per-thread accumulators (summed over this workgroup's trajectories)
+  float loss_acc = 0.f;
+  float acc_cstd[SLODE_MAX_C];
+#pragma unroll
+  for (int c = 0; c < SLODE_MAX_C; ++c) acc_cstd[c] = 0.f;
+  static_assert(H < 32, "lane H of each half-wave carries the head-bias gradients");
+  float acc_head = 0.f;  // one (q,c,s) head-weight entry (head-grad role)
+  // hidden-unit-major role: lane jj = hidden unit, chunk = half-wave index
+  const int jj = tid & 31, chunk = tid >> 5, nchunk = NT >> 5;
+  float acc_wg[S], acc_wd[S], acc_wt = 0.f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) { acc_wg[s] = 0.f; acc_wd[s] = 0.f; }
+  const float wtj = (jj < H) ? k.wh[jj * (1 + L)] : 0.f;
+  const int hg_base = (NT >= 128) ? 64 : 0;  // head-grad role lives on waves >= 1 when they exist
+  const int n_headw = Q * C * S;
+  __syncthreads();
+
+  for (int b = blockIdx.x; b < k.B; b += gridDim.x) {
+    // prefetch this thread's observation column (thread t <-> time point t)
+    float ob[SLODE_MAX_C];
+    if (k.with_ll && tid < T) {
+#pragma unroll
+      for (int c = 0; c < SLODE_MAX_C; ++c)
+        ob[c] = (c < C) ? k.obs[(long long)b * k.sb + (long long)c * k.sc + (long long)tid * k.st] : 0.f;
+    }
+
+    // ---- P0a: latent sample, log q, log p (mechanistic_cvs.py:125-135, 225-237) -------------------------
+    if (tid < L) {
+      const int l = tid;
+      if (k.loc != nullptr) {
+        const float loc = k.loc[(long long)b * L + l], sc = k.scale[(long long)b * L + l], e = k.eps[(long long)b * L + l];
+        const float z = fmaf(sc, e, loc);
+        float pl = 0.f, pls = 0.f;
+        for (int g = 0; g < k.ng; ++g) {
+          const slode_group gr = k.grp[g];
+          if (l >= gr.z_off && l < gr.z_off + gr.z_dim) {
+            const int ll = l - gr.z_off;
+            pl = k.ploc_b[g][ll];
+            pls = k.pls_b[g][ll];
+            for (int q = 0; q < gr.u_dim; ++q) {
+              const float uv = k.u[(long long)b * k.nu + gr.u_off + q];
+              pl = fmaf(k.ploc_w[g][ll * gr.u_dim + q], uv, pl);
+              pls = fmaf(k.pls_w[g][ll * gr.u_dim + q], uv, pls);
+            }
+          }
+        }
+        const float ips = expf(-pls);  // 1 / prior scale
+        const float dz = (z - pl) * ips;
+        const float zq = (z - loc) / sc;
+        const float HL2PI = 0.91893853320467274178f;
+        const float log_q = -logf(sc) - HL2PI - 0.5f * zq * zq;
+        const float log_p = -pls - HL2PI - 0.5f * dz * dz;
+        loss_acc += log_q - log_p;
+        s_z[l] = z;
+        s_gzl[l] = dz * ips;        // d(-log p)/dz
+        s_gpl[l] = -dz * ips;       // d(-log p)/d prior loc
+        s_gls[l] = 1.f - dz * dz;   // d(-log p)/d prior log-scale
+        if (k.z_out) k.z_out[(long long)b * L + l] = z;
+      } else {
+        s_z[l] = k.z_in[(long long)b * L + l];
+        s_gzl[l] = 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- P0b: u = W_z z + b_h (time-invariant part of the hidden layer), init-net hidden -----------------
+    if (tid < H) {
+      const int j = tid;
+      float uj = k.bh[j], p0 = k.b1[j];
+      for (int l = 0; l < L; ++l) {
+        const float zl = s_z[l];
+        uj = fmaf(k.wh[j * (1 + L) + 1 + l], zl, uj);
+        p0 = fmaf(k.w1[j * L + l], zl, p0);
+      }
+      s_u[j] = uj;
+      s_pre0[j] = p0;
+      s_hid0[j] = fmaxf(p0, 0.f);
+    } else if (tid < 32) {
+      s_u[tid] = 0.f;
+    }
+    __syncthreads();
+    // ---- P0c: x0 = sigmoid(W2 relu(.) + b2)  (blackbox_ode.py:19-22) ------------------------------------
+    if (tid < S) {
+      float o = k.b2[tid];
+#pragma unroll 1
+      for (int j = 0; j < H; ++j) o = fmaf(k.w2[tid * H + j], s_hid0[j], o);
+      const float x0 = sigmoidf_fast(o);
+      s_x0[tid] = x0;
+      s_x[tid] = x0;
+    }
+
+    // ---- P1: stage evaluations + step coefficients (thread n <-> grid step n) ---------------------------
+    float av[3][S], dv[3][S];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) { av[r][s] = 0.f; dv[r][s] = 0.f; }
+    }
+    const int n = tid;
+    const bool own_step = n < T - 1;
+    const bool own_last = (n == T - 1) && k.uses_next;
+    if (own_step || own_last) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if (r < R && (own_step || r == 0)) {
+          eval_ad<S, H>(s_ts[R * n + r], s_wt, s_u, wg, bg, wd, bd, av[r], dv[r]);
+          __builtin_amdgcn_sched_barrier(0);  // do not interleave the R evaluations (3x the live registers)
+        }
+      }
+      if (k.uses_next) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          s_st[n * 2 * S + s] = av[0][s];
+          s_st[n * 2 * S + S + s] = dv[0][s];
+        }
+      }
+    }
+    __syncthreads();
+    if (own_step) {
+      const float h = s_dt[n];
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float a3 = 0.f, d3 = 0.f;
+        if (k.uses_next) {
+          a3 = s_st[(n + 1) * 2 * S + s];
+          d3 = s_st[(n + 1) * 2 * S + S + s];
+        }
+        const float a4[4] = {av[0][s], av[1][s], av[2][s], a3};
+        const float d4[4] = {dv[0][s], dv[1][s], dv[2][s], d3};
+        float A, bb;
+        step_fwd(k.method, h, a4, d4, A, bb);
+        s_A[n * S + s] = A;
+        s_x[(n + 1) * S + s] = bb;
+      }
+    }
+    __syncthreads();
+    // ---- P2: forward scan x_{n+1} = A_n x_n + b_n (the only serial part of the solve) -------------------
+    if (tid < S) {
+      float x = s_x[tid];
+#pragma unroll 8
+      for (int i = 0; i < T - 1; ++i) {
+        x = fmaf(s_A[i * S + tid], x, s_x[(i + 1) * S + tid]);
+        s_x[(i + 1) * S + tid] = x;
+      }
+    }
+    __syncthreads();
+    if (k.x_out) {
+      float* xo = k.x_out + (long long)b * T * S;
+      for (int i = tid; i < T * S; i += NT) xo[i] = s_x[i];
+    }
+
+    // ---- P3: decoder heads + likelihood + dLoss/dx (decoders.py:45-53; mechanistic_cvs.py:142-211) -------
+    if (k.with_ll) {
+      if (tid < T) {
+        const int t = tid;
+        float xs[S], gx[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) { xs[s] = s_x[t * S + s]; gx[s] = 0.f; }
+        float ll = 0.f;
+#pragma unroll
+        for (int c = 0; c < SLODE_MAX_C; ++c) {
+          if (c >= C) continue;
+          const float sig = s_sig[c * T + t];
+          const float inv = 1.0f / sig;
+          const float obv = ob[c];
+          float gsig = 0.f;
+          for (int q = 0; q < Q; ++q) {
+            const cptr W = (cptr)k.head[q] + c * S;
+            float mu = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) mu = fmaf(W[s], xs[s], mu);
+            const float r = obv - mu;
+            float gmu;
+            if (k.gauss) {
+              ll += -logf(sig) - 0.91893853320467274178f - 0.5f * r * r * inv * inv;
+              gmu = -r * inv * inv;
+              gsig += inv - r * r * inv * inv * inv;
+            } else {
+              const float w = (obv >= mu) ? k.tau[q] : 1.f - k.tau[q];
+              const float ar = fabsf(r);
+              ll += w * (-logf(2.f * sig) - ar * inv);
+              const float sg = (r > 0.f) ? 1.f : ((r < 0.f) ? -1.f : 0.f);
+              gmu = -w * sg * inv;
+              gsig += w * (inv - ar * inv * inv);
+            }
+            if (BWD) {
+#pragma unroll
+              for (int s = 0; s < S; ++s) gx[s] = fmaf(gmu, W[s], gx[s]);
+              s_st[(q * C + c) * T + t] = gmu;
+            }
+          }
+          if (BWD) acc_cstd[c] += gsig;
+        }
+        loss_acc -= ll;
+        if (BWD) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) s_lam[t * S + s] = gx[s];
+        }
+      }
+    } else if (BWD) {
+      const float* gi = k.gx_in + (long long)b * T * S;
+      for (int i = tid; i < T * S; i += NT) s_lam[i] = gi[i];
+    }
+
+    if (BWD) {
+      __syncthreads();
+      // ---- P4: adjoint scan (wave 0) || head-weight gradients (waves >= 1) ------------------------------
+      if (tid < S) {
+        float lam = s_lam[(T - 1) * S + tid];
+#pragma unroll 8
+        for (int i = T - 2; i >= 0; --i) {
+          lam = fmaf(s_A[i * S + tid], lam, s_lam[i * S + tid]);
+          s_lam[i * S + tid] = lam;
+        }
+      }
+      if (k.with_ll) {
+        const int e = tid - hg_base;
+        if (e >= 0 && e < n_headw) {
+          const int qc = e / S, s = e - qc * S;
+          float acc = 0.f;
+          for (int t = 0; t < T; ++t) acc = fmaf(s_st[qc * T + t], s_x[t * S + s], acc);
+          acc_head += acc;
+        }
+      }
+      __syncthreads();
+      // ---- P5: reverse mode of the step coefficients (thread n <-> step n) ------------------------------
+      // (the stage buffer is free again: re-exchange the first-stage values instead of carrying a3/d3 in registers)
+      if (k.uses_next && (own_step || own_last)) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          s_st[n * 2 * S + s] = av[0][s];
+          s_st[n * 2 * S + S + s] = dv[0][s];
+        }
+      }
+      __syncthreads();
+      if (own_step) {
+        const float h = s_dt[n];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const float gb = s_lam[(n + 1) * S + s];
+          const float gA = gb * s_x[n * S + s];
+          float a3 = 0.f, d3 = 0.f;
+          if (k.uses_next) {  // slot n+1 is read here and rewritten below by this thread only
+            a3 = s_st[(n + 1) * 2 * S + s];
+            d3 = s_st[(n + 1) * 2 * S + S + s];
+          }
+          const float a4[4] = {av[0][s], av[1][s], av[2][s], a3};
+          const float d4[4] = {dv[0][s], dv[1][s], dv[2][s], d3};
+          float ga[4], gd[4];
+          step_bwd(k.method, h, a4, d4, gA, gb, ga, gd);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {  // through the sigmoids
+            ga[r] *= a4[r] * (1.f - a4[r]);
+            gd[r] *= d4[r] * (1.f - d4[r]);
+          }
+          av[0][s] = ga[0]; av[1][s] = ga[1]; av[2][s] = ga[2];
+          dv[0][s] = gd[0]; dv[1][s] = gd[1]; dv[2][s] = gd[2];
+          if (k.uses_next) {  // contribution to the NEXT step's first stage (shared evaluation a(t_{n+1}))
+            s_st[(n + 1) * 2 * S + s] = ga[3];
+            s_st[(n + 1) * 2 * S + S + s] = gd[3];
+          }
+        }
+      } else if (own_last) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) { av[0][s] = 0.f; dv[0][s] = 0.f; }
+      }
+      __syncthreads();
+      if (k.uses_next && (own_step || own_last) && n >= 1) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          av[0][s] += s_st[n * 2 * S + s];
+          dv[0][s] += s_st[n * 2 * S + S + s];
+        }
+      }
+      // ---- P6: weight-gradient contraction, hidden-unit-major; one round per stage index r ---------------
+      float gu_acc = 0.f;
+      float wgj[S], wdj[S];  // this lane's column of the two dynamics heads
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        wgj[s] = (jj < H) ? k.wg[s * H + jj] : 0.f;
+        wdj[s] = (jj < H) ? k.wd[s * H + jj] : 0.f;
+      }
+      const int nsamp0 = k.uses_next ? T : T - 1;
+      for (int r = 0; r < R; ++r) {
+        __syncthreads();
+        const int ns = (r == 0) ? nsamp0 : T - 1;
+        if (n < ns) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            float ga, gd;
+            if (r == 0) { ga = av[0][s]; gd = dv[0][s]; }
+            else if (r == 1) { ga = av[1][s]; gd = dv[1][s]; }
+            else { ga = av[2][s]; gd = dv[2][s]; }
+            s_st[n * 2 * S + s] = ga;
+            s_st[n * 2 * S + S + s] = gd;
+          }
+        }
+        __syncthreads();
+        if (jj <= H) {  // lane H: constant-1 unit => accumulates the head-bias gradients
+          const int per = (ns + nchunk - 1) / nchunk;
+          const int i0 = chunk * per;
+          const int i1 = min(ns, i0 + per);
+          const float uj = s_u[jj];
+          for (int i = i0; i < i1; ++i) {
+            const float t = s_ts[R * i + r];
+            const float pre = fmaf(wtj, t, uj);
+            const float hj = (jj == H) ? 1.f : fmaxf(pre, 0.f);
+            float gh = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+              const float ga = s_st[i * 2 * S + s], gd = s_st[i * 2 * S + S + s];
+              gh = fmaf(wgj[s], ga, gh);
+              gh = fmaf(wdj[s], gd, gh);
+              acc_wg[s] = fmaf(ga, hj, acc_wg[s]);
+              acc_wd[s] = fmaf(gd, hj, acc_wd[s]);
+            }
+            const float gp = (pre > 0.f) ? gh : 0.f;
+            acc_wt = fmaf(gp, t, acc_wt);
+            gu_acc += gp;
+          }
+        }
+      }
+      s_gup[chunk * 32 + jj] = (jj < H) ? gu_acc : 0.f;
+      __syncthreads();
+      // ---- P7: small nets (init net, z-part of the hidden layer, priors) and the latent gradient ----------
+      if (tid < 32) {
+        float g = 0.f;
+        for (int c2 = 0; c2 < nchunk; ++c2) g += s_gup[c2 * 32 + tid];
+        s_gu[tid] = g;  // dLoss/du_j for this trajectory
+      }
+      if (tid >= 64 && tid < 64 + S) {  // (NT >= 128 is guaranteed when BWD; see launcher)
+        const int s = tid - 64;
+        const float x0 = s_x0[s];
+        s_go[s] = s_lam[s] * x0 * (1.f - x0);
+      }
+      __syncthreads();
+      if (tid < H) {
+        float gh0 = 0.f;
+#pragma unroll 1
+        for (int s = 0; s < S; ++s) gh0 = fmaf(k.w2[s * H + tid], s_go[s], gh0);
+        s_gp0[tid] = (s_pre0[tid] > 0.f) ? gh0 : 0.f;
+      } else if (tid < 32) {
+        s_gp0[tid] = 0.f;
+      }
+      __syncthreads();
+      if (tid < L) {
+        const int l = tid;
+        float gz = s_gzl[l];
+#pragma unroll 1
+        for (int j = 0; j < H; ++j) {
+          gz = fmaf(k.wh[j * (1 + L) + 1 + l], s_gu[j], gz);
+          gz = fmaf(k.w1[j * L + l], s_gp0[j], gz);
+        }
+        if (k.loc != nullptr) {
+          const float e = k.eps[(long long)b * L + l], sc = k.scale[(long long)b * L + l];
+          k.g_loc[(long long)b * L + l] = gz;
+          k.g_scale[(long long)b * L + l] = fmaf(gz, e, -1.0f / sc);
+        } else {
+          k.g_loc[(long long)b * L + l] = gz;
+        }
+      }
+      // owner-thread accumulation into the LDS gradient segment (unique owner per element => no atomics)
+      float* acc = s_acc + 1;
+      for (int e = tid; e < H * L; e += NT) {
+        const int j = e / L, l = e - j * L;
+        acc[k.o_wh + j * (1 + L) + 1 + l] += s_gu[j] * s_z[l];
+        acc[k.o_w1 + e] += s_gp0[j] * s_z[l];
+      }
+      for (int e = tid; e < S * H; e += NT) {
+        const int s = e / H, j = e - s * H;
+        acc[k.o_w2 + e] += s_go[s] * s_hid0[j];
+      }
+      if (tid < H) { acc[k.o_bh + tid] += s_gu[tid]; acc[k.o_b1 + tid] += s_gp0[tid]; }
+      if (tid < S) acc[k.o_b2 + tid] += s_go[tid];
+      if (k.loc != nullptr) {
+        for (int g = 0; g < k.ng; ++g) {
+          const slode_group gr = k.grp[g];
+          for (int e = tid; e < gr.z_dim * gr.u_dim; e += NT) {
+            const int ll = e / gr.u_dim, q = e - ll * gr.u_dim;
+            const float uv = k.u[(long long)b * k.nu + gr.u_off + q];
+            acc[k.o_ploc_w[g] + e] += s_gpl[gr.z_off + ll] * uv;
+            acc[k.o_pls_w[g] + e] += s_gls[gr.z_off + ll] * uv;
+          }
+          for (int e = tid; e < gr.z_dim; e += NT) {
+            acc[k.o_ploc_b[g] + e] += s_gpl[gr.z_off + e];
+            acc[k.o_pls_b[g] + e] += s_gls[gr.z_off + e];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }  // trajectories
+
+  // ---- workgroup epilogue: fold register accumulators into the LDS segment, write the slab ---------------
+  float* slab = k.slabs + (long long)blockIdx.x * k.slab_stride;
+  const float loss = block_sum(loss_acc, s_red);
+  if (tid == 0) s_acc[0] = loss;
+  if (BWD) {
+    float* acc = s_acc + 1;
+    // hidden-unit-major accumulators: reduce over chunks through the stage buffer
+    __syncthreads();
+    float* tmp = s_st;  // [nchunk][2S+1][32]
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      tmp[(chunk * (2 * S + 1) + s) * 32 + jj] = acc_wg[s];
+      tmp[(chunk * (2 * S + 1) + S + s) * 32 + jj] = acc_wd[s];
+    }
+    tmp[(chunk * (2 * S + 1) + 2 * S) * 32 + jj] = acc_wt;
+    __syncthreads();
+    for (int e = tid; e < (2 * S + 1) * 32; e += NT) {
+      const int row = e >> 5, j = e & 31;
+      if (j < H) {
+        float v = 0.f;
+        for (int c2 = 0; c2 < nchunk; ++c2) v += tmp[(c2 * (2 * S + 1) + row) * 32 + j];
+        if (row < S) acc[k.o_wg + row * H + j] = v;
+        else if (row < 2 * S) acc[k.o_wd + (row - S) * H + j] = v;
+        else acc[k.o_wh + j * (1 + L)] = v;  // time column
+      } else if (j == H && row < 2 * S) {  // the constant-1 lane: head biases
+        float v = 0.f;
+        for (int c2 = 0; c2 < nchunk; ++c2) v += tmp[(c2 * (2 * S + 1) + row) * 32 + j];
+        if (row < S) acc[k.o_bg + row] = v;
+        else acc[k.o_bd + (row - S)] = v;
+      }
+    }
+    if (k.with_ll) {
+      const int e = tid - hg_base;
+      if (e >= 0 && e < n_headw) {
+        const int qc = e / S, s = e - qc * S, q = qc / C, c = qc - q * C;
+        acc[k.o_head[q] + c * S + s] = acc_head;
+      }
+      if (tid < T) {
+#pragma unroll
+        for (int c = 0; c < SLODE_MAX_C; ++c) {
+          if (c >= C) continue;
+          const float sig = s_sig[c * T + tid];
+          acc[k.o_cstd + c * T + tid] = acc_cstd[c] * (1.f - expf(-sig));  // softplus'(x) = 1 - exp(-softplus(x))
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < k.nseg + 1; i += NT) slab[i] = s_acc[i];
+  } else {
+    if (tid == 0) slab[0] = loss;
+  }
+}
+
+template <int S, int H>
+hipError_t launch_sh(const OdeK& k, int grid, int nthreads, size_t lds, bool bwd, hipStream_t stream) {
+  if (bwd) {
+    hipFuncSetAttribute((const void*)ode_elbo_kernel<S, H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ode_elbo_kernel<S, H, true>), dim3(grid), dim3(nthreads), lds, stream, k);
+  } else {
+    hipFuncSetAttribute((const void*)ode_elbo_kernel<S, H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ode_elbo_kernel<S, H, false>), dim3(grid), dim3(nthreads), lds, stream, k);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+int slode_ode_threads(const slode_shape& s) {
+  int nt = ((s.T + 63) / 64) * 64;
+  // waves >= 1 carry the head-gradient role (one (q,c,s) entry per thread) next to the adjoint scan on wave 0
+  const int Q = s.likelihood == SLODE_GAUSS ? 1 : 3;
+  const int need = 64 + ((Q * s.C * s.S + 63) / 64) * 64;
+  if (nt < need) nt = need;
+  return nt;
+}
+
+static int n_stage(const slode_shape& s) {
+  const int R = s.method == SLODE_EULER ? 1 : (s.method == SLODE_MIDPOINT ? 2 : 3);
+  return R * (s.T - 1) + 1;
+}
+
+size_t slode_ode_lds_bytes(const slode_shape& s, int nthreads) {
+  slode_layout lay;
+  slode_layout_init(&s, &lay);
+  const int Q = s.likelihood == SLODE_GAUSS ? 1 : 3;
+  const LdsMap m = lds_map(s.T, s.S, s.H, s.C, s.L, Q, n_stage(s), lay.ode_end - lay.ode_begin, nthreads);
+  return (size_t)m.total * sizeof(float);
+}
+
+hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, size_t errlen) {
+  const slode_shape& s = a.s;
+  const slode_layout& lay = a.lay;
+  OdeK k;
+  k.B = s.B; k.T = s.T; k.C = s.C; k.L = s.L; k.nu = s.n_u; k.ng = s.n_groups; k.method = s.method;
+  k.R = s.method == SLODE_EULER ? 1 : (s.method == SLODE_MIDPOINT ? 2 : 3);
+  k.nt = n_stage(s);
+  k.gauss = s.likelihood == SLODE_GAUSS;
+  k.Q = k.gauss ? 1 : 3;
+  k.uses_next = s.method == SLODE_RK4;
+  k.tau[0] = 0.5f; k.tau[1] = 0.5f + s.quantile_diff; k.tau[2] = 0.5f - s.quantile_diff;
+  const float* p = a.params;
+  const int ob = lay.ode_begin;
+  for (int g = 0; g < SLODE_MAX_GROUPS; ++g) {
+    k.grp[g] = s.groups[g];
+    const bool on = g < s.n_groups;
+    k.ploc_w[g] = on ? p + lay.ploc_w[g] : nullptr; k.ploc_b[g] = on ? p + lay.ploc_b[g] : nullptr;
+    k.pls_w[g] = on ? p + lay.pls_w[g] : nullptr;   k.pls_b[g] = on ? p + lay.pls_b[g] : nullptr;
+    k.o_ploc_w[g] = lay.ploc_w[g] - ob; k.o_ploc_b[g] = lay.ploc_b[g] - ob;
+    k.o_pls_w[g] = lay.pls_w[g] - ob;   k.o_pls_b[g] = lay.pls_b[g] - ob;
+  }
+  k.w1 = p + lay.init_w1; k.b1 = p + lay.init_b1; k.w2 = p + lay.init_w2; k.b2 = p + lay.init_b2;
+  k.wh = p + lay.dyn_wh; k.bh = p + lay.dyn_bh; k.wg = p + lay.dyn_wg; k.bg = p + lay.dyn_bg;
+  k.wd = p + lay.dyn_wd; k.bd = p + lay.dyn_bd;
+  for (int q = 0; q < SLODE_MAX_HEADS; ++q) { k.head[q] = p + lay.head_w[q]; k.o_head[q] = lay.head_w[q] - ob; }
+  k.cstd = p + lay.cstd;
+  k.o_w1 = lay.init_w1 - ob; k.o_b1 = lay.init_b1 - ob; k.o_w2 = lay.init_w2 - ob; k.o_b2 = lay.init_b2 - ob;
+  k.o_wh = lay.dyn_wh - ob; k.o_bh = lay.dyn_bh - ob; k.o_wg = lay.dyn_wg - ob; k.o_bg = lay.dyn_bg - ob;
+  k.o_wd = lay.dyn_wd - ob; k.o_bd = lay.dyn_bd - ob; k.o_cstd = lay.cstd - ob;
+  k.nseg = lay.ode_end - lay.ode_begin;
+  k.times = a.times; k.stage_t = a.stage_t; k.obs = a.obs; k.u = a.u; k.eps = a.eps; k.loc = a.loc; k.scale = a.scale;
+  k.z_in = a.z_in; k.gx_in = a.gx_in; k.sb = a.sb; k.sc = a.sc; k.st = a.st;
+  k.x_out = a.x_out; k.z_out = a.z_out; k.g_loc = a.g_loc; k.g_scale = a.g_scale; k.slabs = a.slabs;
+  k.slab_stride = a.slab_stride; k.backward = a.backward; k.with_ll = a.with_ll;
+
+  const int nthreads = slode_ode_threads(s);
+  const size_t lds = slode_ode_lds_bytes(s, nthreads);
+  if (lds > 160 * 1024) {
+    snprintf(err, errlen, "ode kernel needs %zu B of LDS (> 160 KiB): T=%d S=%d too large", lds, s.T, s.S);
+    return hipErrorInvalidValue;
+  }
+  const bool bwd = a.backward != 0;
+  if (s.H == 25 && s.S == 5) return launch_sh<5, 25>(k, a.grid, nthreads, lds, bwd, stream);
+  if (s.H == 25 && s.S == 8) return launch_sh<8, 25>(k, a.grid, nthreads, lds, bwd, stream);
+  snprintf(err, errlen, "ode kernel is instantiated for (ode_state_dim, ode_hidden_dim) in {(5,25),(8,25)}; got (%d,%d)", s.S, s.H);
+  return hipErrorInvalidValue;
+}

@@ -1,0 +1,354 @@
+// C ABI of libslode.so (include/slode.h): validation, parameter layout, workspace carving, launch orchestration.
+#include "slode_common.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+static int fail(slode_handle h, int code, const char* fmt, ...) {
+  char* dst = h ? h->err : g_err;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(dst, 512, fmt, ap);
+  va_end(ap);
+  if (h) snprintf(g_err, sizeof(g_err), "%s", h->err);
+  return code;
+}
+#define HIP_TRY(h, expr)                                                                             \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess) return fail(h, SLODE_EHIP, "%s: %s", #expr, hipGetErrorString(e_));        \
+  } while (0)
+
+static int stages_per_step(int method) { return method == SLODE_EULER ? 1 : (method == SLODE_MIDPOINT ? 2 : 3); }
+
+static const char* check_shape(const slode_shape* s) {
+  if (!s) return "shape is NULL";
+  if (s->B < 1) return "B < 1";
+  if (s->T < 2 || s->T > SLODE_MAX_T) return "T out of range [2, 1024]";
+  if (s->C < 1 || s->C > SLODE_MAX_C) return "C (obs_dim) out of range [1, 4]";
+  if (s->L < 1 || s->L > SLODE_MAX_L) return "L (latent dim) out of range [1, 64]";
+  if (s->S < 1 || s->S > SLODE_MAX_S) return "S (ode_state_dim) out of range [1, 8]";
+  if (s->H < 1 || s->H > SLODE_MAX_H) return "H (ode_hidden_dim) out of range [1, 32]";
+  if (s->F < 1 || s->F > SLODE_MAX_F) return "F (n_filters) out of range [1, 16]";
+  if (s->K < 1 || s->K > SLODE_MAX_K) return "K (filter_size) out of range [1, 16]";
+  if (s->P < 1 || s->P > SLODE_MAX_P) return "P (pool_size) out of range [1, 8]";
+  if (s->Hc < 1 || s->Hc > SLODE_MAX_HC) return "Hc (cnn_hidden_dim) out of range [1, 64]";
+  if (s->T - s->K + 1 - s->P + 1 < 1) return "T too short for the conv/pool stack";
+  if (s->n_u < 0 || s->n_u > SLODE_MAX_NU) return "n_u out of range [0, 16]";
+  if (s->n_groups < 0 || s->n_groups > SLODE_MAX_GROUPS) return "n_groups out of range [0, 4]";
+  for (int g = 0; g < s->n_groups; ++g) {
+    const slode_group& gr = s->groups[g];
+    if (gr.z_off < 0 || gr.z_dim < 1 || gr.z_off + gr.z_dim > s->L) return "prior group latent range outside [0, L)";
+    if (gr.u_off < 0 || gr.u_dim < 1 || gr.u_off + gr.u_dim > s->n_u) return "prior group label range outside [0, n_u)";
+    for (int g2 = 0; g2 < g; ++g2) {
+      const slode_group& o = s->groups[g2];
+      if (gr.z_off < o.z_off + o.z_dim && o.z_off < gr.z_off + gr.z_dim) return "prior groups overlap";
+    }
+  }
+  if (s->method != SLODE_EULER && s->method != SLODE_MIDPOINT && s->method != SLODE_RK4)
+    return "method must be euler, midpoint or rk4 for the fixed-grid kernels";
+  if (s->likelihood != SLODE_ALD && s->likelihood != SLODE_GAUSS) return "likelihood must be ALD or GAUSS";
+  return nullptr;
+}
+
+extern "C" {
+
+int slode_version(void) { return SLODE_VERSION; }
+
+const char* slode_last_error(slode_handle h) { return h ? h->err : g_err; }
+
+int slode_create(slode_handle* out, int device_id) {
+  if (!out) return fail(nullptr, SLODE_EINVAL, "handle pointer is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0)
+    return fail(nullptr, SLODE_EHIP, "no HIP device visible (%s); libslode has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (device_id < 0 || device_id >= n) return fail(nullptr, SLODE_EINVAL, "device_id %d outside [0, %d)", device_id, n);
+  hipDeviceProp_t prop;
+  HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, SLODE_EHIP, "device %d is %s; libslode is built for gfx950 only", device_id, prop.gcnArchName);
+  slode_ctx* c = new slode_ctx();
+  c->device = device_id;
+  c->num_cu = prop.multiProcessorCount;
+  c->err[0] = 0;
+  *out = c;
+  return SLODE_OK;
+}
+
+int slode_destroy(slode_handle h) {
+  delete h;
+  return SLODE_OK;
+}
+
+int slode_layout_init(const slode_shape* s, slode_layout* lay) {
+  const char* why = check_shape(s);
+  if (why) return fail(nullptr, SLODE_EINVAL, "%s", why);
+  if (!lay) return fail(nullptr, SLODE_EINVAL, "layout pointer is NULL");
+  memset(lay, 0, sizeof(*lay));
+  const int n_conv = s->T - s->K + 1, FQ = s->F * (n_conv - s->P + 1);
+  const int Q = s->likelihood == SLODE_GAUSS ? 1 : 3;
+  int o = 0;
+  lay->conv_w = o; o += s->F * s->C * s->K;
+  lay->conv_b = o; o += s->F;
+  lay->lin_w = o; o += s->Hc * FQ;
+  lay->lin_b = o; o += s->Hc;
+  lay->zloc_w = o; o += s->L * s->Hc;
+  lay->zloc_b = o; o += s->L;
+  lay->zls_w = o; o += s->L * s->Hc;
+  lay->zls_b = o; o += s->L;
+  lay->ode_begin = o;
+  for (int g = 0; g < s->n_groups; ++g) {
+    const slode_group& gr = s->groups[g];
+    lay->ploc_w[g] = o; o += gr.z_dim * gr.u_dim;
+    lay->ploc_b[g] = o; o += gr.z_dim;
+    lay->pls_w[g] = o; o += gr.z_dim * gr.u_dim;
+    lay->pls_b[g] = o; o += gr.z_dim;
+  }
+  lay->init_w1 = o; o += s->H * s->L;
+  lay->init_b1 = o; o += s->H;
+  lay->init_w2 = o; o += s->S * s->H;
+  lay->init_b2 = o; o += s->S;
+  lay->dyn_wh = o; o += s->H * (1 + s->L);
+  lay->dyn_bh = o; o += s->H;
+  lay->dyn_wg = o; o += s->S * s->H;
+  lay->dyn_bg = o; o += s->S;
+  lay->dyn_wd = o; o += s->S * s->H;
+  lay->dyn_bd = o; o += s->S;
+  for (int q = 0; q < SLODE_MAX_HEADS; ++q) {
+    lay->head_w[q] = o;
+    if (q < Q) o += s->C * s->S;
+  }
+  lay->cstd = o; o += s->C * s->T;
+  lay->ode_end = o;
+  lay->n_params = o;
+  return SLODE_OK;
+}
+
+int slode_num_stage_times(const slode_shape* s) {
+  if (!s || s->T < 2) return SLODE_EINVAL;
+  return stages_per_step(s->method) * (s->T - 1) + 1;
+}
+
+}  // extern "C"
+
+// ---- workspace carving -------------------------------------------------------------------------------------
+struct Workspace {
+  float *loc, *scale, *pooled, *hid, *g_loc, *g_scale, *g_pre, *ode_slabs, *small_slabs, *lin_slabs;
+  int ode_grid, ode_stride, small_grid, small_stride, lin_splitk;
+  size_t bytes;
+};
+
+static int ode_grid_for(slode_handle h, const slode_shape& s) {
+  const int nthreads = slode_ode_threads(s);
+  const size_t lds = slode_ode_lds_bytes(s, nthreads);
+  int occ = lds ? (int)((160 * 1024) / lds) : 1;
+  const int by_waves = 32 / (nthreads / 64);
+  if (occ > by_waves) occ = by_waves;
+  if (occ > 8) occ = 8;
+  if (occ < 1) occ = 1;
+  const int cus = h ? h->num_cu : 256;
+  long long g = (long long)cus * occ;
+  if (g > s.B) g = s.B;
+  return (int)g;
+}
+
+static size_t align_up(size_t v) { return (v + 63) & ~(size_t)63; }  // in floats: 256-byte alignment
+
+static Workspace carve(slode_handle h, const slode_shape& s, const slode_layout& lay, void* base) {
+  Workspace w{};
+  const int n_conv = s.T - s.K + 1, FQ = s.F * (n_conv - s.P + 1);
+  w.ode_grid = ode_grid_for(h, s);
+  w.ode_stride = (int)align_up((size_t)(lay.ode_end - lay.ode_begin) + 1);
+  w.small_grid = slode_enc_bwd_grid(s);
+  w.small_stride = (int)align_up((size_t)slode_enc_small_count(s));
+  w.lin_splitk = slode_enc_lin_splitk(s);
+  size_t o = 0;
+  float* b = (float*)base;
+  auto take = [&](size_t n) { float* p = b ? b + o : nullptr; o += align_up(n); return p; };
+  w.loc = take((size_t)s.B * s.L);
+  w.scale = take((size_t)s.B * s.L);
+  w.pooled = take((size_t)s.B * FQ);
+  w.hid = take((size_t)s.B * s.Hc);
+  w.g_loc = take((size_t)s.B * s.L);
+  w.g_scale = take((size_t)s.B * s.L);
+  w.g_pre = take((size_t)s.B * 64);
+  w.ode_slabs = take((size_t)w.ode_grid * w.ode_stride);
+  w.small_slabs = take((size_t)w.small_grid * w.small_stride);
+  w.lin_slabs = take((size_t)w.lin_splitk * s.Hc * FQ);
+  w.bytes = o * sizeof(float);
+  return w;
+}
+
+static const char* check_common(slode_handle h, const slode_shape* s, const slode_layout* lay, const void* params) {
+  if (!h) return "handle is NULL";
+  const char* why = check_shape(s);
+  if (why) return why;
+  if (!lay) return "layout is NULL";
+  if (!params) return "params is NULL";
+  return nullptr;
+}
+
+extern "C" {
+
+size_t slode_workspace_bytes(slode_handle h, const slode_shape* s) {
+  slode_layout lay;
+  if (slode_layout_init(s, &lay) != SLODE_OK) return 0;
+  return carve(h, *s, lay, nullptr).bytes;
+}
+
+int slode_stage_times(slode_handle h, const slode_shape* s, const float* times, float* stage_t, void* stream) {
+  if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
+  const char* why = check_shape(s);
+  if (why) return fail(h, SLODE_EINVAL, "%s", why);
+  if (!times || !stage_t) return fail(h, SLODE_EINVAL, "times / stage_t is NULL");
+  HIP_TRY(h, slode_launch_stage_times(*s, times, stage_t, (hipStream_t)stream));
+  return SLODE_OK;
+}
+
+int slode_encoder_conv_fwd(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params,
+                           const float* obs, const int64_t obs_strides[3], float* loc, float* scale, float* pooled,
+                           float* hid, void* stream) {
+  const char* why = check_common(h, s, lay, params);
+  if (why) return fail(h, SLODE_EINVAL, "%s", why);
+  if (!obs || !obs_strides || !loc || !scale) return fail(h, SLODE_EINVAL, "obs / obs_strides / loc / scale is NULL");
+  EncLaunch a{*s, *lay, params, obs, obs_strides[0], obs_strides[1], obs_strides[2], loc, scale, pooled, hid};
+  hipError_t e = slode_launch_enc_fwd(a, (hipStream_t)stream);
+  if (e == hipErrorInvalidValue)
+    return fail(h, SLODE_EINVAL, "encoder kernels are instantiated for (obs_dim, filter_size) in {(3,10),(4,10)} and need "
+                                 "the tile to fit 160 KiB of LDS; got C=%d K=%d T=%d", s->C, s->K, s->T);
+  HIP_TRY(h, e);
+  return SLODE_OK;
+}
+
+int slode_encoder_conv_bwd(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params,
+                           const float* obs, const int64_t obs_strides[3], const float* scale, const float* pooled,
+                           const float* hid, const float* g_loc, const float* g_scale, float* grads, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  const char* why = check_common(h, s, lay, params);
+  if (why) return fail(h, SLODE_EINVAL, "%s", why);
+  if (!obs || !obs_strides || !scale || !pooled || !hid || !g_loc || !g_scale || !grads || !workspace)
+    return fail(h, SLODE_EINVAL, "a required pointer is NULL");
+  Workspace w = carve(h, *s, *lay, workspace);
+  if (workspace_bytes < w.bytes) return fail(h, SLODE_ENOSPC, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
+  EncBwdLaunch a{*s, *lay, params, obs, obs_strides[0], obs_strides[1], obs_strides[2], scale, pooled, hid, g_loc, g_scale,
+                 w.g_pre, w.small_slabs, w.small_stride, w.small_grid, w.lin_slabs, w.lin_splitk};
+  hipError_t e = slode_launch_enc_bwd(a, (hipStream_t)stream);
+  if (e == hipErrorInvalidValue) return fail(h, SLODE_EINVAL, "unsupported encoder shape C=%d K=%d T=%d", s->C, s->K, s->T);
+  HIP_TRY(h, e);
+  ReduceLaunch r{*s, *lay, nullptr, 0, 0, w.small_slabs, w.small_stride, w.small_grid, w.lin_slabs, w.lin_splitk, grads, nullptr, 0};
+  HIP_TRY(h, slode_launch_reduce(r, (hipStream_t)stream));
+  return SLODE_OK;
+}
+
+int slode_ode_solve_fwd(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params,
+                        const float* times, const float* stage_t, const float* z, float* x, void* stream) {
+  const char* why = check_common(h, s, lay, params);
+  if (why) return fail(h, SLODE_EINVAL, "%s", why);
+  if (!times || !stage_t || !z || !x) return fail(h, SLODE_EINVAL, "times / stage_t / z / x is NULL");
+  // forward-only solve needs one loss slot per workgroup; borrow the head of x? no: use a tiny static scratch in x's tail
+  // is not possible => the kernel writes its (zero) loss partial into slabs; give it the first floats of a scratch we own.
+  static thread_local float* scratch = nullptr;
+  static thread_local int scratch_n = 0;
+  const int grid = ode_grid_for(h, *s);
+  if (scratch_n < grid) {
+    if (scratch) (void)hipFree(scratch);
+    HIP_TRY(h, hipMalloc(&scratch, sizeof(float) * (size_t)grid));
+    scratch_n = grid;
+  }
+  OdeLaunch a{};
+  a.s = *s; a.lay = *lay; a.params = params; a.times = times; a.stage_t = stage_t; a.z_in = z; a.x_out = x;
+  a.slabs = scratch; a.slab_stride = 1; a.grid = grid; a.backward = 0; a.with_ll = 0;
+  hipError_t e = slode_launch_ode(a, (hipStream_t)stream, h->err, sizeof(h->err));
+  if (e == hipErrorInvalidValue) return SLODE_EINVAL;
+  HIP_TRY(h, e);
+  return SLODE_OK;
+}
+
+int slode_ode_solve_bwd(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params,
+                        const float* times, const float* stage_t, const float* z, const float* g_x, float* g_z,
+                        float* grads, void* workspace, size_t workspace_bytes, void* stream) {
+  const char* why = check_common(h, s, lay, params);
+  if (why) return fail(h, SLODE_EINVAL, "%s", why);
+  if (!times || !stage_t || !z || !g_x || !g_z || !grads || !workspace) return fail(h, SLODE_EINVAL, "a required pointer is NULL");
+  Workspace w = carve(h, *s, *lay, workspace);
+  if (workspace_bytes < w.bytes) return fail(h, SLODE_ENOSPC, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
+  OdeLaunch a{};
+  a.s = *s; a.lay = *lay; a.params = params; a.times = times; a.stage_t = stage_t; a.z_in = z; a.gx_in = g_x;
+  a.g_loc = g_z; a.slabs = w.ode_slabs; a.slab_stride = w.ode_stride; a.grid = w.ode_grid; a.backward = 1; a.with_ll = 0;
+  hipError_t e = slode_launch_ode(a, (hipStream_t)stream, h->err, sizeof(h->err));
+  if (e == hipErrorInvalidValue) return SLODE_EINVAL;
+  HIP_TRY(h, e);
+  ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, nullptr, 0, 0, nullptr, 0, grads, nullptr, 0};
+  HIP_TRY(h, slode_launch_reduce(r, (hipStream_t)stream));
+  return SLODE_OK;
+}
+
+int slode_decode_heads(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* x,
+                       float* mu, float* std_ct, void* stream) {
+  const char* why = check_common(h, s, lay, params);
+  if (why) return fail(h, SLODE_EINVAL, "%s", why);
+  if (!x || !mu) return fail(h, SLODE_EINVAL, "x / mu is NULL");
+  HIP_TRY(h, slode_launch_decode_heads(*s, *lay, params, x, mu, std_ct, (hipStream_t)stream));
+  return SLODE_OK;
+}
+
+int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* times,
+                    const float* stage_t, const float* obs, const int64_t obs_strides[3], const float* u, const float* eps,
+                    float* loss_out, float* grads, float* x_out, float* z_out, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+  const char* why = check_common(h, s, lay, params);
+  if (why) return fail(h, SLODE_EINVAL, "%s", why);
+  if (!times || !stage_t || !obs || !obs_strides || !eps || !loss_out || !workspace)
+    return fail(h, SLODE_EINVAL, "a required pointer is NULL");
+  if (s->n_groups > 0 && !u) return fail(h, SLODE_EINVAL, "u is NULL but the shape has conditional prior groups");
+  Workspace w = carve(h, *s, *lay, workspace);
+  if (workspace_bytes < w.bytes) return fail(h, SLODE_ENOSPC, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const bool bwd = grads != nullptr;
+
+  EncLaunch ef{*s, *lay, params, obs, obs_strides[0], obs_strides[1], obs_strides[2], w.loc, w.scale, w.pooled, w.hid};
+  hipError_t e = slode_launch_enc_fwd(ef, st);
+  if (e == hipErrorInvalidValue) return fail(h, SLODE_EINVAL, "unsupported encoder shape C=%d K=%d T=%d", s->C, s->K, s->T);
+  HIP_TRY(h, e);
+
+  OdeLaunch a{};
+  a.s = *s; a.lay = *lay; a.params = params; a.times = times; a.stage_t = stage_t;
+  a.obs = obs; a.sb = obs_strides[0]; a.sc = obs_strides[1]; a.st = obs_strides[2];
+  a.u = u; a.eps = eps; a.loc = w.loc; a.scale = w.scale; a.x_out = x_out; a.z_out = z_out;
+  a.g_loc = w.g_loc; a.g_scale = w.g_scale; a.slabs = w.ode_slabs; a.slab_stride = w.ode_stride; a.grid = w.ode_grid;
+  a.backward = bwd ? 1 : 0; a.with_ll = 1;
+  e = slode_launch_ode(a, st, h->err, sizeof(h->err));
+  if (e == hipErrorInvalidValue) return SLODE_EINVAL;
+  HIP_TRY(h, e);
+
+  if (bwd) {
+    EncBwdLaunch eb{*s, *lay, params, obs, obs_strides[0], obs_strides[1], obs_strides[2], w.scale, w.pooled, w.hid,
+                    w.g_loc, w.g_scale, w.g_pre, w.small_slabs, w.small_stride, w.small_grid, w.lin_slabs, w.lin_splitk};
+    HIP_TRY(h, slode_launch_enc_bwd(eb, st));
+    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, w.small_slabs, w.small_stride, w.small_grid,
+                   w.lin_slabs, w.lin_splitk, grads, loss_out, 1};
+    HIP_TRY(h, slode_launch_reduce(r, st));
+  } else {
+    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, nullptr, 0, 0, nullptr, 0, nullptr, loss_out, 0};
+    HIP_TRY(h, slode_launch_reduce(r, st));
+  }
+  return SLODE_OK;
+}
+
+int slode_adam_step(slode_handle h, int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float lr,
+                    float beta1, float beta2, float eps, int64_t step, void* stream) {
+  if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
+  if (n < 0 || step < 1 || !params || !grads || !exp_avg || !exp_avg_sq) return fail(h, SLODE_EINVAL, "bad Adam arguments");
+  if (n == 0) return SLODE_OK;
+  HIP_TRY(h, slode_launch_adam(n, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, (hipStream_t)stream));
+  return SLODE_OK;
+}
+
+}  // extern "C"

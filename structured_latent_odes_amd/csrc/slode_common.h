@@ -1,0 +1,135 @@
+// Shared declarations for libslode.so (gfx950 only).  Internal; the public ABI is include/slode.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/slode.h"
+
+#define SLODE_MAX_T 1024
+#define SLODE_MAX_S 8
+#define SLODE_MAX_H 32
+#define SLODE_MAX_L 64
+#define SLODE_MAX_C 4
+#define SLODE_MAX_NU 16
+#define SLODE_MAX_F 16
+#define SLODE_MAX_K 16
+#define SLODE_MAX_P 8
+#define SLODE_MAX_HC 64
+
+struct slode_ctx {
+  int device;
+  int num_cu;
+  char err[512];
+};
+
+// ---- device helpers -------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// sigmoid via v_exp_f32 / v_rcp_f32 (abs error < 1e-7 on the range the dynamics net produces)
+__device__ __forceinline__ float sigmoidf_fast(float x) {
+  return fast_rcp(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+// torch.nn.Softplus(beta=1, threshold=20): models/decoders.py:52
+__device__ __forceinline__ float softplusf(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Deterministic block-wide sum (fixed tree).  `scratch` needs blockDim.x/64 floats.  Result valid in every thread.
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[wave] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int w = 0; w < nw; ++w) r += scratch[w];
+  return r;
+}
+
+// ---- launch wrappers implemented in the kernel translation units ----------------------------------------
+struct OdeLaunch {
+  slode_shape s;
+  slode_layout lay;
+  const float* params;
+  const float* times;    // [T]
+  const float* stage_t;  // [R*(T-1)+1]
+  // fused-ELBO inputs
+  const float* obs;
+  int64_t sb, sc, st;    // element strides of the logical [B,C,T] observations
+  const float* u;        // [B,n_u]
+  const float* eps;      // [B,L]
+  const float* loc;      // [B,L]  (encoder output)
+  const float* scale;    // [B,L]
+  // solve-only inputs
+  const float* z_in;     // [B,L]  (when loc == nullptr)
+  const float* gx_in;    // [B,T,S] upstream gradient (solve-bwd); nullptr => likelihood gradient
+  // outputs
+  float* x_out;          // [B,T,S] or nullptr
+  float* z_out;          // [B,L] or nullptr
+  float* g_loc;          // [B,L]  (dLoss/dloc)   | solve-bwd: g_z
+  float* g_scale;        // [B,L]  or nullptr
+  float* slabs;          // [grid][slab_stride] per-workgroup partial results (slot 0 = loss, then ode segment)
+  int slab_stride;
+  int grid;
+  int backward;          // 0: forward only
+  int with_ll;           // 1: likelihood + latent terms (ELBO); 0: pure ODE solve
+};
+hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, size_t errlen);
+size_t slode_ode_lds_bytes(const slode_shape& s, int nthreads);
+int slode_ode_threads(const slode_shape& s);
+
+struct EncLaunch {
+  slode_shape s;
+  slode_layout lay;
+  const float* params;
+  const float* obs;
+  int64_t sb, sc, st;
+  float* loc;
+  float* scale;
+  float* pooled;  // [B, F*n_pool]
+  float* hid;     // [B, Hc]
+};
+hipError_t slode_launch_enc_fwd(const EncLaunch& a, hipStream_t stream);
+
+struct EncBwdLaunch {
+  slode_shape s;
+  slode_layout lay;
+  const float* params;
+  const float* obs;
+  int64_t sb, sc, st;
+  const float* scale;
+  const float* pooled;
+  const float* hid;
+  const float* g_loc;
+  const float* g_scale;
+  float* g_pre;        // [B, 64]   workspace: dLoss/d(lin pre-activation)
+  float* slabs_small;  // [grid_small][small_stride]: conv_w, conv_b, lin_b, zloc_w, zloc_b, zls_w, zls_b partials
+  int small_stride;
+  int grid_small;
+  float* slabs_lin;    // [splitk][Hc*FQ] partial lin.weight gradients
+  int splitk;
+};
+hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream);
+int slode_enc_small_count(const slode_shape& s);   // floats per small slab
+int slode_enc_bwd_grid(const slode_shape& s);
+int slode_enc_lin_splitk(const slode_shape& s);
+
+struct ReduceLaunch {
+  slode_shape s;
+  slode_layout lay;
+  const float* ode_slabs; int ode_stride; int ode_n;       // may be null
+  const float* small_slabs; int small_stride; int small_n; // may be null
+  const float* lin_slabs; int lin_n;                       // may be null
+  float* grads;       // flat gradient (may be null when only the loss is wanted)
+  float* loss_out;    // may be null
+  int zero_rest;      // also zero grads outside the written segments [0, n_params)
+};
+hipError_t slode_launch_reduce(const ReduceLaunch& a, hipStream_t stream);
+
+hipError_t slode_launch_stage_times(const slode_shape& s, const float* times, float* stage_t, hipStream_t stream);
+hipError_t slode_launch_decode_heads(const slode_shape& s, const slode_layout& lay, const float* params,
+                                     const float* x, float* mu, float* std_ct, hipStream_t stream);
+hipError_t slode_launch_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2,
+                             float eps, int64_t step, hipStream_t stream);

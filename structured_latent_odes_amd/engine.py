@@ -1,0 +1,266 @@
+"""Host-side engine: owns the libslode handle, the parameter layout and the workspaces; every method is one call
+through the C ABI (include/slode.h) on the caller's current HIP stream.  PyTorch tensors are storage only."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+@dataclass
+class PriorGroup:
+    """p(z_g | u_g): latent dims [z_off, z_off+z_dim), label columns [u_off, u_off+u_dim) of u.
+    `prefix` is the reference attribute name of the EncoderMLP (e.g. 'p_z_iext_given_iext')."""
+    prefix: str
+    z_off: int
+    z_dim: int
+    u_off: int
+    u_dim: int
+
+
+@dataclass
+class ModelSpec:
+    """Shape of one of the reference's three model families (models/mechanistic_{cvs,proc,challenge}[_Gauss].py)."""
+    name: str
+    gauss: bool
+    n_channels: int
+    latent_dim: int
+    z_eps_dim: int
+    n_u: int
+    prior_groups: List[PriorGroup]
+    ode_state_dim: int = 5
+    ode_hidden_dim: int = 25
+    n_filters: int = 10
+    filter_size: int = 10
+    pool_size: int = 5
+    cnn_hidden_dim: int = 50
+    solver: str = "midpoint"
+    quantile_diff: float = 0.475
+
+    @property
+    def head_names(self) -> List[str]:
+        return ["output_mean"] if self.gauss else ["output_q50", "output_q75", "output_q25"]
+
+
+def _check(lib, handle, rc):
+    if rc != 0:
+        msg = lib.slode_last_error(handle)
+        raise L.SlodeError("libslode call failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+
+
+class Engine:
+    def __init__(self, spec: ModelSpec, n_time: int, device: Optional[torch.device] = None):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.SlodeError("no HIP device visible: the slode engine has no CPU fallback")
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise L.SlodeError("the slode engine runs on a HIP device only, got %s" % self.device)
+        self.spec, self.T = spec, int(n_time)
+        self.handle = C.c_void_p()
+        _check(self.lib, None, self.lib.slode_create(C.byref(self.handle), self.device.index or 0))
+        self._shapes: Dict[int, L.Shape] = {}
+        self.layout = L.Layout()
+        _check(self.lib, None, self.lib.slode_layout_init(C.byref(self.shape(1)), C.byref(self.layout)))
+        self.n_params = int(self.layout.n_params)
+        self._ws: Dict[int, torch.Tensor] = {}
+        self._stage_t: Optional[torch.Tensor] = None
+        self._times: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.slode_destroy(self.handle)
+        except Exception:
+            pass
+
+    # ---- shapes / layout ---------------------------------------------------------------------------------
+    def shape(self, B: int) -> L.Shape:
+        s = self._shapes.get(B)
+        if s is None:
+            sp = self.spec
+            if sp.solver not in L.METHODS:
+                raise ValueError("unknown solver %r" % sp.solver)
+            s = L.Shape(B=B, T=self.T, C=sp.n_channels, L=sp.latent_dim, S=sp.ode_state_dim, H=sp.ode_hidden_dim,
+                        F=sp.n_filters, K=sp.filter_size, P=sp.pool_size, Hc=sp.cnn_hidden_dim, n_u=sp.n_u,
+                        n_groups=len(sp.prior_groups), method=L.METHODS[sp.solver],
+                        likelihood=L.GAUSS if sp.gauss else L.ALD, quantile_diff=sp.quantile_diff, rtol=1e-7, atol=1e-9)
+            for i, g in enumerate(sp.prior_groups):
+                s.groups[i] = L.Group(g.z_off, g.z_dim, g.u_off, g.u_dim)
+            self._shapes[B] = s
+        return s
+
+    def param_table(self) -> List[Tuple[str, int, Tuple[int, ...]]]:
+        """(reference state_dict key, offset, shape) of every tensor of the flat layout, in layout order."""
+        sp, lay, T = self.spec, self.layout, self.T
+        C_, Ld, S, H, F, K, Hc = sp.n_channels, sp.latent_dim, sp.ode_state_dim, sp.ode_hidden_dim, sp.n_filters, sp.filter_size, sp.cnn_hidden_dim
+        FQ = F * (T - K + 1 - sp.pool_size + 1)
+        t = [("encoder.conv.weight", lay.conv_w, (F, C_, K)), ("encoder.conv.bias", lay.conv_b, (F,)),
+             ("encoder.lin.weight", lay.lin_w, (Hc, FQ)), ("encoder.lin.bias", lay.lin_b, (Hc,)),
+             ("encoder.z_loc.weight", lay.zloc_w, (Ld, Hc)), ("encoder.z_loc.bias", lay.zloc_b, (Ld,)),
+             ("encoder.z_scale.0.weight", lay.zls_w, (Ld, Hc)), ("encoder.z_scale.0.bias", lay.zls_b, (Ld,))]
+        for i, g in enumerate(sp.prior_groups):
+            t += [(g.prefix + ".sequential_mlp.1.0.0.weight", lay.ploc_w[i], (g.z_dim, g.u_dim)),
+                  (g.prefix + ".sequential_mlp.1.0.0.bias", lay.ploc_b[i], (g.z_dim,)),
+                  (g.prefix + ".sequential_mlp.1.1.0.weight", lay.pls_w[i], (g.z_dim, g.u_dim)),
+                  (g.prefix + ".sequential_mlp.1.1.0.bias", lay.pls_b[i], (g.z_dim,))]
+        o = "decoder.ode_model."
+        t += [(o + "latent_to_ode_net.0.weight", lay.init_w1, (H, Ld)), (o + "latent_to_ode_net.0.bias", lay.init_b1, (H,)),
+              (o + "latent_to_ode_net.2.weight", lay.init_w2, (S, H)), (o + "latent_to_ode_net.2.bias", lay.init_b2, (S,)),
+              (o + "dynamics.dynamics_hidden.weight", lay.dyn_wh, (H, 1 + Ld)), (o + "dynamics.dynamics_hidden.bias", lay.dyn_bh, (H,)),
+              (o + "dynamics.dyanamics_growth.weight", lay.dyn_wg, (S, H)), (o + "dynamics.dyanamics_growth.bias", lay.dyn_bg, (S,)),
+              (o + "dynamics.dyanmics_degradation.weight", lay.dyn_wd, (S, H)), (o + "dynamics.dyanmics_degradation.bias", lay.dyn_bd, (S,))]
+        for i, hn in enumerate(sp.head_names):
+            t.append(("decoder.%s.0.weight" % hn, lay.head_w[i], (C_, S)))
+        t.append(("decoder.constant_std", lay.cstd, (C_, T)))
+        return t
+
+    def pack(self, params: Dict[str, torch.Tensor], flat: Optional[torch.Tensor] = None, extra: int = 0) -> torch.Tensor:
+        """Copy a reference-keyed parameter dict into a flat device vector (n_params + extra floats)."""
+        if flat is None:
+            flat = torch.zeros(self.n_params + extra, dtype=torch.float32, device=self.device)
+        for key, off, shp in self.param_table():
+            n = 1
+            for d in shp:
+                n *= d
+            flat[off:off + n].copy_(params[key].reshape(-1).to(torch.float32))
+        return flat
+
+    def unpack(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        out = {}
+        for key, off, shp in self.param_table():
+            n = 1
+            for d in shp:
+                n *= d
+            out[key] = flat[off:off + n].view(*shp)
+        return out
+
+    # ---- plumbing ----------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _p(t: Optional[torch.Tensor]):
+        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+    def _f32(self, t: torch.Tensor, name: str, contiguous: bool = True) -> torch.Tensor:
+        if t.device != self.device or t.dtype != torch.float32:
+            raise ValueError("%s must be a float32 tensor on %s (got %s on %s)" % (name, self.device, t.dtype, t.device))
+        if contiguous and not t.is_contiguous():
+            raise ValueError("%s must be contiguous" % name)
+        return t
+
+    def workspace(self, B: int) -> torch.Tensor:
+        w = self._ws.get(B)
+        if w is None:
+            nbytes = int(self.lib.slode_workspace_bytes(self.handle, C.byref(self.shape(B))))
+            if nbytes == 0:
+                _check(self.lib, None, -1)
+            w = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+            self._ws[B] = w
+        return w
+
+    def set_times(self, times: torch.Tensor) -> torch.Tensor:
+        """Bind the time grid (len T) and build the stage-time table on device."""
+        times = self._f32(times.to(self.device, torch.float32).contiguous(), "times")
+        if times.numel() != self.T:
+            raise ValueError("times has %d points, engine built for T=%d" % (times.numel(), self.T))
+        n = int(self.lib.slode_num_stage_times(C.byref(self.shape(1))))
+        st = torch.empty(n, dtype=torch.float32, device=self.device)
+        _check(self.lib, self.handle, self.lib.slode_stage_times(self.handle, C.byref(self.shape(1)), self._p(times), self._p(st), self._stream()))
+        self._times, self._stage_t = times, st
+        return st
+
+    def _obs_strides(self, obs: torch.Tensor):
+        if obs.dim() != 3 or obs.shape[1] != self.spec.n_channels or obs.shape[2] != self.T:
+            raise ValueError("observations must be [B, %d, %d], got %s" % (self.spec.n_channels, self.T, tuple(obs.shape)))
+        return (C.c_int64 * 3)(*obs.stride())
+
+    # ---- ops (one C-ABI call each) ---------------------------------------------------------------------------
+    def encoder_fwd(self, params, obs, save: bool = True):
+        B = obs.shape[0]
+        sp = self.spec
+        self._f32(obs, "observations", contiguous=False)
+        FQ = sp.n_filters * (self.T - sp.filter_size + 1 - sp.pool_size + 1)
+        loc = torch.empty(B, sp.latent_dim, dtype=torch.float32, device=self.device)
+        scale = torch.empty_like(loc)
+        pooled = torch.empty(B, FQ, dtype=torch.float32, device=self.device) if save else None
+        hid = torch.empty(B, sp.cnn_hidden_dim, dtype=torch.float32, device=self.device) if save else None
+        _check(self.lib, self.handle, self.lib.slode_encoder_conv_fwd(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(obs), self._obs_strides(obs),
+            self._p(loc), self._p(scale), self._p(pooled), self._p(hid), self._stream()))
+        return loc, scale, pooled, hid
+
+    def encoder_bwd(self, params, obs, scale, pooled, hid, g_loc, g_scale, grads):
+        B = obs.shape[0]
+        ws = self.workspace(B)
+        _check(self.lib, self.handle, self.lib.slode_encoder_conv_bwd(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(obs), self._obs_strides(obs),
+            self._p(scale), self._p(pooled), self._p(hid), self._p(self._f32(g_loc, "g_loc")), self._p(self._f32(g_scale, "g_scale")),
+            self._p(grads), self._p(ws), ws.numel() * 4, self._stream()))
+        return grads
+
+    def ode_solve(self, params, z):
+        B = z.shape[0]
+        x = torch.empty(B, self.T, self.spec.ode_state_dim, dtype=torch.float32, device=self.device)
+        _check(self.lib, self.handle, self.lib.slode_ode_solve_fwd(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._times), self._p(self._stage_t),
+            self._p(self._f32(z, "z")), self._p(x), self._stream()))
+        return x
+
+    def ode_solve_bwd(self, params, z, g_x, grads):
+        B = z.shape[0]
+        ws = self.workspace(B)
+        g_z = torch.empty_like(z)
+        _check(self.lib, self.handle, self.lib.slode_ode_solve_bwd(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._times), self._p(self._stage_t),
+            self._p(self._f32(z, "z")), self._p(self._f32(g_x, "g_x")), self._p(g_z), self._p(grads), self._p(ws), ws.numel() * 4, self._stream()))
+        return g_z
+
+    def decode_heads(self, params, x):
+        B = x.shape[0]
+        sp = self.spec
+        Q = 1 if sp.gauss else 3
+        mu = torch.empty(Q, B, sp.n_channels, self.T, dtype=torch.float32, device=self.device)
+        std = torch.empty(sp.n_channels, self.T, dtype=torch.float32, device=self.device)
+        _check(self.lib, self.handle, self.lib.slode_decode_heads(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._f32(x, "x")), self._p(mu), self._p(std), self._stream()))
+        return mu, std
+
+    def elbo_step(self, params, obs, u, eps, loss_out, grads=None, x_out=None, z_out=None):
+        """-ELBO (summed over the batch) into loss_out[0]; exact gradient into grads (flat) unless grads is None."""
+        B = obs.shape[0]
+        ws = self.workspace(B)
+        _check(self.lib, self.handle, self.lib.slode_elbo_step(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._times), self._p(self._stage_t),
+            self._p(obs), self._obs_strides(obs), self._p(u), self._p(eps), self._p(loss_out), self._p(grads), self._p(x_out), self._p(z_out),
+            self._p(ws), ws.numel() * 4, self._stream()))
+        return loss_out
+
+    def adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-8):
+        _check(self.lib, self.handle, self.lib.slode_adam_step(
+            self.handle, params.numel(), self._p(params), self._p(grads), self._p(exp_avg), self._p(exp_avg_sq),
+            float(lr), float(betas[0]), float(betas[1]), float(eps), int(step), self._stream()))
+
+
+def cvs_spec(z_iext=5, z_rtpr=5, z_eps=5, gauss=False, solver="midpoint", quantile_diff=0.475) -> ModelSpec:
+    """data/cvs/config_cvs.py:6-52; u = [iext, rtpr] columns (models/mechanistic_cvs.py:131-135)."""
+    return ModelSpec("cvs", gauss, 3, z_iext + z_rtpr + z_eps, z_eps, 2,
+                     [PriorGroup("p_z_iext_given_iext", 0, z_iext, 0, 1), PriorGroup("p_z_rtprs_given_rtprs", z_iext, z_rtpr, 1, 1)],
+                     solver=solver, quantile_diff=quantile_diff)
+
+
+def challenge_spec(z_shed=5, z_symp=5, z_eps=5, gauss=False, solver="midpoint", quantile_diff=0.475) -> ModelSpec:
+    """data/challenge/config_challenge.py; u = cat(symptoms, shedding) (models/mechanistic_challenge.py:167)."""
+    return ModelSpec("challenge", gauss, 4, z_shed + z_symp + z_eps, z_eps, 2, [PriorGroup("p_z_u_given_u", 0, z_shed + z_symp, 0, 2)],
+                     solver=solver, quantile_diff=quantile_diff)
+
+
+def proc_spec(z_g=10, z_eps=10, gauss=False, solver="midpoint", quantile_diff=0.475) -> ModelSpec:
+    """data/proc/config_proc.py; u = cat(aR[3], aS[4], C12, C6) (models/mechanistic_proc.py:196-198)."""
+    return ModelSpec("proc", gauss, 4, 4 * z_g + z_eps, z_eps, 9, [PriorGroup("p_z_u_given_u", 0, 4 * z_g, 0, 9)],
+                     ode_state_dim=8, solver=solver, quantile_diff=quantile_diff)

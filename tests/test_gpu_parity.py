@@ -1,0 +1,249 @@
+"""GPU parity tests: the HIP path (libslode.so through the C ABI) against the CPU oracle on identical seeded inputs.
+Run on an MI355X with ``pytest -m gpu``.  Tolerances (fp32 path, stated per test):
+  * stage-time table: bit-exact;  * encoder loc/scale: 2e-5 relative;  * latent trajectories: 1e-5 * max(1, |x|);
+  * -ELBO: 1e-5 relative (north-star bar: 1e-4);  * gradients: 5e-4 norm-wise relative per tensor vs the fp64 oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import slode_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # name: (oracle spec factory, kwargs, B, T)
+    "cvs_c1_rk4": ("cvs", dict(z_iext=3, z_rtpr=3, z_eps=2, solver="rk4"), 48, 200),        # BASELINE config[1] shapes
+    "cvs_c0_rk4": ("cvs", dict(z_iext=1, z_rtpr=1, z_eps=2, solver="rk4"), 32, 100),        # BASELINE config[0]
+    "cvs_ref_midpoint": ("cvs", dict(solver="midpoint"), 37, 86),                           # reference default, ragged B
+    "cvs_gauss_euler": ("cvs", dict(gauss=True, solver="euler"), 16, 86),
+    "challenge_c4_rk4_gauss": ("challenge", dict(gauss=True, solver="rk4"), 12, 300),       # BASELINE config[4] shapes
+    "challenge_ald_midpoint": ("challenge", dict(solver="midpoint"), 9, 142),
+}
+
+
+def _mk(case):
+    from structured_latent_odes_amd import engine as E
+    fam, kw, B, T = CASES[case]
+    ospec = {"cvs": O.cvs_spec, "challenge": O.challenge_spec}[fam](**kw)
+    espec = {"cvs": E.cvs_spec, "challenge": E.challenge_spec}[fam](**kw)
+    p = O.init_params(ospec, T=T)
+    g = torch.Generator().manual_seed(11)
+    # move off the near-zero initialisation so every gradient path is exercised; keep std params positive-ish
+    p = {k: v + 0.05 * torch.randn(v.shape, generator=g) for k, v in p.items()}
+    obs, u, eps, times = O.synthetic_batch(ospec, B, T)
+    dev = torch.device("cuda:0")
+    eng = E.Engine(espec, T, dev)
+    eng.set_times(times)
+    flat = eng.pack(p)
+    obs_d = obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)   # [B,C,T] view of contiguous [B,T,C]
+    return dict(ospec=ospec, p=p, obs=obs, u=u, eps=eps, times=times, eng=eng, flat=flat, obs_d=obs_d,
+                u_d=u.to(dev).contiguous(), eps_d=eps.to(dev).contiguous(), dev=dev, B=B, T=T)
+
+
+@pytest.fixture(scope="module", params=list(CASES))
+def ctx(request):
+    return _mk(request.param)
+
+
+def _close(a, b, tol=1e-5):
+    """|a - b| <= tol * max(1, |b|) element-wise (trajectories are O(1); the perturbed test weights can push them higher)."""
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs() / b.abs().clamp_min(1.0)).max().item() < tol
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def test_library_loaded_from_tree():
+    from structured_latent_odes_amd import _lib
+    lib = _lib.load()
+    assert lib.slode_version() >= 100
+    assert os.path.dirname(_lib.LIB_PATH).endswith("structured_latent_odes_amd")
+
+
+def test_stage_times_bit_exact(ctx):
+    want = O.stage_times(ctx["times"], ctx["ospec"].solver)
+    assert torch.equal(ctx["eng"]._stage_t.cpu(), want)
+
+
+def test_encoder_forward(ctx):
+    loc, scale, pooled, hid = ctx["eng"].encoder_fwd(ctx["flat"], ctx["obs_d"])
+    wl, ws = O.encoder_conv(ctx["p"], ctx["obs"], ctx["ospec"].pool_size)
+    assert _rel(loc, wl) < 2e-5 and _rel(scale, ws) < 2e-5
+    # contiguous [B,C,T] input (the proc layout) gives the same result as the permuted view
+    loc2, scale2, _, _ = ctx["eng"].encoder_fwd(ctx["flat"], ctx["obs_d"].contiguous())
+    assert torch.equal(loc, loc2) and torch.equal(scale, scale2)
+
+
+def test_ode_solve_forward(ctx):
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(ctx["B"], ctx["ospec"].latent_dim, generator=g)
+    x = ctx["eng"].ode_solve(ctx["flat"], z.to(ctx["dev"]))
+    want = O.solve_ode(ctx["p"], z, ctx["times"], ctx["ospec"].solver)
+    assert _close(x, want)
+    want64 = O.solve_ode({k: v.double() for k, v in ctx["p"].items()}, z.double(), ctx["times"].double(), ctx["ospec"].solver)
+    assert _close(x, want64)
+
+
+def test_decode_heads(ctx):
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(ctx["B"], ctx["T"], 5, generator=g)
+    mu, std = ctx["eng"].decode_heads(ctx["flat"], x.to(ctx["dev"]))
+    import torch.nn.functional as F
+    names = ["decoder.output_mean.0.weight"] if ctx["ospec"].gauss else ["decoder.output_%s.0.weight" % q for q in ("q50", "q75", "q25")]
+    for i, n in enumerate(names):
+        assert _rel(mu[i], F.linear(x, ctx["p"][n]).permute(0, 2, 1)) < 1e-6
+    assert _rel(std, F.softplus(ctx["p"]["decoder.constant_std"])) < 1e-6
+
+
+def test_elbo_loss_and_trajectories(ctx):
+    eng, dev = ctx["eng"], ctx["dev"]
+    loss = torch.zeros(1, device=dev)
+    x = torch.empty(ctx["B"], ctx["T"], 5, device=dev)
+    z = torch.empty(ctx["B"], ctx["ospec"].latent_dim, device=dev)
+    eng.elbo_step(ctx["flat"], ctx["obs_d"], ctx["u_d"], ctx["eps_d"], loss, grads=None, x_out=x, z_out=z)
+    with torch.no_grad():
+        want, parts = O.main_loss(ctx["p"], ctx["ospec"], ctx["obs"], ctx["u"], ctx["eps"], ctx["times"], return_parts=True)
+    assert _rel(z, parts["z"]) < 2e-5
+    assert _close(x, parts["dec"][0])
+    assert abs(loss.item() - want.item()) / abs(want.item()) < 1e-5, (loss.item(), want.item())
+
+
+def test_elbo_gradients(ctx):
+    eng, dev = ctx["eng"], ctx["dev"]
+    loss = torch.zeros(1, device=dev)
+    grads = torch.full((eng.n_params,), float("nan"), device=dev)
+    eng.elbo_step(ctx["flat"], ctx["obs_d"], ctx["u_d"], ctx["eps_d"], loss, grads=grads)
+    p64 = {k: v.double() for k, v in ctx["p"].items()}
+    want_loss, want = O.loss_and_grads(p64, ctx["ospec"], ctx["obs"].double(), ctx["u"].double(), ctx["eps"].double(), ctx["times"].double())
+    assert abs(loss.item() - want_loss.item()) / abs(want_loss.item()) < 1e-5
+    got = eng.unpack(grads)
+    assert torch.isfinite(grads).all()
+    worst = {}
+    for k, v in got.items():
+        worst[k] = _rel(v, want[k])
+    bad = {k: e for k, e in worst.items() if e > 5e-4}
+    assert not bad, bad
+    # forward-only evaluation gives the same loss value (SVI.evaluate_loss vs SVI.step, training_cvs.py:81,152)
+    loss2 = torch.zeros(1, device=dev)
+    eng.elbo_step(ctx["flat"], ctx["obs_d"], ctx["u_d"], ctx["eps_d"], loss2, grads=None)
+    assert loss2.item() == loss.item()
+
+
+def test_bitwise_reproducible(ctx):
+    eng, dev = ctx["eng"], ctx["dev"]
+    outs = []
+    for _ in range(2):
+        loss = torch.zeros(1, device=dev)
+        grads = torch.zeros(eng.n_params, device=dev)
+        eng.elbo_step(ctx["flat"], ctx["obs_d"], ctx["u_d"], ctx["eps_d"], loss, grads=grads)
+        outs.append((loss.clone(), grads.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_encoder_backward_standalone(ctx):
+    eng, dev, B = ctx["eng"], ctx["dev"], ctx["B"]
+    L = ctx["ospec"].latent_dim
+    g = torch.Generator().manual_seed(8)
+    g_loc, g_scale = torch.randn(B, L, generator=g), torch.randn(B, L, generator=g)
+    loc, scale, pooled, hid = eng.encoder_fwd(ctx["flat"], ctx["obs_d"])
+    grads = torch.zeros(eng.n_params, device=dev)
+    eng.encoder_bwd(ctx["flat"], ctx["obs_d"], scale, pooled, hid, g_loc.to(dev), g_scale.to(dev), grads)
+    q = {k: v.double().requires_grad_(k.startswith("encoder.")) for k, v in ctx["p"].items()}
+    wl, ws = O.encoder_conv(q, ctx["obs"].double(), ctx["ospec"].pool_size)
+    ((wl * g_loc.double()).sum() + (ws * g_scale.double()).sum()).backward()
+    got = eng.unpack(grads)
+    for k in q:
+        if k.startswith("encoder."):
+            assert _rel(got[k], q[k].grad) < 2e-4, k
+
+
+def test_ode_solve_backward_standalone(ctx):
+    eng, dev, B, T = ctx["eng"], ctx["dev"], ctx["B"], ctx["T"]
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(B, ctx["ospec"].latent_dim, generator=g)
+    gx = torch.randn(B, T, 5, generator=g)
+    grads = torch.zeros(eng.n_params, device=dev)
+    gz = eng.ode_solve_bwd(ctx["flat"], z.to(dev), gx.to(dev), grads)
+    q = {k: v.double().requires_grad_("ode_model" in k) for k, v in ctx["p"].items()}
+    zz = z.double().requires_grad_(True)
+    (O.solve_ode(q, zz, ctx["times"].double(), ctx["ospec"].solver) * gx.double()).sum().backward()
+    assert _rel(gz, zz.grad) < 5e-4
+    got = eng.unpack(grads)
+    for k in q:
+        if "ode_model" in k:
+            assert _rel(got[k], q[k].grad) < 5e-4, k
+
+
+def test_golden_reference_vectors_on_gpu(golden_dir):
+    """The reference's own outputs (tests/golden, generated from the reference modules) through the HIP path."""
+    from structured_latent_odes_amd import engine as E
+    dev = torch.device("cuda:0")
+    g1 = np.load(os.path.join(golden_dir, "g1_encoder_conv.npz"))
+    for case in range(5):
+        B, C, T, L = [int(v) for v in g1["c%d.meta" % case]]
+        spec = E.ModelSpec("golden", False, C, L, L, 0, [])
+        eng = E.Engine(spec, T, dev)
+        p = {"encoder." + k[len("c%d.p." % case):]: torch.from_numpy(g1[k]) for k in g1.files if k.startswith("c%d.p." % case)}
+        flat = torch.zeros(eng.n_params, device=dev)
+        for key, off, shp in eng.param_table():
+            if key in p:
+                flat[off:off + p[key].numel()] = p[key].reshape(-1).to(dev)
+        x = torch.from_numpy(g1["c%d.x" % case]).to(dev)
+        loc, scale, _, _ = eng.encoder_fwd(flat, x, save=False)
+        assert _rel(loc, torch.from_numpy(g1["c%d.loc" % case])) < 2e-5
+        assert _rel(scale, torch.from_numpy(g1["c%d.scale" % case])) < 2e-5
+    g3 = np.load(os.path.join(golden_dir, "g3_dynamics.npz"))
+    for case, (L, S) in enumerate([(4, 5), (8, 5), (15, 5), (50, 8)]):
+        spec = E.ModelSpec("golden", False, 3, L, L, 0, [], ode_state_dim=S, solver="euler")
+        T = 100
+        eng = E.Engine(spec, T, dev)
+        eng.set_times(torch.arange(T, dtype=torch.float32) * 0.01)
+        p = {k[len("d%d.p." % case):]: torch.from_numpy(g3[k]) for k in g3.files if k.startswith("d%d.p." % case)}
+        flat = torch.zeros(eng.n_params, device=dev)
+        for key, off, shp in eng.param_table():
+            if key in p:
+                flat[off:off + p[key].numel()] = p[key].reshape(-1).to(dev)
+        z = torch.from_numpy(g3["d%d.z" % case]).to(dev)
+        x = eng.ode_solve(flat, z)
+        # x[:,0] is OdeModel.initialize_state(z) (blackbox_ode.py:32-34); the first euler step is x0 + dt*f(0, x0)
+        x0 = torch.from_numpy(g3["d%d.x0" % case])
+        assert (x[:, 0].cpu() - x0).abs().max().item() < 2e-6
+        f0 = O.dynamics(p, torch.tensor(0.0), x0, torch.from_numpy(g3["d%d.z" % case]))
+        assert (x[:, 1].cpu() - (x0 + 0.01 * f0)).abs().max().item() < 2e-6
+
+
+def test_full_size_batch_linearity():
+    """BASELINE config[1] at full size (B=1024, T=200): the loss and gradient are sums over trajectories, so the
+    step over the whole batch equals the sum over its two halves (size-independent property; also the data-parallel
+    contract of SURVEY 8e)."""
+    from structured_latent_odes_amd import engine as E
+    dev = torch.device("cuda:0")
+    ospec = O.cvs_spec(3, 3, 2, solver="rk4")
+    B, T = 1024, 200
+    p = O.init_params(ospec, T=T)
+    obs, u, eps, times = O.synthetic_batch(ospec, B, T)
+    eng = E.Engine(E.cvs_spec(3, 3, 2, solver="rk4"), T, dev)
+    eng.set_times(times)
+    flat = eng.pack(p)
+    obs_d = obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)
+    u_d, eps_d = u.to(dev), eps.to(dev)
+
+    def run(sl):
+        loss, grads = torch.zeros(1, device=dev), torch.zeros(eng.n_params, device=dev)
+        eng.elbo_step(flat, obs_d[sl], u_d[sl].contiguous(), eps_d[sl].contiguous(), loss, grads)
+        return loss.double().cpu(), grads.double().cpu()
+    l_all, g_all = run(slice(0, B))
+    l_a, g_a = run(slice(0, B // 2))
+    l_b, g_b = run(slice(B // 2, B))
+    assert abs((l_a + l_b - l_all).item()) / abs(l_all.item()) < 1e-6
+    assert ((g_a + g_b - g_all).norm() / g_all.norm()).item() < 1e-5
+    # spot-check 32 trajectories of the full-size batch against the oracle
+    with torch.no_grad():
+        want = O.main_loss(p, ospec, obs[:32], u[:32], eps[:32], times)
+    l32, _ = run(slice(0, 32))
+    assert abs(l32.item() - want.item()) / abs(want.item()) < 1e-5
