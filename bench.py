@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Headline benchmark: trajectories/sec of one ELBO step (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one synthetic CVS-shaped minibatch shard: encoder -> latent sample -> rk4
+(3/8-rule) latent-ODE solve over T=200 -> 3 quantile heads -> asymmetric-Laplace likelihood + latent log-probs ->
+-ELBO -> exact gradient of all 96,462 parameters (one slode_elbo_step call) -> [N>1: one RCCL SUM all-reduce of the flat
+gradient + loss scalar] -> Adam (one slode_adam_step call).  Workload = BASELINE config[1] "Synthetic CVS batch=1024,
+T=200, latent_dim=8, blackbox_ode RK4" per GPU; N GPUs run N such shards (config[3]: 8 x 1024 = 8192) => weak scaling.
+Inputs are generated on the host from a seed and are resident in HBM before the timed region starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]        # N>1: launched under torch.distributed.run, one rank/GPU
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the step, measured live with HIP events on the
+launch stream (slode_profile_*); `cpu_baseline` is the oracle (reference-equivalent eager-PyTorch CPU restatement,
+oracle/slode_oracle.py) timed on this box's host cores on the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU, T, Z_SPLIT = 1024, 200, (3, 3, 2)
+
+# Algorithmic FLOPs per trajectory of the forward pass (hidden z-part hoisted, each distinct stage time
+# evaluated once), fwd+bwd = 3x.  Per kernel:
+FLOP_FWD = {"enc": 312_550, "ode": 335_280 + 7_960 + 18_000 + 18_000}
+KERNEL_FLOPS = {  # fwd+bwd algorithmic FLOPs per trajectory attributed to each kernel of the step
+    "enc_fwd": FLOP_FWD["enc"],
+    "ode_elbo": 3 * FLOP_FWD["ode"],
+    "enc_bwd": 2 * FLOP_FWD["enc"] - 2 * 10 * 187 * 50,      # everything of the encoder backward but the lin.weight GEMM
+    "enc_bwd_lin": 2 * 10 * 187 * 50,                        # [Hc x B] x [B x F*n_pool] on the f32 MFMA
+    "reduce": 0,
+}
+BYTES_PER_TRAJ = 4 * (3 * T + 8 + 2)            # algorithmic HBM bytes: obs once + eps + labels = 2,440 B
+PEAK_FP32 = 157.3                               # TFLOP/s, fp32 vector == fp32 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM = 8000.0                               # GB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    from oracle import slode_oracle as O            # synthetic data + reference initialisers (and the cpu_baseline leg)
+    from structured_latent_odes_amd import engine as E
+    from structured_latent_odes_amd.svi import ELBOStep, FlatAdam
+
+    ospec = O.cvs_spec(*Z_SPLIT, solver="rk4")
+    params = O.init_params(ospec, T=T, seed=12)                     # identical on every rank (config_cvs.py:28 seed)
+    obs, u, eps, times = O.synthetic_batch(ospec, B_PER_GPU, T, seed=1234 + rank)   # this rank's shard
+    eng = E.Engine(E.cvs_spec(*Z_SPLIT, solver="rk4"), T, dev)
+    eng.set_times(times)
+    flat = eng.pack(params)
+    obs_d = obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)   # [B,C,T] view of contiguous [B,T,C] (native layout)
+    u_d, eps_d = u.to(dev).contiguous(), eps.to(dev).contiguous()
+    opt = FlatAdam(eng, flat, lr=1e-3)
+    svi = ELBOStep(eng, flat, opt)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        svi.step_async(obs_d, eps=eps_d, u=u_d)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        svi.step_async(obs_d, eps=eps_d, u=u_d)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    final_loss = float(svi.loss.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * B_PER_GPU * args.steps / dt
+
+    # ---- per-kernel durations (HIP events on the launch stream), same steps, instrumented second pass --------------
+    eng.profile_enable(True)
+    acc = {}
+    n_prof = min(args.steps, 50)
+    for _ in range(n_prof):
+        svi.step_async(obs_d, eps=eps_d, u=u_d)
+        for k, v in eng.profile_read().items():
+            acc[k] = acc.get(k, 0.0) + v
+    eng.profile_enable(False)
+    kern_us = {k: 1e3 * v / n_prof for k, v in acc.items()}
+    dom = max(kern_us, key=kern_us.get)
+    flops_launch = KERNEL_FLOPS[dom] * B_PER_GPU
+    achieved = flops_launch / (kern_us[dom] * 1e-6) / 1e12
+    step_flops = sum(KERNEL_FLOPS.values()) * B_PER_GPU
+
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "trajectories/sec ELBO step (CVS, batch=1024, T=200)", "value": value, "unit": "trajectories/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config[1]: synthetic CVS, B=1024/GPU, T=200, C=3, latent_dim=8 (3,3,2), S=5, "
+                               "rk4(3/8) fixed grid dt=1, ALD 3-quantile likelihood; step = ELBO fwd+bwd (all 96,462 params) "
+                               "+ grad all-reduce (N>1) + Adam",
+                   "global_batch": world * B_PER_GPU, "T": T, "parallelism": "dp%d" % world},
+        "final_loss_per_traj": final_loss / (world * B_PER_GPU),
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32, "traffic": traffic,
+                     "algorithmic_flops_per_launch": flops_launch, "kernel_us": kern_us,
+                     "step_frac_fp32": step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32,
+                     "step_frac_hbm": (BYTES_PER_TRAJ * B_PER_GPU / (ms_per_step * 1e-3)) / 1e9 / PEAK_HBM,
+                     "note": "intensity ~850 FLOP/B => compute side of the ridge; fp32 vector peak == fp32 MFMA peak (157.3 TF)"},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        nthreads = torch.get_num_threads()
+        for _ in range(2):
+            O.loss_and_grads(params, ospec, obs, u, eps, times)
+        n_cpu, c0 = 0, time.perf_counter()
+        while n_cpu < 4 or (time.perf_counter() - c0 < 12.0 and n_cpu < 64):
+            O.loss_and_grads(params, ospec, obs, u, eps, times)
+            n_cpu += 1
+        cdt = time.perf_counter() - c0
+        out["cpu_baseline"] = {"value": B_PER_GPU * n_cpu / cdt, "unit": "trajectories/s", "cores": nthreads, "kind": "port",
+                               "sample": "same workload (B=1024, T=200, rk4), %d ELBO fwd+bwd steps (no Adam) after 2 warm-ups, "
+                                         "oracle/slode_oracle.py eager PyTorch fp32, torch threads=%d" % (n_cpu, nthreads)}
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -157,6 +157,13 @@ int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* la
 int slode_adam_step(slode_handle h, int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                     float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
 
+/* Measurement aid for bench.py's roofline block (no reference counterpart): when enabled, slode_elbo_step records HIP
+ * events on `stream` around each of its kernels; slode_profile_read waits for the last one and returns the durations in
+ * milliseconds of [encoder_fwd, ode_elbo (fused solve + ELBO fwd/bwd), encoder_bwd, encoder_bwd_lin (MFMA), reduce]. */
+#define SLODE_PROFILE_SLOTS 5
+int slode_profile_enable(slode_handle h, int on);
+int slode_profile_read(slode_handle h, float ms[SLODE_PROFILE_SLOTS]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -397,7 +397,7 @@ hipError_t slode_launch_enc_fwd(const EncLaunch& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream) {
+hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream, hipEvent_t mid) {
   EncK k = make_enck(a.s, a.lay, a.params);
   k.obs = a.obs; k.sb = a.sb; k.sc = a.sc; k.st = a.st;
   k.scale_in = a.scale; k.pooled_in = a.pooled; k.hid_in = a.hid; k.g_loc = a.g_loc; k.g_scale = a.g_scale;
@@ -415,6 +415,7 @@ hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream) {
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  if (mid) (void)hipEventRecord(mid, stream);
   // lin.weight gradient (MFMA split-K); consumes g_pre written by the kernel above (same stream => ordered)
   const int total_splits = a.splitk * 4;
   int per_wave = (a.s.B + total_splits - 1) / total_splits;

@@ -78,11 +78,14 @@ int slode_create(slode_handle* out, int device_id) {
   c->device = device_id;
   c->num_cu = prop.multiProcessorCount;
   c->err[0] = 0;
+  c->profile = 0; c->ev_ready = 0; c->ev_valid = 0;
   *out = c;
   return SLODE_OK;
 }
 
 int slode_destroy(slode_handle h) {
+  if (h && h->ev_ready)
+    for (int i = 0; i <= SLODE_PROFILE_SLOTS; ++i) (void)hipEventDestroy(h->ev[i]);
   delete h;
   return SLODE_OK;
 }
@@ -312,11 +315,15 @@ int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* la
   if (workspace_bytes < w.bytes) return fail(h, SLODE_ENOSPC, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
   hipStream_t st = (hipStream_t)stream;
   const bool bwd = grads != nullptr;
+  const bool prof = h->profile && h->ev_ready && bwd;
+#define SLODE_MARK(i) do { if (prof) (void)hipEventRecord(h->ev[i], st); } while (0)
+  SLODE_MARK(0);
 
   EncLaunch ef{*s, *lay, params, obs, obs_strides[0], obs_strides[1], obs_strides[2], w.loc, w.scale, w.pooled, w.hid};
   hipError_t e = slode_launch_enc_fwd(ef, st);
   if (e == hipErrorInvalidValue) return fail(h, SLODE_EINVAL, "unsupported encoder shape C=%d K=%d T=%d", s->C, s->K, s->T);
   HIP_TRY(h, e);
+  SLODE_MARK(1);
 
   OdeLaunch a{};
   a.s = *s; a.lay = *lay; a.params = params; a.times = times; a.stage_t = stage_t;
@@ -327,18 +334,41 @@ int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* la
   e = slode_launch_ode(a, st, h->err, sizeof(h->err));
   if (e == hipErrorInvalidValue) return SLODE_EINVAL;
   HIP_TRY(h, e);
+  SLODE_MARK(2);
 
   if (bwd) {
     EncBwdLaunch eb{*s, *lay, params, obs, obs_strides[0], obs_strides[1], obs_strides[2], w.scale, w.pooled, w.hid,
                     w.g_loc, w.g_scale, w.g_pre, w.small_slabs, w.small_stride, w.small_grid, w.lin_slabs, w.lin_splitk};
-    HIP_TRY(h, slode_launch_enc_bwd(eb, st));
+    HIP_TRY(h, slode_launch_enc_bwd(eb, st, prof ? h->ev[3] : nullptr));
+    SLODE_MARK(4);
     ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, w.small_slabs, w.small_stride, w.small_grid,
                    w.lin_slabs, w.lin_splitk, grads, loss_out, 1};
     HIP_TRY(h, slode_launch_reduce(r, st));
+    SLODE_MARK(5);
+    if (prof) h->ev_valid = 1;
   } else {
     ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, nullptr, 0, 0, nullptr, 0, nullptr, loss_out, 0};
     HIP_TRY(h, slode_launch_reduce(r, st));
   }
+  return SLODE_OK;
+}
+
+int slode_profile_enable(slode_handle h, int on) {
+  if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
+  if (on && !h->ev_ready) {
+    for (int i = 0; i <= SLODE_PROFILE_SLOTS; ++i) HIP_TRY(h, hipEventCreate(&h->ev[i]));
+    h->ev_ready = 1;
+  }
+  h->profile = on ? 1 : 0;
+  h->ev_valid = 0;
+  return SLODE_OK;
+}
+
+int slode_profile_read(slode_handle h, float ms[SLODE_PROFILE_SLOTS]) {
+  if (!h || !ms) return fail(h, SLODE_EINVAL, "handle / ms is NULL");
+  if (!h->ev_valid) return fail(h, SLODE_EINVAL, "no profiled slode_elbo_step (with gradients) has been recorded");
+  HIP_TRY(h, hipEventSynchronize(h->ev[SLODE_PROFILE_SLOTS]));
+  for (int i = 0; i < SLODE_PROFILE_SLOTS; ++i) HIP_TRY(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
   return SLODE_OK;
 }
 

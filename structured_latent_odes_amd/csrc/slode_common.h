@@ -19,6 +19,10 @@ struct slode_ctx {
   int device;
   int num_cu;
   char err[512];
+  int profile;            // record per-kernel events in slode_elbo_step
+  hipEvent_t ev[SLODE_PROFILE_SLOTS + 1];
+  int ev_ready;           // events created
+  int ev_valid;           // a profiled step has been recorded
 };
 
 // ---- device helpers -------------------------------------------------------------------------------------
@@ -111,7 +115,7 @@ struct EncBwdLaunch {
   float* slabs_lin;    // [splitk][Hc*FQ] partial lin.weight gradients
   int splitk;
 };
-hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream);
+hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream, hipEvent_t mid = nullptr);
 int slode_enc_small_count(const slode_shape& s);   // floats per small slab
 int slode_enc_bwd_grid(const slode_shape& s);
 int slode_enc_lin_splitk(const slode_shape& s);

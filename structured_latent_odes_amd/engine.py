@@ -247,6 +247,16 @@ class Engine:
             float(lr), float(betas[0]), float(betas[1]), float(eps), int(step), self._stream()))
 
 
+    def profile_enable(self, on: bool):
+        _check(self.lib, self.handle, self.lib.slode_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_read(self):
+        """Durations (ms) of the kernels of the last profiled elbo_step: enc_fwd, ode_elbo, enc_bwd, enc_bwd_lin, reduce."""
+        ms = (C.c_float * 5)()
+        _check(self.lib, self.handle, self.lib.slode_profile_read(self.handle, ms))
+        return dict(zip(("enc_fwd", "ode_elbo", "enc_bwd", "enc_bwd_lin", "reduce"), [float(v) for v in ms]))
+
+
 def cvs_spec(z_iext=5, z_rtpr=5, z_eps=5, gauss=False, solver="midpoint", quantile_diff=0.475) -> ModelSpec:
     """data/cvs/config_cvs.py:6-52; u = [iext, rtpr] columns (models/mechanistic_cvs.py:131-135)."""
     return ModelSpec("cvs", gauss, 3, z_iext + z_rtpr + z_eps, z_eps, 2,
