@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslode.so")
+LIB_PATH = os.environ.get("SLODE_LIB_PATH") or os.path.join(_HERE, "libslode.so")  # env override: diagnostics only
 
 MAX_GROUPS, MAX_HEADS = 4, 3
 EULER, MIDPOINT, RK4, DOPRI5 = 0, 1, 2, 3

@@ -14,6 +14,16 @@
 
 typedef const __attribute__((address_space(4))) float* cptr;
 
+#ifdef SLODE_STAMPS
+__device__ unsigned long long g_stamps_enc[32];
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps_enc[i] = wall_clock64(); } while (0)
+extern "C" int slode_debug_stamps_enc(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_enc), sizeof(unsigned long long) * 32);
+}
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int TBE = 4;       // trajectories per workgroup
@@ -48,18 +58,27 @@ __device__ __forceinline__ void load_obs_tile(const EncK& k, int b0, float* s_x)
 template <int C, int K>
 __global__ void __launch_bounds__(ENC_NT) enc_fwd_kernel(const EncK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CKP = ((C * K + 1) + 3) & ~3;  // taps + bias, padded to a multiple of 4 floats
   const int tid = threadIdx.x, NT = blockDim.x;
   const int T = k.T, F = k.F, n_conv = k.n_conv, n_pool = k.n_pool, FQ = k.FQ, Hc = k.Hc, L = k.L;
   float* s_x = smem;                               // [TBE][C][T]
   float* s_conv = s_x + TBE * C * T;               // [TBE][F][n_conv]
   float* s_pool = s_conv + TBE * F * n_conv;       // [TBE][FQ]
   float* s_hid = s_pool + TBE * FQ;                // [TBE][64]
+  float* s_cw = s_hid + TBE * 64;                  // [F][CKP] conv taps (+ bias in the last padded slot), rows 16-B aligned
+  float* s_hw = s_cw + F * CKP;                    // [2][L][Hc] z_loc / z_scale head weights
   const int b0 = blockIdx.x * TBE;
+  STAMP(0);
 
   load_obs_tile(k, b0, s_x);
+  for (int e = tid; e < F * CKP; e += NT) {
+    const int f = e / CKP, r = e - f * CKP;
+    s_cw[e] = (r < C * K) ? k.conv_w[f * C * K + r] : ((r == CKP - 1) ? k.conv_b[f] : 0.f);
+  }
+  for (int e = tid; e < 2 * L * Hc; e += NT) s_hw[e] = (e < L * Hc) ? k.zloc_w[e] : k.zls_w[e - L * Hc];
   __syncthreads();
-  // conv: one thread per (tb, p); the K-window of every channel in registers, filter taps as SGPR operands
-  const cptr cw = (cptr)k.conv_w, cb = (cptr)k.conv_b;
+  STAMP(1);
+  // conv: one thread per (tb, p); the K-window of every channel in registers, filter taps broadcast from LDS (b128 reads)
   for (int e = tid; e < TBE * n_conv; e += NT) {
     const int tb = e / n_conv, p = e - tb * n_conv;
     float xw[C][K];
@@ -68,15 +87,23 @@ __global__ void __launch_bounds__(ENC_NT) enc_fwd_kernel(const EncK k) {
 #pragma unroll
       for (int kk = 0; kk < K; ++kk) xw[c][kk] = s_x[(tb * C + c) * T + p + kk];
     for (int f = 0; f < F; ++f) {
-      float acc = cb[f];
+      const float4* w4 = reinterpret_cast<const float4*>(s_cw + f * CKP);
+      float wr[CKP];
+#pragma unroll
+      for (int q = 0; q < CKP / 4; ++q) {
+        const float4 v = w4[q];
+        wr[4 * q] = v.x; wr[4 * q + 1] = v.y; wr[4 * q + 2] = v.z; wr[4 * q + 3] = v.w;
+      }
+      float acc = wr[CKP - 1];  // bias
 #pragma unroll
       for (int c = 0; c < C; ++c)
 #pragma unroll
-        for (int kk = 0; kk < K; ++kk) acc = fmaf(cw[(f * C + c) * K + kk], xw[c][kk], acc);
+        for (int kk = 0; kk < K; ++kk) acc = fmaf(wr[c * K + kk], xw[c][kk], acc);
       s_conv[(tb * F + f) * n_conv + p] = acc;
     }
   }
   __syncthreads();
+  STAMP(2);
   // average pool, stride 1 (sum / P as ATen's avg_pool does), filter-major flatten
   const float fP = (float)k.P;
   for (int e = tid; e < TBE * FQ; e += NT) {
@@ -89,6 +116,7 @@ __global__ void __launch_bounds__(ENC_NT) enc_fwd_kernel(const EncK k) {
     if (k.pooled && b0 + tb < k.B) k.pooled[(long long)(b0 + tb) * FQ + i] = v;
   }
   __syncthreads();
+  STAMP(3);
   // lin + tanh: each wave streams RB rows of lin.weight (coalesced) against the TBE pooled vectors in LDS
   {
     const int wave = tid >> 6, lane = tid & 63, nw = NT >> 6;
@@ -100,6 +128,7 @@ __global__ void __launch_bounds__(ENC_NT) enc_fwd_kernel(const EncK k) {
       for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int tb = 0; tb < TBE; ++tb) acc[r][tb] = 0.f;
+#pragma unroll 4
       for (int i = lane; i < FQ; i += 64) {
         float pv[TBE];
 #pragma unroll
@@ -126,18 +155,21 @@ __global__ void __launch_bounds__(ENC_NT) enc_fwd_kernel(const EncK k) {
     }
   }
   __syncthreads();
+  STAMP(4);
   // heads: z_loc, z_scale = exp(.)
   for (int e = tid; e < TBE * L * 2; e += NT) {
     const int which = e / (TBE * L), r = e - which * (TBE * L);
     const int tb = r / L, l = r - tb * L;
-    const float* W = which ? k.zls_w : k.zloc_w;
+    const float* W = s_hw + which * L * Hc;
     float acc = which ? k.zls_b[l] : k.zloc_b[l];
+#pragma unroll 10
     for (int mm = 0; mm < Hc; ++mm) acc = fmaf(W[l * Hc + mm], s_hid[tb * 64 + mm], acc);
     if (b0 + tb < k.B) {
       if (which) k.scale[(long long)(b0 + tb) * L + l] = expf(acc);
       else k.loc[(long long)(b0 + tb) * L + l] = acc;
     }
   }
+  STAMP(5);
 }
 
 // ---- backward, part 1: heads, tanh, lin^T, pool^T, conv weight gradient -----------------------------------
@@ -154,12 +186,15 @@ __global__ void __launch_bounds__(ENC_NT) enc_bwd_kernel(const EncK k) {
   float* s_hid = s_gpre + 64 * TBE;             // [TBE][64]
   float* s_gl = s_hid + TBE * 64;               // [TBE][L]  g_loc
   float* s_gs = s_gl + TBE * L;                 // [TBE][L]  g_scale * scale
+  float* s_hw = s_gs + TBE * L;                 // [2][L][Hc] z_loc / z_scale head weights
   const int b0 = blockIdx.x * TBE;
   float* slab = k.slabs + (long long)blockIdx.x * k.small_stride;
   const int o_convw = 0, o_convb = F * C * K, o_linb = o_convb + F, o_zlw = o_linb + Hc, o_zlb = o_zlw + L * Hc,
             o_zsw = o_zlb + L, o_zsb = o_zsw + L * Hc;
 
+  STAMP(8);
   load_obs_tile(k, b0, s_x);
+  for (int e = tid; e < 2 * L * Hc; e += NT) s_hw[e] = (e < L * Hc) ? k.zloc_w[e] : k.zls_w[e - L * Hc];
   for (int e = tid; e < TBE * L; e += NT) {
     const int tb = e / L, l = e - tb * L, b = b0 + tb;
     const bool ok = b < k.B;
@@ -171,14 +206,16 @@ __global__ void __launch_bounds__(ENC_NT) enc_bwd_kernel(const EncK k) {
     s_hid[e] = (b < k.B && mm < Hc) ? k.hid_in[(long long)b * Hc + mm] : 0.f;
   }
   __syncthreads();
+  STAMP(9);
   // through the heads and tanh
   for (int e = tid; e < TBE * 64; e += NT) {
     const int tb = e >> 6, mm = e & 63;
     float g = 0.f;
     if (mm < Hc) {
+#pragma unroll 4
       for (int l = 0; l < L; ++l) {
-        g = fmaf(k.zloc_w[l * Hc + mm], s_gl[tb * L + l], g);
-        g = fmaf(k.zls_w[l * Hc + mm], s_gs[tb * L + l], g);
+        g = fmaf(s_hw[l * Hc + mm], s_gl[tb * L + l], g);
+        g = fmaf(s_hw[(L + l) * Hc + mm], s_gs[tb * L + l], g);
       }
       const float hv = s_hid[tb * 64 + mm];
       g *= (1.f - hv * hv);
@@ -206,6 +243,7 @@ __global__ void __launch_bounds__(ENC_NT) enc_bwd_kernel(const EncK k) {
     slab[o_zsb + l] = a2;
   }
   __syncthreads();
+  STAMP(10);
   for (int mm = tid; mm < Hc; mm += NT) {
     float a = 0.f;
 #pragma unroll
@@ -217,6 +255,7 @@ __global__ void __launch_bounds__(ENC_NT) enc_bwd_kernel(const EncK k) {
     float acc[TBE];
 #pragma unroll
     for (int tb = 0; tb < TBE; ++tb) acc[tb] = 0.f;
+#pragma unroll 10
     for (int mm = 0; mm < Hc; ++mm) {
       const float w = k.lin_w[(long long)mm * FQ + i];
       const float4 g = *reinterpret_cast<const float4*>(s_gpre + mm * TBE);
@@ -227,6 +266,7 @@ __global__ void __launch_bounds__(ENC_NT) enc_bwd_kernel(const EncK k) {
     for (int tb = 0; tb < TBE; ++tb) s_gpool[tb * FQ + i] = acc[tb];
   }
   __syncthreads();
+  STAMP(11);
   // pool^T: g_conv[p] = (1/P) * sum_{q in [p-P+1, p] ∩ [0, n_pool)} g_pooled[q]
   const float fP = (float)k.P;
   for (int e = tid; e < TBE * F * n_conv; e += NT) {
@@ -240,6 +280,7 @@ __global__ void __launch_bounds__(ENC_NT) enc_bwd_kernel(const EncK k) {
     s_gconv[e] = sum / fP;
   }
   __syncthreads();
+  STAMP(12);
   // conv weight gradient: lane f = tid % 16, slot = tid / 16 walks (tb, block of 8 output positions)
   {
     constexpr int PB = 8;
@@ -284,6 +325,7 @@ __global__ void __launch_bounds__(ENC_NT) enc_bwd_kernel(const EncK k) {
     accb += __shfl_xor(accb, 16, 64);
     accb += __shfl_xor(accb, 32, 64);
     __syncthreads();  // s_gpool is free now
+    STAMP(13);
     float* s_red = s_gpool;  // [nw][16][C*K+1]
     const int wave = tid >> 6, lane = tid & 63, nw = NT >> 6;
     if (lane < 16) {
@@ -302,6 +344,7 @@ __global__ void __launch_bounds__(ENC_NT) enc_bwd_kernel(const EncK k) {
       else slab[o_convb + ff] = v;
     }
   }
+  STAMP(14);
 }
 
 // ---- backward, part 2: lin.weight gradient on the f32 matrix cores -----------------------------------------
@@ -320,14 +363,21 @@ __global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restric
   const int col = lane & 31, kh = lane >> 5;
   const bool col_ok = i0 + col < FQ;
   f32x16 acc0 = {0}, acc1 = {0};
-  for (int bb = bbeg; bb < bend; bb += 2) {
-    const int b = bb + kh;
-    const bool ok = b < bend;
-    const float a0 = ok ? g_pre[(long long)b * 64 + col] : 0.f;
-    const float a1 = ok ? g_pre[(long long)b * 64 + 32 + col] : 0.f;
-    const float bv = (ok && col_ok) ? pooled[(long long)b * FQ + i0 + col] : 0.f;
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc1, 0, 0, 0);
+  for (int bb = bbeg; bb < bend; bb += 8) {
+    float a0[4], a1[4], bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int b = bb + 2 * q + kh;
+      const bool ok = b < bend;
+      a0[q] = ok ? g_pre[(long long)b * 64 + col] : 0.f;
+      a1[q] = ok ? g_pre[(long long)b * 64 + 32 + col] : 0.f;
+      bv[q] = (ok && col_ok) ? pooled[(long long)b * FQ + i0 + col] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], bv[q], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], bv[q], acc1, 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -357,14 +407,16 @@ EncK make_enck(const slode_shape& s, const slode_layout& lay, const float* p) {
 }
 
 size_t enc_fwd_lds(const EncK& k) {
-  return sizeof(float) * ((size_t)TBE * k.C * k.T + (size_t)TBE * k.F * k.n_conv + (size_t)TBE * k.FQ + TBE * 64);
+  const int ckp = ((k.C * k.K + 1) + 3) & ~3;
+  return sizeof(float) * ((size_t)TBE * k.C * k.T + (size_t)TBE * k.F * k.n_conv + (size_t)TBE * k.FQ + TBE * 64 +
+                          (size_t)k.F * ckp + 2 * (size_t)k.L * k.Hc);
 }
 size_t enc_bwd_lds(const EncK& k) {
   size_t gpool = (size_t)TBE * k.FQ;
   const size_t red = (size_t)(ENC_NT / 64) * 16 * (k.C * k.K + 1);
   if (red > gpool) gpool = red;
   return sizeof(float) * ((size_t)TBE * k.C * k.T + gpool + (size_t)TBE * k.F * k.n_conv + 64 * TBE + TBE * 64 +
-                          2 * (size_t)TBE * k.L);
+                          2 * (size_t)TBE * k.L + 2 * (size_t)k.L * k.Hc);
 }
 
 }  // namespace

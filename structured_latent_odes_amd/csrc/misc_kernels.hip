@@ -40,6 +40,30 @@ __device__ __forceinline__ float strided_sum(const float* p, int stride, int n) 
   return (a0 + a1) + (a2 + a3);
 }
 
+// Stage 1 of the slab reduction: [n][stride] -> [G][stride] partial sums.  Block = 64 elements x 4 sub-groups; every
+// thread keeps 4 independent loads in flight; summation order is fixed (slab index) => bitwise reproducible.
+__global__ void __launch_bounds__(256) slab_stage1_kernel(const float* __restrict__ slabs, int stride, int n, int count, int per,
+                                                          float* __restrict__ out) {
+  __shared__ float s_p[4][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6, g = blockIdx.y;
+  const int w0 = g * per, w1 = min(n, w0 + per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (e < count) {
+    const float* p = slabs + e;
+    int w = w0 + q;
+    for (; w + 12 < w1; w += 16) {
+      a0 += p[(long long)w * stride];
+      a1 += p[(long long)(w + 4) * stride];
+      a2 += p[(long long)(w + 8) * stride];
+      a3 += p[(long long)(w + 12) * stride];
+    }
+    for (; w < w1; w += 4) a0 += p[(long long)w * stride];
+  }
+  s_p[q][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (q == 0 && e < count) out[(long long)g * stride + e] = (s_p[0][threadIdx.x] + s_p[1][threadIdx.x]) + (s_p[2][threadIdx.x] + s_p[3][threadIdx.x]);
+}
+
 // One thread per flat-gradient element; fixed summation order over slabs => bitwise reproducible.
 __global__ void reduce_kernel(const ReduceK k) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,10 +141,22 @@ hipError_t slode_launch_stage_times(const slode_shape& s, const float* times, fl
   return hipGetLastError();
 }
 
-hipError_t slode_launch_reduce(const ReduceLaunch& a, hipStream_t stream) {
+hipError_t slode_launch_reduce(const ReduceLaunch& a_in, hipStream_t stream) {
+  ReduceLaunch a = a_in;
   ReduceK k{};
   const slode_shape& s = a.s;
   const int n_conv = s.T - s.K + 1, FQ = s.F * (n_conv - s.P + 1);
+  // two-stage: n slabs -> SLODE_REDUCE_GROUPS partial slabs -> final (keeps every thread's serial loop short)
+  auto stage1 = [&](const float*& slabs, int stride, int& n, int count, float* part) {
+    if (!slabs || !part || n <= 2 * SLODE_REDUCE_GROUPS) return;
+    const int per = (n + SLODE_REDUCE_GROUPS - 1) / SLODE_REDUCE_GROUPS;
+    hipLaunchKernelGGL(slab_stage1_kernel, dim3((count + 63) / 64, SLODE_REDUCE_GROUPS), dim3(256), 0, stream, slabs, stride, n,
+                       count, per, part);
+    slabs = part;
+    n = (n + per - 1) / per;
+  };
+  stage1(a.ode_slabs, a.ode_stride, a.ode_n, (a.lay.ode_end - a.lay.ode_begin) + 1, a.ode_part);
+  stage1(a.small_slabs, a.small_stride, a.small_n, slode_enc_small_count(s), a.small_part);
   k.ode_slabs = a.ode_slabs; k.ode_stride = a.ode_stride; k.ode_n = a.ode_n;
   k.nseg = a.lay.ode_end - a.lay.ode_begin; k.ode_begin = a.lay.ode_begin;
   k.small_slabs = a.small_slabs; k.small_stride = a.small_stride; k.small_n = a.small_n;

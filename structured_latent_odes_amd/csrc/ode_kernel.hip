@@ -23,7 +23,18 @@
 
 typedef const __attribute__((address_space(4))) float* cptr;  // uniform loads => s_load + SGPR operands
 
+#ifdef SLODE_STAMPS  // diagnostic build only: phase boundaries of workgroup 0 in 10 ns ticks (s_memrealtime)
+__device__ unsigned long long g_stamps_ode[32];
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps_ode[i] = wall_clock64(); } while (0)
+extern "C" int slode_debug_stamps_ode(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_ode), sizeof(unsigned long long) * 32);
+}
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 namespace {
+
 
 struct OdeK {
   int B, T, C, L, nu, ng, method, R, nt, Q, gauss;
@@ -36,6 +47,8 @@ struct OdeK {
   int o_ploc_w[SLODE_MAX_GROUPS], o_ploc_b[SLODE_MAX_GROUPS], o_pls_w[SLODE_MAX_GROUPS], o_pls_b[SLODE_MAX_GROUPS];
   int o_w1, o_b1, o_w2, o_b2, o_wh, o_bh, o_wg, o_bg, o_wd, o_bd, o_head[SLODE_MAX_HEADS], o_cstd;
   int nseg;
+  int npar;            // floats of the segment staged in LDS: [ode_begin, cstd) = priors | init net | dynamics | heads
+  const float* pseg;   // params + ode_begin
   const float *times, *stage_t, *obs, *u, *eps, *loc, *scale, *z_in, *gx_in;
   long long sb, sc, st;
   float *x_out, *z_out, *g_loc, *g_scale, *slabs;
@@ -43,12 +56,12 @@ struct OdeK {
 };
 
 struct LdsMap {  // offsets in floats
-  int ts, dt, sig, A, x, lam, st, acc, z, gzl, gpl, gls, u, wt, pre0, hid0, x0, go, gp0, gu, gup, red, total;
+  int ts, dt, sig, A, x, lam, st, acc, par, uu, z, gzl, gpl, gls, u, wt, pre0, hid0, x0, go, gp0, gu, gup, red, total;
 };
 
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
 
-__host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int Q, int nt, int nseg, int nthreads) {
+__host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int Q, int nt, int nseg, int npar, int nthreads) {
   LdsMap m;
   int o = 0;
   m.ts = o; o += pad4(nt);
@@ -57,15 +70,18 @@ __host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int
   m.A = o; o += pad4(T * S);
   m.x = o; o += pad4(T * S);
   m.lam = o; o += pad4(T * S);
-  int stn = 2 * S * T; if (Q * C * T > stn) stn = Q * C * T;
-  const int eps_n = (nthreads / 32) * (2 * S + 1) * 32;  // epilogue chunk-reduction scratch
-  if (eps_n > stn) stn = eps_n;
+  int stn = ((2 * S + 3) & ~3) * T; if (Q * C * T > stn) stn = Q * C * T;
+  // the epilogue's chunk-reduction scratch ((nthreads/32) x (2S+1) x 32 floats) aliases the A | x | lam | st block
+  const int eps_n = (nthreads / 32) * (2 * S + 1) * 32, have = 3 * pad4(T * S) + pad4(stn);
+  if (eps_n > have) stn += eps_n - have;
   m.st = o; o += pad4(stn);
-  m.acc = o; o += pad4(nseg + 1);
+  m.acc = o; o += pad4(npar + 1);  // [loss | priors | init net | dynamics | heads]; constant_std goes straight to the slab
+  m.par = o; o += pad4(npar);
+  m.uu = o; o += SLODE_MAX_NU;
   m.z = o; o += pad4(L);
   m.gzl = o; o += pad4(L);
-  m.gpl = o; o += pad4(L);
-  m.gls = o; o += pad4(L);
+  m.gpl = o; o += pad4(2 * L);  // [d(-log p)/d prior loc | eps]
+  m.gls = o; o += pad4(2 * L);  // [d(-log p)/d prior log-scale | guide scale]
   m.u = o; o += 32;
   m.wt = o; o += 32;
   m.pre0 = o; o += 32;
@@ -174,12 +190,66 @@ __device__ __forceinline__ void step_bwd(int method, float h, const float a[4], 
   }
 }
 
+// Affine recurrence y_{k+1} = A[i(k)] * y_k + v[j(k)], k = 0..T-2, results stored back over v, executed by ONE wave.
+//   forward (REV=false): i = k,       j = k+1, y_0 = v[0]      (x_{n+1} = A_n x_n + b_n, b_n pre-stored in v[n+1])
+//   reverse (REV=true):  i = T-2-k,   j = i,   y_0 = v[T-1]    (lambda_i = A_i lambda_{i+1} + g_i)
+// Affine maps compose, so the T-1 long dependency chain is cut into NC = 64/S chunks handled by lanes (chunk, s):
+// compose the chunk's maps (registers), chain the NC chunk start states with shuffles, replay the chunk.
+template <int S, bool REV>
+__device__ __forceinline__ void wave_affine_scan(const float* __restrict__ s_A, float* __restrict__ s_v, int T, int lane) {
+  constexpr int NC = 64 / S;
+  constexpr int CLMAX = 12;  // steps per lane per pass (2 x CLMAX registers); longer grids take several passes
+  const int nsteps = T - 1;
+  const int c = lane / S, s = lane - c * S;
+  const bool lane_on = c < NC;
+  float carry = lane_on ? s_v[(REV ? (T - 1) : 0) * S + s] : 0.f;
+  for (int base = 0; base < nsteps; base += NC * CLMAX) {
+    const int left = nsteps - base;
+    int CL = (left + NC - 1) / NC;
+    if (CL > CLMAX) CL = CLMAX;
+    const int k0 = base + c * CL;
+    float Ar[CLMAX], vr[CLMAX];
+#pragma unroll
+    for (int q = 0; q < CLMAX; ++q) {
+      const int kk = k0 + q;
+      const bool on = lane_on && q < CL && kk < nsteps;
+      const int i = REV ? (T - 2 - kk) : kk;
+      Ar[q] = on ? s_A[i * S + s] : 1.f;
+      vr[q] = on ? s_v[(REV ? i : i + 1) * S + s] : 0.f;
+    }
+    float Ac = 1.f, bc = 0.f;
+#pragma unroll
+    for (int q = 0; q < CLMAX; ++q) {
+      bc = fmaf(Ar[q], bc, vr[q]);
+      Ac *= Ar[q];
+    }
+    float ys = carry;
+    for (int cc = 1; cc < NC; ++cc) {
+      const float ye = fmaf(Ac, ys, bc);
+      const float prev = __shfl_up(ye, S, 64);
+      if (c == cc) ys = prev;
+    }
+    float y = ys;
+#pragma unroll
+    for (int q = 0; q < CLMAX; ++q) {
+      const int kk = k0 + q;
+      const bool on = lane_on && q < CL && kk < nsteps;
+      y = fmaf(Ar[q], y, vr[q]);  // masked entries are the identity map
+      if (on) {
+        const int i = REV ? (T - 2 - kk) : kk;
+        s_v[(REV ? i : i + 1) * S + s] = y;
+      }
+    }
+    carry = __shfl(y, (NC - 1) * S + s, 64);
+  }
+}
+
 template <int S, int H, bool BWD>
 __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, NT = blockDim.x;
   const int T = k.T, C = k.C, L = k.L, R = k.R, Q = k.Q;
-  const LdsMap m = lds_map(T, S, H, C, L, Q, k.nt, k.nseg, NT);
+  const LdsMap m = lds_map(T, S, H, C, L, Q, k.nt, k.nseg, k.npar, NT);
   float* s_ts = smem + m.ts;
   float* s_dt = smem + m.dt;
   float* s_sig = smem + m.sig;
@@ -188,6 +258,8 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
   float* s_lam = smem + m.lam;
   float* s_st = smem + m.st;
   float* s_acc = smem + m.acc;
+  float* s_par = smem + m.par;  // small weights, staged once per workgroup (cold phases read LDS, not HBM/L2)
+  float* s_uu = smem + m.uu;  // this trajectory's label row u[b, :]
   float* s_z = smem + m.z;
   float* s_gzl = smem + m.gzl;
   float* s_gpl = smem + m.gpl;
@@ -204,14 +276,41 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
   float* s_red = smem + m.red;
 
   const cptr wg = (cptr)k.wg, bg = (cptr)k.bg, wd = (cptr)k.wd, bd = (cptr)k.bd;
+  STAMP(0);
+  // Prefetch of a trajectory's per-thread inputs: issued before the setup (first trajectory) and before the tail of the
+  // previous trajectory, so their HBM latency is off the critical path of P0.
+  float pf_loc = 0.f, pf_sc = 1.f, pf_eps = 0.f, pf_u = 0.f, pf_ob[SLODE_MAX_C];
+  auto prefetch = [&](int b) {
+    if (b >= k.B) return;
+    if (tid < L) {
+      if (k.loc != nullptr) {
+        pf_loc = k.loc[(long long)b * L + tid];
+        pf_sc = k.scale[(long long)b * L + tid];
+        pf_eps = k.eps[(long long)b * L + tid];
+      } else {
+        pf_loc = k.z_in[(long long)b * L + tid];
+      }
+    }
+    if (k.u != nullptr && tid < k.nu) pf_u = k.u[(long long)b * k.nu + tid];
+    if (k.with_ll && tid < T) {
+#pragma unroll
+      for (int c = 0; c < SLODE_MAX_C; ++c)
+        pf_ob[c] = (c < C) ? k.obs[(long long)b * k.sb + (long long)c * k.sc + (long long)tid * k.st] : 0.f;
+    }
+  };
+#pragma unroll
+  for (int c = 0; c < SLODE_MAX_C; ++c) pf_ob[c] = 0.f;
+  prefetch(blockIdx.x);
 
   // ---- per-workgroup setup (shared by all trajectories this workgroup integrates) ----------------------
   for (int i = tid; i < k.nt; i += NT) s_ts[i] = k.stage_t[i];
   for (int i = tid; i < T - 1; i += NT) s_dt[i] = k.times[i + 1] - k.times[i];
   if (k.with_ll)
     for (int i = tid; i < C * T; i += NT) s_sig[i] = softplusf(k.cstd[i]);
-  for (int i = tid; i < k.nseg + 1; i += NT) s_acc[i] = 0.f;
-  if (tid < 32) s_wt[tid] = (tid < H) ? k.wh[tid * (1 + L)] : 0.f;  // time column of dynamics_hidden (col 0)
+  for (int i = tid; i < k.npar + 1; i += NT) s_acc[i] = 0.f;
+  for (int i = tid; i < k.npar; i += NT) s_par[i] = k.pseg[i];
+  __syncthreads();
+  if (tid < 32) s_wt[tid] = (tid < H) ? s_par[k.o_wh + tid * (1 + L)] : 0.f;  // time column of dynamics_hidden (col 0)
 
   // persistent per-thread accumulators (summed over this workgroup's trajectories)
   float loss_acc = 0.f;
@@ -221,41 +320,48 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
   static_assert(H < 32, "lane H of each half-wave carries the head-bias gradients");
   float acc_head = 0.f;  // one (q,c,s) head-weight entry (head-grad role)
   // hidden-unit-major role: lane jj = hidden unit, chunk = half-wave index
-  const int jj = tid & 31, chunk = tid >> 5, nchunk = NT >> 5;
+  constexpr int SP = (2 * S + 3) & ~3;  // stage-row stride: [a/ga (S) | d/gd (S) | pad], 16-B aligned rows
+  const int jj_e = tid & 31, chunk_e = tid >> 5, nchunk = NT >> 5;
   float acc_wg[S], acc_wd[S], acc_wt = 0.f;
 #pragma unroll
   for (int s = 0; s < S; ++s) { acc_wg[s] = 0.f; acc_wd[s] = 0.f; }
-  const float wtj = (jj < H) ? k.wh[jj * (1 + L)] : 0.f;
-  const int hg_base = (NT >= 128) ? 64 : 0;  // head-grad role lives on waves >= 1 when they exist
+  const int hg_base = 64;  // head-grad role lives on waves >= 1 (the launcher guarantees NT >= 64 + roundup64(Q*C*S))
   const int n_headw = Q * C * S;
+  int hsplit = (NT - hg_base) / n_headw;  // time range split over hsplit threads per head-weight entry
+  hsplit = hsplit > 4 ? 4 : hsplit;
   __syncthreads();
+  STAMP(1);
 
+  const int tid_outer = tid;
   for (int b = blockIdx.x; b < k.B; b += gridDim.x) {
-    // prefetch this thread's observation column (thread t <-> time point t)
-    float ob[SLODE_MAX_C];
-    if (k.with_ll && tid < T) {
-#pragma unroll
-      for (int c = 0; c < SLODE_MAX_C; ++c)
-        ob[c] = (c < C) ? k.obs[(long long)b * k.sb + (long long)c * k.sc + (long long)tid * k.st] : 0.f;
-    }
+    // Launder the thread id once per trajectory: with it opaque, the compiler cannot hoist the dozens of per-thread
+    // address computations of the phases below out of this loop (which only lengthens live ranges and spills).
+    int tid = tid_outer;
+    asm volatile("" : "+v"(tid));
+    const int jj = tid & 31, chunk = tid >> 5;
+    // this trajectory's prefetched inputs (thread t <-> time point t for the observation column)
+    if (tid < k.nu) s_uu[tid] = pf_u;
+    __syncthreads();
 
     // ---- P0a: latent sample, log q, log p (mechanistic_cvs.py:125-135, 225-237) -------------------------
     if (tid < L) {
       const int l = tid;
       if (k.loc != nullptr) {
-        const float loc = k.loc[(long long)b * L + l], sc = k.scale[(long long)b * L + l], e = k.eps[(long long)b * L + l];
+        const float loc = pf_loc, sc = pf_sc, e = pf_eps;
+        s_gpl[L + l] = e;   // kept for the latent gradient in P7 (the registers are reused by the next prefetch)
+        s_gls[L + l] = sc;
         const float z = fmaf(sc, e, loc);
         float pl = 0.f, pls = 0.f;
         for (int g = 0; g < k.ng; ++g) {
           const slode_group gr = k.grp[g];
           if (l >= gr.z_off && l < gr.z_off + gr.z_dim) {
             const int ll = l - gr.z_off;
-            pl = k.ploc_b[g][ll];
-            pls = k.pls_b[g][ll];
+            pl = s_par[k.o_ploc_b[g] + ll];
+            pls = s_par[k.o_pls_b[g] + ll];
             for (int q = 0; q < gr.u_dim; ++q) {
-              const float uv = k.u[(long long)b * k.nu + gr.u_off + q];
-              pl = fmaf(k.ploc_w[g][ll * gr.u_dim + q], uv, pl);
-              pls = fmaf(k.pls_w[g][ll * gr.u_dim + q], uv, pls);
+              const float uv = s_uu[gr.u_off + q];
+              pl = fmaf(s_par[k.o_ploc_w[g] + ll * gr.u_dim + q], uv, pl);
+              pls = fmaf(s_par[k.o_pls_w[g] + ll * gr.u_dim + q], uv, pls);
             }
           }
         }
@@ -272,7 +378,7 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
         s_gls[l] = 1.f - dz * dz;   // d(-log p)/d prior log-scale
         if (k.z_out) k.z_out[(long long)b * L + l] = z;
       } else {
-        s_z[l] = k.z_in[(long long)b * L + l];
+        s_z[l] = pf_loc;
         s_gzl[l] = 0.f;
       }
     }
@@ -280,11 +386,14 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
     // ---- P0b: u = W_z z + b_h (time-invariant part of the hidden layer), init-net hidden -----------------
     if (tid < H) {
       const int j = tid;
-      float uj = k.bh[j], p0 = k.b1[j];
+      float uj = s_par[k.o_bh + j], p0 = s_par[k.o_b1 + j];
+      const float* whr = s_par + k.o_wh + j * (1 + L) + 1;
+      const float* w1r = s_par + k.o_w1 + j * L;
+#pragma unroll 4
       for (int l = 0; l < L; ++l) {
         const float zl = s_z[l];
-        uj = fmaf(k.wh[j * (1 + L) + 1 + l], zl, uj);
-        p0 = fmaf(k.w1[j * L + l], zl, p0);
+        uj = fmaf(whr[l], zl, uj);
+        p0 = fmaf(w1r[l], zl, p0);
       }
       s_u[j] = uj;
       s_pre0[j] = p0;
@@ -295,14 +404,16 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
     __syncthreads();
     // ---- P0c: x0 = sigmoid(W2 relu(.) + b2)  (blackbox_ode.py:19-22) ------------------------------------
     if (tid < S) {
-      float o = k.b2[tid];
-#pragma unroll 1
-      for (int j = 0; j < H; ++j) o = fmaf(k.w2[tid * H + j], s_hid0[j], o);
+      float o = s_par[k.o_b2 + tid];
+      const float* w2r = s_par + k.o_w2 + tid * H;
+#pragma unroll
+      for (int j = 0; j < H; ++j) o = fmaf(w2r[j], s_hid0[j], o);
       const float x0 = sigmoidf_fast(o);
       s_x0[tid] = x0;
       s_x[tid] = x0;
     }
 
+    STAMP(2);
     // ---- P1: stage evaluations + step coefficients (thread n <-> grid step n) ---------------------------
     float av[3][S], dv[3][S];
 #pragma unroll
@@ -324,20 +435,21 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
       if (k.uses_next) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          s_st[n * 2 * S + s] = av[0][s];
-          s_st[n * 2 * S + S + s] = dv[0][s];
+          s_st[n * SP + s] = av[0][s];
+          s_st[n * SP + S + s] = dv[0][s];
         }
       }
     }
     __syncthreads();
+    STAMP(3);
     if (own_step) {
       const float h = s_dt[n];
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         float a3 = 0.f, d3 = 0.f;
         if (k.uses_next) {
-          a3 = s_st[(n + 1) * 2 * S + s];
-          d3 = s_st[(n + 1) * 2 * S + S + s];
+          a3 = s_st[(n + 1) * SP + s];
+          d3 = s_st[(n + 1) * SP + S + s];
         }
         const float a4[4] = {av[0][s], av[1][s], av[2][s], a3};
         const float d4[4] = {dv[0][s], dv[1][s], dv[2][s], d3};
@@ -348,16 +460,11 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
       }
     }
     __syncthreads();
+    STAMP(4);
     // ---- P2: forward scan x_{n+1} = A_n x_n + b_n (the only serial part of the solve) -------------------
-    if (tid < S) {
-      float x = s_x[tid];
-#pragma unroll 8
-      for (int i = 0; i < T - 1; ++i) {
-        x = fmaf(s_A[i * S + tid], x, s_x[(i + 1) * S + tid]);
-        s_x[(i + 1) * S + tid] = x;
-      }
-    }
+    if (tid < 64) wave_affine_scan<S, false>(s_A, s_x, T, tid);
     __syncthreads();
+    STAMP(5);
     if (k.x_out) {
       float* xo = k.x_out + (long long)b * T * S;
       for (int i = tid; i < T * S; i += NT) xo[i] = s_x[i];
@@ -376,7 +483,7 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
           if (c >= C) continue;
           const float sig = s_sig[c * T + t];
           const float inv = 1.0f / sig;
-          const float obv = ob[c];
+          const float obv = pf_ob[c];
           float gsig = 0.f;
           for (int q = 0; q < Q; ++q) {
             const cptr W = (cptr)k.head[q] + c * S;
@@ -416,34 +523,40 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
       for (int i = tid; i < T * S; i += NT) s_lam[i] = gi[i];
     }
 
+    prefetch(b + gridDim.x);
     if (BWD) {
       __syncthreads();
+      STAMP(6);
       // ---- P4: adjoint scan (wave 0) || head-weight gradients (waves >= 1) ------------------------------
-      if (tid < S) {
-        float lam = s_lam[(T - 1) * S + tid];
-#pragma unroll 8
-        for (int i = T - 2; i >= 0; --i) {
-          lam = fmaf(s_A[i * S + tid], lam, s_lam[i * S + tid]);
-          s_lam[i * S + tid] = lam;
-        }
-      }
+      if (tid < 64) wave_affine_scan<S, true>(s_A, s_lam, T, tid);
       if (k.with_ll) {
         const int e = tid - hg_base;
-        if (e >= 0 && e < n_headw) {
-          const int qc = e / S, s = e - qc * S;
-          float acc = 0.f;
-          for (int t = 0; t < T; ++t) acc = fmaf(s_st[qc * T + t], s_x[t * S + s], acc);
-          acc_head += acc;
+        if (e >= 0 && e < n_headw * hsplit) {
+          const int part = e / n_headw, ew = e - part * n_headw;
+          const int qc = ew / S, s = ew - qc * S;
+          const int tper = (T + hsplit - 1) / hsplit, t0 = part * tper, t1 = min(T, t0 + tper);
+          float a0 = 0.f, a1 = 0.f;
+          int t = t0;
+          for (; t + 7 < t1; t += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+              a0 = fmaf(s_st[qc * T + t + q], s_x[(t + q) * S + s], a0);
+              a1 = fmaf(s_st[qc * T + t + q + 1], s_x[(t + q + 1) * S + s], a1);
+            }
+          }
+          for (; t < t1; ++t) a0 = fmaf(s_st[qc * T + t], s_x[t * S + s], a0);
+          acc_head += a0 + a1;
         }
       }
       __syncthreads();
+      STAMP(7);
       // ---- P5: reverse mode of the step coefficients (thread n <-> step n) ------------------------------
       // (the stage buffer is free again: re-exchange the first-stage values instead of carrying a3/d3 in registers)
       if (k.uses_next && (own_step || own_last)) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          s_st[n * 2 * S + s] = av[0][s];
-          s_st[n * 2 * S + S + s] = dv[0][s];
+          s_st[n * SP + s] = av[0][s];
+          s_st[n * SP + S + s] = dv[0][s];
         }
       }
       __syncthreads();
@@ -455,8 +568,8 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
           const float gA = gb * s_x[n * S + s];
           float a3 = 0.f, d3 = 0.f;
           if (k.uses_next) {  // slot n+1 is read here and rewritten below by this thread only
-            a3 = s_st[(n + 1) * 2 * S + s];
-            d3 = s_st[(n + 1) * 2 * S + S + s];
+            a3 = s_st[(n + 1) * SP + s];
+            d3 = s_st[(n + 1) * SP + S + s];
           }
           const float a4[4] = {av[0][s], av[1][s], av[2][s], a3};
           const float d4[4] = {dv[0][s], dv[1][s], dv[2][s], d3};
@@ -470,8 +583,8 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
           av[0][s] = ga[0]; av[1][s] = ga[1]; av[2][s] = ga[2];
           dv[0][s] = gd[0]; dv[1][s] = gd[1]; dv[2][s] = gd[2];
           if (k.uses_next) {  // contribution to the NEXT step's first stage (shared evaluation a(t_{n+1}))
-            s_st[(n + 1) * 2 * S + s] = ga[3];
-            s_st[(n + 1) * 2 * S + S + s] = gd[3];
+            s_st[(n + 1) * SP + s] = ga[3];
+            s_st[(n + 1) * SP + S + s] = gd[3];
           }
         }
       } else if (own_last) {
@@ -482,17 +595,19 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
       if (k.uses_next && (own_step || own_last) && n >= 1) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          av[0][s] += s_st[n * 2 * S + s];
-          dv[0][s] += s_st[n * 2 * S + S + s];
+          av[0][s] += s_st[n * SP + s];
+          dv[0][s] += s_st[n * SP + S + s];
         }
       }
+      STAMP(8);
       // ---- P6: weight-gradient contraction, hidden-unit-major; one round per stage index r ---------------
       float gu_acc = 0.f;
+      const float wtj = s_wt[jj];
       float wgj[S], wdj[S];  // this lane's column of the two dynamics heads
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        wgj[s] = (jj < H) ? k.wg[s * H + jj] : 0.f;
-        wdj[s] = (jj < H) ? k.wd[s * H + jj] : 0.f;
+        wgj[s] = (jj < H) ? s_par[k.o_wg + s * H + jj] : 0.f;
+        wdj[s] = (jj < H) ? s_par[k.o_wd + s * H + jj] : 0.f;
       }
       const int nsamp0 = k.uses_next ? T : T - 1;
       for (int r = 0; r < R; ++r) {
@@ -505,8 +620,8 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
             if (r == 0) { ga = av[0][s]; gd = dv[0][s]; }
             else if (r == 1) { ga = av[1][s]; gd = dv[1][s]; }
             else { ga = av[2][s]; gd = dv[2][s]; }
-            s_st[n * 2 * S + s] = ga;
-            s_st[n * 2 * S + S + s] = gd;
+            s_st[n * SP + s] = ga;
+            s_st[n * SP + S + s] = gd;
           }
         }
         __syncthreads();
@@ -515,14 +630,22 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
           const int i0 = chunk * per;
           const int i1 = min(ns, i0 + per);
           const float uj = s_u[jj];
+#pragma unroll 2
           for (int i = i0; i < i1; ++i) {
             const float t = s_ts[R * i + r];
             const float pre = fmaf(wtj, t, uj);
             const float hj = (jj == H) ? 1.f : fmaxf(pre, 0.f);
             float gh = 0.f;
+            float gv[SP];
+            const float4* row = reinterpret_cast<const float4*>(s_st + i * SP);
+#pragma unroll
+            for (int q4 = 0; q4 < SP / 4; ++q4) {
+              const float4 v4 = row[q4];
+              gv[4 * q4] = v4.x; gv[4 * q4 + 1] = v4.y; gv[4 * q4 + 2] = v4.z; gv[4 * q4 + 3] = v4.w;
+            }
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-              const float ga = s_st[i * 2 * S + s], gd = s_st[i * 2 * S + S + s];
+              const float ga = gv[s], gd = gv[S + s];
               gh = fmaf(wgj[s], ga, gh);
               gh = fmaf(wdj[s], gd, gh);
               acc_wg[s] = fmaf(ga, hj, acc_wg[s]);
@@ -536,6 +659,7 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
       }
       s_gup[chunk * 32 + jj] = (jj < H) ? gu_acc : 0.f;
       __syncthreads();
+      STAMP(9);
       // ---- P7: small nets (init net, z-part of the hidden layer, priors) and the latent gradient ----------
       if (tid < 32) {
         float g = 0.f;
@@ -550,8 +674,8 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
       __syncthreads();
       if (tid < H) {
         float gh0 = 0.f;
-#pragma unroll 1
-        for (int s = 0; s < S; ++s) gh0 = fmaf(k.w2[s * H + tid], s_go[s], gh0);
+#pragma unroll
+        for (int s = 0; s < S; ++s) gh0 = fmaf(s_par[k.o_w2 + s * H + tid], s_go[s], gh0);
         s_gp0[tid] = (s_pre0[tid] > 0.f) ? gh0 : 0.f;
       } else if (tid < 32) {
         s_gp0[tid] = 0.f;
@@ -560,15 +684,14 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
       if (tid < L) {
         const int l = tid;
         float gz = s_gzl[l];
-#pragma unroll 1
+#pragma unroll 5
         for (int j = 0; j < H; ++j) {
-          gz = fmaf(k.wh[j * (1 + L) + 1 + l], s_gu[j], gz);
-          gz = fmaf(k.w1[j * L + l], s_gp0[j], gz);
+          gz = fmaf(s_par[k.o_wh + j * (1 + L) + 1 + l], s_gu[j], gz);
+          gz = fmaf(s_par[k.o_w1 + j * L + l], s_gp0[j], gz);
         }
         if (k.loc != nullptr) {
-          const float e = k.eps[(long long)b * L + l], sc = k.scale[(long long)b * L + l];
           k.g_loc[(long long)b * L + l] = gz;
-          k.g_scale[(long long)b * L + l] = fmaf(gz, e, -1.0f / sc);
+          k.g_scale[(long long)b * L + l] = fmaf(gz, s_gpl[L + l], -1.0f / s_gls[L + l]);
         } else {
           k.g_loc[(long long)b * L + l] = gz;
         }
@@ -591,7 +714,7 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
           const slode_group gr = k.grp[g];
           for (int e = tid; e < gr.z_dim * gr.u_dim; e += NT) {
             const int ll = e / gr.u_dim, q = e - ll * gr.u_dim;
-            const float uv = k.u[(long long)b * k.nu + gr.u_off + q];
+            const float uv = s_uu[gr.u_off + q];
             acc[k.o_ploc_w[g] + e] += s_gpl[gr.z_off + ll] * uv;
             acc[k.o_pls_w[g] + e] += s_gls[gr.z_off + ll] * uv;
           }
@@ -603,6 +726,7 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
       }
     }
     __syncthreads();
+    STAMP(10);
   }  // trajectories
 
   // ---- workgroup epilogue: fold register accumulators into the LDS segment, write the slab ---------------
@@ -613,13 +737,13 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
     float* acc = s_acc + 1;
     // hidden-unit-major accumulators: reduce over chunks through the stage buffer
     __syncthreads();
-    float* tmp = s_st;  // [nchunk][2S+1][32]
+    float* tmp = s_A;  // [nchunk][2S+1][32], aliasing the (now dead) A | x | lam | st block
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      tmp[(chunk * (2 * S + 1) + s) * 32 + jj] = acc_wg[s];
-      tmp[(chunk * (2 * S + 1) + S + s) * 32 + jj] = acc_wd[s];
+      tmp[(chunk_e * (2 * S + 1) + s) * 32 + jj_e] = acc_wg[s];
+      tmp[(chunk_e * (2 * S + 1) + S + s) * 32 + jj_e] = acc_wd[s];
     }
-    tmp[(chunk * (2 * S + 1) + 2 * S) * 32 + jj] = acc_wt;
+    tmp[(chunk_e * (2 * S + 1) + 2 * S) * 32 + jj_e] = acc_wt;
     __syncthreads();
     for (int e = tid; e < (2 * S + 1) * 32; e += NT) {
       const int row = e >> 5, j = e & 31;
@@ -637,25 +761,33 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
       }
     }
     if (k.with_ll) {
+      __syncthreads();  // tmp (s_st) is free again
       const int e = tid - hg_base;
+      if (e >= 0 && e < n_headw * hsplit) tmp[e] = acc_head;
+      __syncthreads();
       if (e >= 0 && e < n_headw) {
         const int qc = e / S, s = e - qc * S, q = qc / C, c = qc - q * C;
-        acc[k.o_head[q] + c * S + s] = acc_head;
+        float v = 0.f;
+        for (int part = 0; part < hsplit; ++part) v += tmp[part * n_headw + e];
+        acc[k.o_head[q] + c * S + s] = v;
       }
       if (tid < T) {
 #pragma unroll
         for (int c = 0; c < SLODE_MAX_C; ++c) {
           if (c >= C) continue;
           const float sig = s_sig[c * T + tid];
-          acc[k.o_cstd + c * T + tid] = acc_cstd[c] * (1.f - expf(-sig));  // softplus'(x) = 1 - exp(-softplus(x))
+          slab[1 + k.o_cstd + c * T + tid] = acc_cstd[c] * (1.f - expf(-sig));  // softplus'(x) = 1 - exp(-softplus(x))
         }
       }
     }
+    if (!k.with_ll)  // pure solve backward: the likelihood-only entries of the segment carry no gradient
+      for (int i = tid; i < C * T; i += NT) slab[1 + k.o_cstd + i] = 0.f;
     __syncthreads();
-    for (int i = tid; i < k.nseg + 1; i += NT) slab[i] = s_acc[i];
+    for (int i = tid; i < k.npar + 1; i += NT) slab[i] = s_acc[i];
   } else {
     if (tid == 0) slab[0] = loss;
   }
+  STAMP(11);
 }
 
 template <int S, int H>
@@ -690,7 +822,7 @@ size_t slode_ode_lds_bytes(const slode_shape& s, int nthreads) {
   slode_layout lay;
   slode_layout_init(&s, &lay);
   const int Q = s.likelihood == SLODE_GAUSS ? 1 : 3;
-  const LdsMap m = lds_map(s.T, s.S, s.H, s.C, s.L, Q, n_stage(s), lay.ode_end - lay.ode_begin, nthreads);
+  const LdsMap m = lds_map(s.T, s.S, s.H, s.C, s.L, Q, n_stage(s), lay.ode_end - lay.ode_begin, lay.cstd - lay.ode_begin, nthreads);
   return (size_t)m.total * sizeof(float);
 }
 
@@ -724,6 +856,8 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   k.o_wh = lay.dyn_wh - ob; k.o_bh = lay.dyn_bh - ob; k.o_wg = lay.dyn_wg - ob; k.o_bg = lay.dyn_bg - ob;
   k.o_wd = lay.dyn_wd - ob; k.o_bd = lay.dyn_bd - ob; k.o_cstd = lay.cstd - ob;
   k.nseg = lay.ode_end - lay.ode_begin;
+  k.npar = lay.cstd - lay.ode_begin;
+  k.pseg = p + lay.ode_begin;
   k.times = a.times; k.stage_t = a.stage_t; k.obs = a.obs; k.u = a.u; k.eps = a.eps; k.loc = a.loc; k.scale = a.scale;
   k.z_in = a.z_in; k.gx_in = a.gx_in; k.sb = a.sb; k.sc = a.sc; k.st = a.st;
   k.x_out = a.x_out; k.z_out = a.z_out; k.g_loc = a.g_loc; k.g_scale = a.g_scale; k.slabs = a.slabs;

@@ -143,7 +143,7 @@ int slode_num_stage_times(const slode_shape* s) {
 
 // ---- workspace carving -------------------------------------------------------------------------------------
 struct Workspace {
-  float *loc, *scale, *pooled, *hid, *g_loc, *g_scale, *g_pre, *ode_slabs, *small_slabs, *lin_slabs;
+  float *loc, *scale, *pooled, *hid, *g_loc, *g_scale, *g_pre, *ode_slabs, *ode_part, *small_slabs, *small_part, *lin_slabs;
   int ode_grid, ode_stride, small_grid, small_stride, lin_splitk;
   size_t bytes;
 };
@@ -183,7 +183,9 @@ static Workspace carve(slode_handle h, const slode_shape& s, const slode_layout&
   w.g_scale = take((size_t)s.B * s.L);
   w.g_pre = take((size_t)s.B * 64);
   w.ode_slabs = take((size_t)w.ode_grid * w.ode_stride);
+  w.ode_part = take((size_t)SLODE_REDUCE_GROUPS * w.ode_stride);
   w.small_slabs = take((size_t)w.small_grid * w.small_stride);
+  w.small_part = take((size_t)SLODE_REDUCE_GROUPS * w.small_stride);
   w.lin_slabs = take((size_t)w.lin_splitk * s.Hc * FQ);
   w.bytes = o * sizeof(float);
   return w;
@@ -245,7 +247,7 @@ int slode_encoder_conv_bwd(slode_handle h, const slode_shape* s, const slode_lay
   hipError_t e = slode_launch_enc_bwd(a, (hipStream_t)stream);
   if (e == hipErrorInvalidValue) return fail(h, SLODE_EINVAL, "unsupported encoder shape C=%d K=%d T=%d", s->C, s->K, s->T);
   HIP_TRY(h, e);
-  ReduceLaunch r{*s, *lay, nullptr, 0, 0, w.small_slabs, w.small_stride, w.small_grid, w.lin_slabs, w.lin_splitk, grads, nullptr, 0};
+  ReduceLaunch r{*s, *lay, nullptr, 0, 0, w.small_slabs, w.small_stride, w.small_grid, w.lin_slabs, w.lin_splitk, grads, nullptr, 0, nullptr, w.small_part};
   HIP_TRY(h, slode_launch_reduce(r, (hipStream_t)stream));
   return SLODE_OK;
 }
@@ -288,7 +290,7 @@ int slode_ode_solve_bwd(slode_handle h, const slode_shape* s, const slode_layout
   hipError_t e = slode_launch_ode(a, (hipStream_t)stream, h->err, sizeof(h->err));
   if (e == hipErrorInvalidValue) return SLODE_EINVAL;
   HIP_TRY(h, e);
-  ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, nullptr, 0, 0, nullptr, 0, grads, nullptr, 0};
+  ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, nullptr, 0, 0, nullptr, 0, grads, nullptr, 0, w.ode_part, nullptr};
   HIP_TRY(h, slode_launch_reduce(r, (hipStream_t)stream));
   return SLODE_OK;
 }
@@ -342,12 +344,12 @@ int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* la
     HIP_TRY(h, slode_launch_enc_bwd(eb, st, prof ? h->ev[3] : nullptr));
     SLODE_MARK(4);
     ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, w.small_slabs, w.small_stride, w.small_grid,
-                   w.lin_slabs, w.lin_splitk, grads, loss_out, 1};
+                   w.lin_slabs, w.lin_splitk, grads, loss_out, 1, w.ode_part, w.small_part};
     HIP_TRY(h, slode_launch_reduce(r, st));
     SLODE_MARK(5);
     if (prof) h->ev_valid = 1;
   } else {
-    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, nullptr, 0, 0, nullptr, 0, nullptr, loss_out, 0};
+    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, nullptr, 0, 0, nullptr, 0, nullptr, loss_out, 0, w.ode_part, nullptr};
     HIP_TRY(h, slode_launch_reduce(r, st));
   }
   return SLODE_OK;

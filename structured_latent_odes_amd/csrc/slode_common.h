@@ -120,6 +120,7 @@ int slode_enc_small_count(const slode_shape& s);   // floats per small slab
 int slode_enc_bwd_grid(const slode_shape& s);
 int slode_enc_lin_splitk(const slode_shape& s);
 
+#define SLODE_REDUCE_GROUPS 16
 struct ReduceLaunch {
   slode_shape s;
   slode_layout lay;
@@ -129,6 +130,8 @@ struct ReduceLaunch {
   float* grads;       // flat gradient (may be null when only the loss is wanted)
   float* loss_out;    // may be null
   int zero_rest;      // also zero grads outside the written segments [0, n_params)
+  float* ode_part;    // [SLODE_REDUCE_GROUPS][ode_stride] scratch for the two-stage reduction (may be null)
+  float* small_part;  // [SLODE_REDUCE_GROUPS][small_stride] likewise
 };
 hipError_t slode_launch_reduce(const ReduceLaunch& a, hipStream_t stream);
 

@@ -1,0 +1,38 @@
+"""Diagnostic: per-phase timeline of workgroup 0 of the three big kernels (needs `make -C structured_latent_odes_amd/csrc stamps`).
+Usage (GPU box): SLODE_LIB_PATH=structured_latent_odes_amd/libslode_stamps.so python tools/stamps.py"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import slode_oracle as O
+from structured_latent_odes_amd import _lib, engine as E
+
+dev = torch.device("cuda:0")
+ospec = O.cvs_spec(3, 3, 2, solver="rk4")
+B, T = 1024, 200
+p = O.init_params(ospec, T=T)
+obs, u, eps, times = O.synthetic_batch(ospec, B, T)
+eng = E.Engine(E.cvs_spec(3, 3, 2, solver="rk4"), T, dev)
+eng.set_times(times)
+flat = eng.pack(p)
+obs_d = obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)
+loss, grads = torch.zeros(1, device=dev), torch.zeros(eng.n_params, device=dev)
+for _ in range(5):
+    eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss, grads)
+torch.cuda.synchronize()
+lib = _lib.load()
+for name, labels in (("ode", ["setup", "P0 latent/init", "P1 eval a,d", "P1 coeffs", "P2 scan", "P3 heads+LL", "P4 adj scan|head grads",
+                              "P5 step bwd", "P6 weight grads", "P7 small nets", "epilogue"]),
+                     ("enc", ["fwd: loads", "fwd: conv", "fwd: pool", "fwd: lin", "fwd: heads", None, None, None,
+                              "bwd: loads", "bwd: heads/tanh", "bwd: lin^T", "bwd: pool^T", "bwd: conv grad", "bwd: reduce+slab"])):
+    buf = (C.c_ulonglong * 32)()
+    rc = getattr(lib, "slode_debug_stamps_" + name)(buf)
+    assert rc == 0
+    v = list(buf)
+    print("== %s kernel, workgroup 0 (us)" % name)
+    for i, lab in enumerate(labels):
+        if lab is not None and v[i + 1] and v[i]:
+            print("  %-26s %8.2f" % (lab, (v[i + 1] - v[i]) / 100.0))
