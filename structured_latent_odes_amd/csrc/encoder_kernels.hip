@@ -27,8 +27,10 @@ extern "C" int slode_debug_stamps_enc(unsigned long long* out) {
 namespace {
 
 constexpr int TBE = 4;       // trajectories per workgroup
-constexpr int ENC_NT = 512;  // threads per workgroup
+constexpr int ENC_NT = 1024; // threads per workgroup (1 workgroup per CU: 16 waves keep ~100 KB of lin.weight loads in flight)
 constexpr int RB = 4;        // lin rows per wave pass
+constexpr int ENC_NT_BWD = 512;  // backward: 2 waves/SIMD => 256-VGPR budget for its register-blocked phases
+constexpr int IU = 5;        // float2 column chunks a lane keeps in flight per row
 
 struct EncK {
   int B, T, C, L, F, K, P, Hc, n_conv, n_pool, FQ;
@@ -104,16 +106,21 @@ __global__ void __launch_bounds__(ENC_NT) enc_fwd_kernel(const EncK k) {
   }
   __syncthreads();
   STAMP(2);
-  // average pool, stride 1 (sum / P as ATen's avg_pool does), filter-major flatten
-  const float fP = (float)k.P;
-  for (int e = tid; e < TBE * FQ; e += NT) {
-    const int tb = e / FQ, i = e - tb * FQ;
-    const int f = i / n_pool, q = i - f * n_pool;
-    float sum = 0.f;
-    for (int j = 0; j < k.P; ++j) sum += s_conv[(tb * F + f) * n_conv + q + j];
-    const float v = sum / fP;
-    s_pool[tb * FQ + i] = v;
-    if (k.pooled && b0 + tb < k.B) k.pooled[(long long)(b0 + tb) * FQ + i] = v;
+  // average pool, stride 1 (sum / P as ATen's avg_pool does), filter-major flatten; one wave per (tb, f) row
+  {
+    const float fP = (float)k.P;
+    const int wave = tid >> 6, lane = tid & 63, nw = NT >> 6;
+    for (int row = wave; row < TBE * F; row += nw) {
+      const int tb = row / F, f = row - tb * F;
+      const float* cr = s_conv + row * n_conv;
+      for (int q = lane; q < n_pool; q += 64) {
+        float sum = 0.f;
+        for (int j = 0; j < k.P; ++j) sum += cr[q + j];
+        const float v = sum / fP;
+        s_pool[tb * FQ + f * n_pool + q] = v;
+        if (k.pooled && b0 + tb < k.B) k.pooled[(long long)(b0 + tb) * FQ + f * n_pool + q] = v;
+      }
+    }
   }
   __syncthreads();
   STAMP(3);
@@ -128,17 +135,51 @@ __global__ void __launch_bounds__(ENC_NT) enc_fwd_kernel(const EncK k) {
       for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int tb = 0; tb < TBE; ++tb) acc[r][tb] = 0.f;
+      if ((FQ & 1) == 0) {
+        // each lane owns column pairs i = 2*lane + 128*it; all RB x IU float2 loads of a macro-iteration are issued
+        // before the first FMA so ~10 KB per wave are in flight (the phase is L2-latency bound otherwise)
+        const float* wrow[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) wrow[r] = k.lin_w + (long long)min(m0 + r, Hc - 1) * FQ;
+        for (int i0 = 2 * lane; i0 < FQ; i0 += 128 * IU) {
+          float2 w[RB][IU];
+#pragma unroll
+          for (int u = 0; u < IU; ++u) {
+            const int i = i0 + 128 * u;
+            const int ic = min(i, FQ - 2);  // unconditional load from a clamped address, zeroed by a select below:
+#pragma unroll                          // a predicated load would become a branch + s_waitcnt per load
+            for (int r = 0; r < RB; ++r) w[r][u] = *reinterpret_cast<const float2*>(wrow[r] + ic);
+          }
+#pragma unroll
+          for (int u = 0; u < IU; ++u) {
+            const bool in = i0 + 128 * u < FQ;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) { w[r][u].x = in ? w[r][u].x : 0.f; w[r][u].y = in ? w[r][u].y : 0.f; }
+          }
+#pragma unroll
+          for (int u = 0; u < IU; ++u) {
+            const int i = min(i0 + 128 * u, FQ - 2);  // out-of-range chunks carry zero weights
+#pragma unroll
+            for (int tb = 0; tb < TBE; ++tb) {
+              const float2 pv = *reinterpret_cast<const float2*>(s_pool + tb * FQ + i);
+#pragma unroll
+              for (int r = 0; r < RB; ++r) acc[r][tb] = fmaf(w[r][u].y, pv.y, fmaf(w[r][u].x, pv.x, acc[r][tb]));
+            }
+          }
+        }
+      } else {
 #pragma unroll 4
-      for (int i = lane; i < FQ; i += 64) {
-        float pv[TBE];
+        for (int i = lane; i < FQ; i += 64) {
+          float pv[TBE];
 #pragma unroll
-        for (int tb = 0; tb < TBE; ++tb) pv[tb] = s_pool[tb * FQ + i];
+          for (int tb = 0; tb < TBE; ++tb) pv[tb] = s_pool[tb * FQ + i];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-          const int m = min(m0 + r, Hc - 1);
-          const float w = k.lin_w[(long long)m * FQ + i];
+          for (int r = 0; r < RB; ++r) {
+            const int m = min(m0 + r, Hc - 1);
+            const float w = k.lin_w[(long long)m * FQ + i];
 #pragma unroll
-          for (int tb = 0; tb < TBE; ++tb) acc[r][tb] = fmaf(w, pv[tb], acc[r][tb]);
+            for (int tb = 0; tb < TBE; ++tb) acc[r][tb] = fmaf(w, pv[tb], acc[r][tb]);
+          }
         }
       }
 #pragma unroll
@@ -175,7 +216,7 @@ __global__ void __launch_bounds__(ENC_NT) enc_fwd_kernel(const EncK k) {
 // ---- backward, part 1: heads, tanh, lin^T, pool^T, conv weight gradient -----------------------------------
 // small slab layout: [conv_w F*C*K][conv_b F][lin_b Hc][zloc_w L*Hc][zloc_b L][zls_w L*Hc][zls_b L]
 template <int C, int K>
-__global__ void __launch_bounds__(ENC_NT) enc_bwd_kernel(const EncK k) {
+__global__ void __launch_bounds__(ENC_NT_BWD) enc_bwd_kernel(const EncK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, NT = blockDim.x;
   const int T = k.T, F = k.F, n_conv = k.n_conv, n_pool = k.n_pool, FQ = k.FQ, Hc = k.Hc, L = k.L;
@@ -250,34 +291,64 @@ __global__ void __launch_bounds__(ENC_NT) enc_bwd_kernel(const EncK k) {
     for (int tb = 0; tb < TBE; ++tb) a += s_gpre[mm * TBE + tb];
     slab[o_linb + mm] = a;
   }
-  // g_pooled[tb][i] = sum_m g_pre[tb][m] * lin_w[m][i]   (thread <-> i, coalesced rows of lin_w)
-  for (int i = tid; i < FQ; i += NT) {
-    float acc[TBE];
+  // g_pooled[tb][i] = sum_m g_pre[tb][m] * lin_w[m][i]   (thread <-> column pair, coalesced rows of lin_w, MB loads in flight)
+  if ((FQ & 1) == 0) {
+    constexpr int MB = 25;
+    for (int i = 2 * tid; i < FQ; i += 2 * NT) {
+      float acc[TBE][2];
 #pragma unroll
-    for (int tb = 0; tb < TBE; ++tb) acc[tb] = 0.f;
-#pragma unroll 10
-    for (int mm = 0; mm < Hc; ++mm) {
-      const float w = k.lin_w[(long long)mm * FQ + i];
-      const float4 g = *reinterpret_cast<const float4*>(s_gpre + mm * TBE);
-      acc[0] = fmaf(g.x, w, acc[0]); acc[1] = fmaf(g.y, w, acc[1]);
-      acc[2] = fmaf(g.z, w, acc[2]); acc[3] = fmaf(g.w, w, acc[3]);
+      for (int tb = 0; tb < TBE; ++tb) acc[tb][0] = acc[tb][1] = 0.f;
+      for (int mb = 0; mb < Hc; mb += MB) {
+        float2 w[MB];
+#pragma unroll
+        for (int q = 0; q < MB; ++q)  // unconditional loads (clamped row); rows >= Hc meet g_pre == 0 below
+          w[q] = *reinterpret_cast<const float2*>(k.lin_w + (long long)min(mb + q, Hc - 1) * FQ + i);
+#pragma unroll
+        for (int q = 0; q < MB; ++q) {
+          const float4 g = *reinterpret_cast<const float4*>(s_gpre + min(mb + q, 63) * TBE);
+          acc[0][0] = fmaf(g.x, w[q].x, acc[0][0]); acc[0][1] = fmaf(g.x, w[q].y, acc[0][1]);
+          acc[1][0] = fmaf(g.y, w[q].x, acc[1][0]); acc[1][1] = fmaf(g.y, w[q].y, acc[1][1]);
+          acc[2][0] = fmaf(g.z, w[q].x, acc[2][0]); acc[2][1] = fmaf(g.z, w[q].y, acc[2][1]);
+          acc[3][0] = fmaf(g.w, w[q].x, acc[3][0]); acc[3][1] = fmaf(g.w, w[q].y, acc[3][1]);
+        }
+      }
+#pragma unroll
+      for (int tb = 0; tb < TBE; ++tb) { s_gpool[tb * FQ + i] = acc[tb][0]; s_gpool[tb * FQ + i + 1] = acc[tb][1]; }
     }
+  } else {
+    for (int i = tid; i < FQ; i += NT) {
+      float acc[TBE];
 #pragma unroll
-    for (int tb = 0; tb < TBE; ++tb) s_gpool[tb * FQ + i] = acc[tb];
+      for (int tb = 0; tb < TBE; ++tb) acc[tb] = 0.f;
+#pragma unroll 10
+      for (int mm = 0; mm < Hc; ++mm) {
+        const float w = k.lin_w[(long long)mm * FQ + i];
+        const float4 g = *reinterpret_cast<const float4*>(s_gpre + mm * TBE);
+        acc[0] = fmaf(g.x, w, acc[0]); acc[1] = fmaf(g.y, w, acc[1]);
+        acc[2] = fmaf(g.z, w, acc[2]); acc[3] = fmaf(g.w, w, acc[3]);
+      }
+#pragma unroll
+      for (int tb = 0; tb < TBE; ++tb) s_gpool[tb * FQ + i] = acc[tb];
+    }
   }
   __syncthreads();
   STAMP(11);
-  // pool^T: g_conv[p] = (1/P) * sum_{q in [p-P+1, p] ∩ [0, n_pool)} g_pooled[q]
-  const float fP = (float)k.P;
-  for (int e = tid; e < TBE * F * n_conv; e += NT) {
-    const int p = e % n_conv, tf = e / n_conv;  // tf = tb*F + f
-    const int tb = tf / F, f = tf - tb * F;
-    float sum = 0.f;
-    for (int j = 0; j < k.P; ++j) {
-      const int q = p - j;
-      if (q >= 0 && q < n_pool) sum += s_gpool[tb * FQ + f * n_pool + q];
+  // pool^T: g_conv[p] = (1/P) * sum_{q in [p-P+1, p] ∩ [0, n_pool)} g_pooled[q]; one wave per (tb, f) row
+  {
+    const float fP = (float)k.P;
+    const int wave = tid >> 6, lane = tid & 63, nw = NT >> 6;
+    for (int row = wave; row < TBE * F; row += nw) {
+      const int tb = row / F, f = row - tb * F;
+      const float* gr = s_gpool + tb * FQ + f * n_pool;
+      for (int p = lane; p < n_conv; p += 64) {
+        float sum = 0.f;
+        for (int j = 0; j < k.P; ++j) {
+          const int q = p - j;
+          if (q >= 0 && q < n_pool) sum += gr[q];
+        }
+        s_gconv[row * n_conv + p] = sum / fP;
+      }
     }
-    s_gconv[e] = sum / fP;
   }
   __syncthreads();
   STAMP(12);
@@ -352,6 +423,7 @@ __global__ void __launch_bounds__(ENC_NT) enc_bwd_kernel(const EncK k) {
 // rows of row-major HBM arrays, so lane (l&31, l>>5) loads element [b0 + (l>>5)][base + (l&31)] directly (coalesced).
 // Workgroup = 4 waves = 4 K-splits of one 64(m) x 32(i) output tile, reduced in LDS; grid = (i-tiles, splitk_grid).
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+constexpr int KP = 16;  // batch-pairs (K = 2 each) whose operands a wave loads before issuing the MFMAs
 
 __global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restrict__ g_pre, const float* __restrict__ pooled,
                                                           float* __restrict__ slabs, int B, int Hc, int FQ, int per_wave) {
@@ -362,19 +434,26 @@ __global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restric
   const int bbeg = ks * per_wave, bend = min(B, bbeg + per_wave);
   const int col = lane & 31, kh = lane >> 5;
   const bool col_ok = i0 + col < FQ;
+  const int icol = min(i0 + col, FQ - 1);
   f32x16 acc0 = {0}, acc1 = {0};
-  for (int bb = bbeg; bb < bend; bb += 8) {
-    float a0[4], a1[4], bv[4];
+  for (int bb = bbeg; bb < bend; bb += 2 * KP) {
+    float a0[KP], a1[KP], bv[KP];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int b = bb + 2 * q + kh;
-      const bool ok = b < bend;
-      a0[q] = ok ? g_pre[(long long)b * 64 + col] : 0.f;
-      a1[q] = ok ? g_pre[(long long)b * 64 + 32 + col] : 0.f;
-      bv[q] = (ok && col_ok) ? pooled[(long long)b * FQ + i0 + col] : 0.f;
+    for (int q = 0; q < KP; ++q) {
+      const int b = min(bb + 2 * q + kh, B - 1);  // unconditional clamped loads, masked by selects below
+      a0[q] = g_pre[(long long)b * 64 + col];
+      a1[q] = g_pre[(long long)b * 64 + 32 + col];
+      bv[q] = pooled[(long long)b * FQ + icol];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < KP; ++q) {
+      const bool ok = bb + 2 * q + kh < bend;
+      a0[q] = ok ? a0[q] : 0.f;
+      a1[q] = ok ? a1[q] : 0.f;
+      bv[q] = (ok && col_ok) ? bv[q] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < KP; ++q) {
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], bv[q], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], bv[q], acc1, 0, 0, 0);
     }
@@ -413,7 +492,7 @@ size_t enc_fwd_lds(const EncK& k) {
 }
 size_t enc_bwd_lds(const EncK& k) {
   size_t gpool = (size_t)TBE * k.FQ;
-  const size_t red = (size_t)(ENC_NT / 64) * 16 * (k.C * k.K + 1);
+  const size_t red = (size_t)(ENC_NT_BWD / 64) * 16 * (k.C * k.K + 1);
   if (red > gpool) gpool = red;
   return sizeof(float) * ((size_t)TBE * k.C * k.T + gpool + (size_t)TBE * k.F * k.n_conv + 64 * TBE + TBE * 64 +
                           2 * (size_t)TBE * k.L + 2 * (size_t)k.L * k.Hc);
@@ -424,7 +503,7 @@ size_t enc_bwd_lds(const EncK& k) {
 int slode_enc_small_count(const slode_shape& s) { return s.F * s.C * s.K + s.F + s.Hc + 2 * (s.L * s.Hc + s.L); }
 int slode_enc_bwd_grid(const slode_shape& s) { return (s.B + TBE - 1) / TBE; }
 int slode_enc_lin_splitk(const slode_shape& s) {
-  int g = (s.B + 255) / 256;
+  int g = (s.B + 127) / 128;  // 4 waves per workgroup => <= 32 trajectories (one prefetch batch) per wave up to B = 2048
   if (g < 1) g = 1;
   if (g > 16) g = 16;
   return g;
@@ -458,10 +537,10 @@ hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream, hipEv
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (a.s.C == 3 && a.s.K == 10) {
     hipFuncSetAttribute((const void*)enc_bwd_kernel<3, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((enc_bwd_kernel<3, 10>), dim3(a.grid_small), dim3(ENC_NT), lds, stream, k);
+    hipLaunchKernelGGL((enc_bwd_kernel<3, 10>), dim3(a.grid_small), dim3(ENC_NT_BWD), lds, stream, k);
   } else if (a.s.C == 4 && a.s.K == 10) {
     hipFuncSetAttribute((const void*)enc_bwd_kernel<4, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((enc_bwd_kernel<4, 10>), dim3(a.grid_small), dim3(ENC_NT), lds, stream, k);
+    hipLaunchKernelGGL((enc_bwd_kernel<4, 10>), dim3(a.grid_small), dim3(ENC_NT_BWD), lds, stream, k);
   } else {
     return hipErrorInvalidValue;
   }

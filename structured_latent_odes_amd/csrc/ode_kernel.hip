@@ -200,7 +200,7 @@ __device__ __forceinline__ void wave_affine_scan(const float* __restrict__ s_A, 
   constexpr int NC = 64 / S;
   constexpr int CLMAX = 12;  // steps per lane per pass (2 x CLMAX registers); longer grids take several passes
   const int nsteps = T - 1;
-  const int c = lane / S, s = lane - c * S;
+  const int c = lane / S, s = min(lane - c * S, S - 1);
   const bool lane_on = c < NC;
   float carry = lane_on ? s_v[(REV ? (T - 1) : 0) * S + s] : 0.f;
   for (int base = 0; base < nsteps; base += NC * CLMAX) {
@@ -213,9 +213,10 @@ __device__ __forceinline__ void wave_affine_scan(const float* __restrict__ s_A, 
     for (int q = 0; q < CLMAX; ++q) {
       const int kk = k0 + q;
       const bool on = lane_on && q < CL && kk < nsteps;
-      const int i = REV ? (T - 2 - kk) : kk;
-      Ar[q] = on ? s_A[i * S + s] : 1.f;
-      vr[q] = on ? s_v[(REV ? i : i + 1) * S + s] : 0.f;
+      const int kc = min(kk, nsteps - 1), i = REV ? (T - 2 - kc) : kc;  // unconditional LDS reads (clamped), then selects
+      const float Aq = s_A[i * S + s], vq = s_v[(REV ? i : i + 1) * S + s];
+      Ar[q] = on ? Aq : 1.f;
+      vr[q] = on ? vq : 0.f;
     }
     float Ac = 1.f, bc = 0.f;
 #pragma unroll
