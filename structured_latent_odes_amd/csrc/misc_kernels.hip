@@ -42,9 +42,14 @@ __device__ __forceinline__ float strided_sum(const float* p, int stride, int n) 
 
 // Stage 1 of the slab reduction: [n][stride] -> [G][stride] partial sums.  Block = 64 elements x 4 sub-groups; every
 // thread keeps 4 independent loads in flight; summation order is fixed (slab index) => bitwise reproducible.
-__global__ void __launch_bounds__(256) slab_stage1_kernel(const float* __restrict__ slabs, int stride, int n, int count, int per,
-                                                          float* __restrict__ out) {
+struct Stage1 { const float* slabs; int stride, n, count, per; float* out; };
+__global__ void __launch_bounds__(256) slab_stage1_kernel(const Stage1 fam0, const Stage1 fam1) {
   __shared__ float s_p[4][64];
+  const Stage1 f = blockIdx.z == 0 ? fam0 : fam1;  // two slab families reduced by one launch
+  const float* __restrict__ slabs = f.slabs;
+  float* __restrict__ out = f.out;
+  const int stride = f.stride, n = f.n, count = f.count, per = f.per;
+  if (slabs == nullptr || blockIdx.x * 64 >= count) return;
   const int e = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6, g = blockIdx.y;
   const int w0 = g * per, w1 = min(n, w0 + per);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -147,16 +152,20 @@ hipError_t slode_launch_reduce(const ReduceLaunch& a_in, hipStream_t stream) {
   const slode_shape& s = a.s;
   const int n_conv = s.T - s.K + 1, FQ = s.F * (n_conv - s.P + 1);
   // two-stage: n slabs -> SLODE_REDUCE_GROUPS partial slabs -> final (keeps every thread's serial loop short)
-  auto stage1 = [&](const float*& slabs, int stride, int& n, int count, float* part) {
+  Stage1 fam[2] = {{nullptr, 0, 0, 0, 0, nullptr}, {nullptr, 0, 0, 0, 0, nullptr}};
+  int maxcount = 0;
+  auto stage1 = [&](int slot, const float*& slabs, int stride, int& n, int count, float* part) {
     if (!slabs || !part || n <= 2 * SLODE_REDUCE_GROUPS) return;
     const int per = (n + SLODE_REDUCE_GROUPS - 1) / SLODE_REDUCE_GROUPS;
-    hipLaunchKernelGGL(slab_stage1_kernel, dim3((count + 63) / 64, SLODE_REDUCE_GROUPS), dim3(256), 0, stream, slabs, stride, n,
-                       count, per, part);
+    fam[slot] = Stage1{slabs, stride, n, count, per, part};
+    if (count > maxcount) maxcount = count;
     slabs = part;
     n = (n + per - 1) / per;
   };
-  stage1(a.ode_slabs, a.ode_stride, a.ode_n, (a.lay.ode_end - a.lay.ode_begin) + 1, a.ode_part);
-  stage1(a.small_slabs, a.small_stride, a.small_n, slode_enc_small_count(s), a.small_part);
+  stage1(0, a.ode_slabs, a.ode_stride, a.ode_n, (a.lay.ode_end - a.lay.ode_begin) + 1, a.ode_part);
+  stage1(1, a.small_slabs, a.small_stride, a.small_n, slode_enc_small_count(s), a.small_part);
+  if (maxcount > 0)
+    hipLaunchKernelGGL(slab_stage1_kernel, dim3((maxcount + 63) / 64, SLODE_REDUCE_GROUPS, 2), dim3(256), 0, stream, fam[0], fam[1]);
   k.ode_slabs = a.ode_slabs; k.ode_stride = a.ode_stride; k.ode_n = a.ode_n;
   k.nseg = a.lay.ode_end - a.lay.ode_begin; k.ode_begin = a.lay.ode_begin;
   k.small_slabs = a.small_slabs; k.small_stride = a.small_stride; k.small_n = a.small_n;
