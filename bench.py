@@ -3,7 +3,7 @@
 
 A "step" is one pass of the hot path over one synthetic CVS-shaped minibatch shard: encoder -> latent sample -> rk4
 (3/8-rule) latent-ODE solve over T=200 -> 3 quantile heads -> asymmetric-Laplace likelihood + latent log-probs ->
--ELBO -> exact gradient of all 96,462 parameters (one slode_elbo_step call) -> [N>1: one RCCL SUM all-reduce of the flat
+-ELBO -> exact gradient of all 96,210 hot-path parameters (one slode_elbo_step call) -> [N>1: one RCCL SUM all-reduce of the flat
 gradient + loss scalar] -> Adam (one slode_adam_step call).  Workload = BASELINE config[1] "Synthetic CVS batch=1024,
 T=200, latent_dim=8, blackbox_ode RK4" per GPU; N GPUs run N such shards (config[3]: 8 x 1024 = 8192) => weak scaling.
 Inputs are generated on the host from a seed and are resident in HBM before the timed region starts.
@@ -63,20 +63,28 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=dev)
 
-    from oracle import slode_oracle as O            # synthetic data + reference initialisers (and the cpu_baseline leg)
-    from structured_latent_odes_amd import engine as E
+    from structured_latent_odes_amd.configs import load_config_cvs
+    from structured_latent_odes_amd.models.mechanistic_cvs import MechanisticModel
     from structured_latent_odes_amd.svi import ELBOStep, FlatAdam
+    from structured_latent_odes_amd.synthetic import synthetic_batch
+    from structured_latent_odes_amd.utils.utils import set_seed
 
-    ospec = O.cvs_spec(*Z_SPLIT, solver="rk4")
-    params = O.init_params(ospec, T=T, seed=12)                     # identical on every rank (config_cvs.py:28 seed)
-    obs, u, eps, times = O.synthetic_batch(ospec, B_PER_GPU, T, seed=1234 + rank)   # this rank's shard
-    eng = E.Engine(E.cvs_spec(*Z_SPLIT, solver="rk4"), T, dev)
-    eng.set_times(times)
-    flat = eng.pack(params)
-    obs_d = obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)   # [B,C,T] view of contiguous [B,T,C] (native layout)
-    u_d, eps_d = u.to(dev).contiguous(), eps.to(dev).contiguous()
-    opt = FlatAdam(eng, flat, lr=1e-3)
+    cfg = load_config_cvs()
+    cfg.update(seq_len=T, z_iext_dim=Z_SPLIT[0], z_rtpr_dim=Z_SPLIT[1], z_epsilon_dim=Z_SPLIT[2], solver="rk4", mini_batch_size=B_PER_GPU)
+    set_seed(cfg.seed)                                              # identical weights on every rank (config_cvs.py:28)
+    times = torch.arange(0.0, T * cfg.delta_t, cfg.delta_t, device=dev)
+    model = MechanisticModel(cfg, dev, times)                       # reference initialisers, random init
+    binding = model._bind()
+    eng, flat = binding.engine, binding.flat
+    obs, labels, _ = synthetic_batch("cvs", B_PER_GPU, T, 3, seed=1234 + rank)   # this rank's shard
+    obs_d = obs.to(dev)                                             # [B,C,T] view of a contiguous [B,T,C] tensor (native layout)
+    u_d = model.labels_to_u(**{k: v.to(dev) for k, v in labels.items()})
+    eps_d = torch.randn(B_PER_GPU, model.latent_dim, generator=torch.Generator().manual_seed(99 + rank)).to(dev)
+    assert obs_d.stride() == (T * 3, 1, 3), obs_d.stride()
+    opt = FlatAdam(eng, flat, lr=cfg.learning_rate)
     svi = ELBOStep(eng, flat, opt)
+    # snapshot for the CPU baseline (the timed loop below updates `flat` in place)
+    cpu_params = {k: v.detach().cpu().clone() for k, v in eng.unpack(flat[:eng.n_params]).items()} if rank == 0 and world == 1 else None
 
     def sync():
         if world > 1:
@@ -127,7 +135,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE config[1]: synthetic CVS, B=1024/GPU, T=200, C=3, latent_dim=8 (3,3,2), S=5, "
-                               "rk4(3/8) fixed grid dt=1, ALD 3-quantile likelihood; step = ELBO fwd+bwd (all 96,462 params) "
+                               "rk4(3/8) fixed grid dt=1, ALD 3-quantile likelihood; step = ELBO fwd+bwd (all 96,210 hot-path params) "
                                "+ grad all-reduce (N>1) + Adam",
                    "global_batch": world * B_PER_GPU, "T": T, "parallelism": "dp%d" % world},
         "final_loss_per_traj": final_loss / (world * B_PER_GPU),
@@ -140,17 +148,30 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        nthreads = torch.get_num_threads()
-        for _ in range(2):
-            O.loss_and_grads(params, ospec, obs, u, eps, times)
+        from oracle import slode_oracle as O        # the ONLY use of the oracle here: the reported CPU baseline
+        ospec = O.cvs_spec(*Z_SPLIT, solver="rk4")
+        c_obs, c_u, c_eps, c_t = obs.cpu(), u_d.cpu(), eps_d.cpu(), times.cpu()
+        # eager PyTorch with one thread per core thrashes on these tiny ops; pick the fastest of a few thread counts
+        best_n, best_t = torch.get_num_threads(), float("inf")
+        for n in sorted({8, 16, 32, torch.get_num_threads()}):
+            if n > (os.cpu_count() or n):
+                continue
+            torch.set_num_threads(n)
+            O.loss_and_grads(cpu_params, ospec, c_obs, c_u, c_eps, c_t)
+            c0 = time.perf_counter()
+            O.loss_and_grads(cpu_params, ospec, c_obs, c_u, c_eps, c_t)
+            if time.perf_counter() - c0 < best_t:
+                best_n, best_t = n, time.perf_counter() - c0
+        torch.set_num_threads(best_n)
+        nthreads = best_n
         n_cpu, c0 = 0, time.perf_counter()
         while n_cpu < 4 or (time.perf_counter() - c0 < 12.0 and n_cpu < 64):
-            O.loss_and_grads(params, ospec, obs, u, eps, times)
+            O.loss_and_grads(cpu_params, ospec, c_obs, c_u, c_eps, c_t)
             n_cpu += 1
         cdt = time.perf_counter() - c0
         out["cpu_baseline"] = {"value": B_PER_GPU * n_cpu / cdt, "unit": "trajectories/s", "cores": nthreads, "kind": "port",
                                "sample": "same workload (B=1024, T=200, rk4), %d ELBO fwd+bwd steps (no Adam) after 2 warm-ups, "
-                                         "oracle/slode_oracle.py eager PyTorch fp32, torch threads=%d" % (n_cpu, nthreads)}
+                                         "oracle/slode_oracle.py eager PyTorch fp32, torch threads=%d (fastest of 8/16/32/all)" % (n_cpu, nthreads)}
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -135,6 +135,11 @@ int slode_ode_solve_bwd(slode_handle h, const slode_shape* s, const slode_layout
                         const float* times, const float* stage_t, const float* z, const float* g_x,
                         float* g_z, float* grads, void* workspace, size_t workspace_bytes, void* stream);
 
+/* OdeFunc.forward(t, state) (models/blackbox_ode.py:57-61 -> Dynamics.forward :97-109): one evaluation of
+ * dx/dt = a(t,z) - d(t,z) * state for state[B,S], z[B,L] -> out[B,S].  API completeness; the solver does not use it. */
+int slode_dynamics_eval(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, float t,
+                        const float* state, const float* z, float* out, void* stream);
+
 /* Decoder.forward / GaussianDecoder.forward heads (models/decoders.py:45-53, 86-89) on a given trajectory:
  * x[B,T,S] -> mu[Q][B,C,T] (Q = 3: mu_50, mu_75, mu_25 in that order; Q = 1: mean) and std[C,T] = softplus(constant_std). */
 int slode_decode_heads(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params,

@@ -119,6 +119,29 @@ __global__ void decode_heads_kernel(const float* __restrict__ x, const float* __
   mu[i] = acc;
 }
 
+// One evaluation of the dynamics net, OdeFunc.forward(t, state) -> dx/dt = a(t,z) - d(t,z) * state
+// (models/blackbox_ode.py:57-61,97-109).  Thread per trajectory; API-completeness kernel (the solver never calls it).
+__global__ void dynamics_eval_kernel(const float* __restrict__ params, int wh, int bh, int wg, int bg, int wd, int bd, int B, int L,
+                                     int S, int H, float t, const float* __restrict__ state, const float* __restrict__ z,
+                                     float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float h[SLODE_MAX_H];
+  for (int j = 0; j < H; ++j) {
+    float pre = fmaf(params[wh + j * (1 + L)], t, params[bh + j]);
+    for (int l = 0; l < L; ++l) pre = fmaf(params[wh + j * (1 + L) + 1 + l], z[(long long)b * L + l], pre);
+    h[j] = fmaxf(pre, 0.f);
+  }
+  for (int s = 0; s < S; ++s) {
+    float xa = params[bg + s], xd = params[bd + s];
+    for (int j = 0; j < H; ++j) {
+      xa = fmaf(params[wg + s * H + j], h[j], xa);
+      xd = fmaf(params[wd + s * H + j], h[j], xd);
+    }
+    out[(long long)b * S + s] = sigmoidf_fast(xa) - sigmoidf_fast(xd) * state[(long long)b * S + s];
+  }
+}
+
 // torch.optim.Adam single-tensor update (amsgrad=False, weight_decay=0, maximize=False) as applied per parameter by
 // pyro.optim.Adam (training_cvs.py:226-227): exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v + (1-b2) g*g;
 // denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m/denom.
@@ -184,6 +207,13 @@ hipError_t slode_launch_decode_heads(const slode_shape& s, const slode_layout& l
   if (total < (long long)s.C * s.T) total = (long long)s.C * s.T;
   hipLaunchKernelGGL(decode_heads_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, params, s.B, s.T,
                      s.C, s.S, Q, lay.head_w[0], lay.head_w[1], lay.head_w[2], lay.cstd, mu, std_ct);
+  return hipGetLastError();
+}
+
+hipError_t slode_launch_dynamics_eval(const slode_shape& s, const slode_layout& lay, const float* params, float t,
+                                      const float* state, const float* z, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(dynamics_eval_kernel, dim3((s.B + 63) / 64), dim3(64), 0, stream, params, lay.dyn_wh, lay.dyn_bh, lay.dyn_wg,
+                     lay.dyn_bg, lay.dyn_wd, lay.dyn_bd, s.B, s.L, s.S, s.H, t, state, z, out);
   return hipGetLastError();
 }
 

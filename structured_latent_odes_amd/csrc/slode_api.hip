@@ -355,6 +355,15 @@ int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* la
   return SLODE_OK;
 }
 
+int slode_dynamics_eval(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, float t,
+                        const float* state, const float* z, float* out, void* stream) {
+  const char* why = check_common(h, s, lay, params);
+  if (why) return fail(h, SLODE_EINVAL, "%s", why);
+  if (!state || !z || !out) return fail(h, SLODE_EINVAL, "state / z / out is NULL");
+  HIP_TRY(h, slode_launch_dynamics_eval(*s, *lay, params, t, state, z, out, (hipStream_t)stream));
+  return SLODE_OK;
+}
+
 int slode_profile_enable(slode_handle h, int on) {
   if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
   if (on && !h->ev_ready) {

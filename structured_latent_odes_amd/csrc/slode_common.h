@@ -138,5 +138,7 @@ hipError_t slode_launch_reduce(const ReduceLaunch& a, hipStream_t stream);
 hipError_t slode_launch_stage_times(const slode_shape& s, const float* times, float* stage_t, hipStream_t stream);
 hipError_t slode_launch_decode_heads(const slode_shape& s, const slode_layout& lay, const float* params,
                                      const float* x, float* mu, float* std_ct, hipStream_t stream);
+hipError_t slode_launch_dynamics_eval(const slode_shape& s, const slode_layout& lay, const float* params, float t,
+                                      const float* state, const float* z, float* out, hipStream_t stream);
 hipError_t slode_launch_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2,
                              float eps, int64_t step, hipStream_t stream);

@@ -221,6 +221,14 @@ class Engine:
             self._p(self._f32(z, "z")), self._p(self._f32(g_x, "g_x")), self._p(g_z), self._p(grads), self._p(ws), ws.numel() * 4, self._stream()))
         return g_z
 
+    def dynamics_eval(self, params, t: float, state, z):
+        B = z.shape[0]
+        out = torch.empty_like(state)
+        _check(self.lib, self.handle, self.lib.slode_dynamics_eval(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), float(t), self._p(self._f32(state, "state")),
+            self._p(self._f32(z, "z")), self._p(out), self._stream()))
+        return out
+
     def decode_heads(self, params, x):
         B = x.shape[0]
         sp = self.spec

@@ -72,3 +72,138 @@ class ELBOStep:
         if self.world > 1:
             torch.distributed.all_reduce(self.loss, op=torch.distributed.ReduceOp.SUM, group=self.pg)
         return float(self.loss.item())
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Name-compatible stand-ins for the three Pyro objects the reference training scripts construct (training_cvs.py:226-249):
+#     optimizer = Adam({"lr": ..., "betas": (0.9, 0.999)});  elbo = Trace_ELBO(num_particles=1)
+#     loss_basic = SVI(var_model.model, var_model.guide, optimizer, loss=elbo)
+#     loss_aux   = SVI(var_model.model_meta, var_model.guide_meta, optimizer, loss=elbo)
+# ------------------------------------------------------------------------------------------------------------------------
+class Adam:
+    """pyro.optim.Adam stand-in: one optimizer object shared by both SVI objects, state created on first use."""
+
+    def __init__(self, optim_args):
+        self.optim_args = dict(optim_args)
+        self._flat: Optional[FlatAdam] = None
+
+    def for_binding(self, binding) -> FlatAdam:
+        if self._flat is None:
+            a = self.optim_args
+            self._flat = FlatAdam(binding.engine, binding.flat, lr=a.get("lr", 1e-3), betas=tuple(a.get("betas", (0.9, 0.999))),
+                                  eps=a.get("eps", 1e-8))
+        return self._flat
+
+
+class Trace_ELBO:
+    """pyro.infer.Trace_ELBO stand-in; only num_particles=1 (the reference's setting, config_cvs.py:44) is supported."""
+
+    def __init__(self, num_particles=1, **kwargs):
+        if num_particles != 1:
+            raise NotImplementedError("num_particles != 1")
+        self.num_particles = num_particles
+
+
+class AuxStep:
+    """-ELBO of SVI(model_meta, guide_meta) (mechanistic_cvs.py:240-276): encoder again (HIP, through the module-level
+    autograd functions), group latents sampled in the model, labels scored at aux_loss_multiplier.  SURVEY row N1: this
+    composition (HIP encoder fwd/bwd + a 176-parameter torch MLP per head) is functional, not yet fused."""
+
+    def __init__(self, owner, optimizer: Optional[FlatAdam]):
+        self.owner, self.optimizer = owner, optimizer
+        b = owner._bind()
+        self.gbuf = torch.zeros(b.n_total, dtype=torch.float32, device=b.flat.device)
+
+    def _loss(self, observations, labels, eps):
+        from torch.distributions import Bernoulli, Laplace, Normal, OneHotCategorical
+        o = self.owner
+        loc, scale = o.encoder.forward(observations)
+        lp = loc.new_zeros(())
+        for attr, group, label, kind in o.AUX:
+            lg, sg = o._z_group(loc, group), o._z_group(scale, group)
+            zg = lg + sg * o._z_group(eps, group)
+            lp = lp + Normal(lg, sg).log_prob(zg).sum()
+            lab = labels[label].reshape(zg.shape[0], -1).to(torch.float32)
+            out = getattr(o, attr)(zg)
+            if kind == "sigmoid":
+                term = Bernoulli(probs=out).log_prob(lab).sum()
+            elif kind == "softmax":
+                term = OneHotCategorical(probs=out).log_prob(lab).sum()
+            else:
+                std = o.softplus(o.constant_std_C_12 if label == "C12" else o.constant_std_C_6)
+                term = Laplace(out[0], std).log_prob(lab).sum()
+            lp = lp + o.aux_loss_multiplier * term
+        return -lp
+
+    def step(self, observations, eps=None, **labels) -> float:
+        o = self.owner
+        b = o._bind()
+        if eps is None:
+            eps = o.draw_eps(observations.shape[0], b.flat.device)
+        self.gbuf.zero_()
+        b.grad_views(self.gbuf)
+        loss = self._loss(observations, labels, eps)
+        loss.backward()
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            torch.distributed.all_reduce(self.gbuf, op=torch.distributed.ReduceOp.SUM)
+        if self.optimizer is not None:
+            self.optimizer.step(self.gbuf)
+        return float(loss.item())
+
+    def evaluate_loss(self, observations, eps=None, **labels) -> float:
+        o = self.owner
+        b = o._bind()
+        if eps is None:
+            eps = o.draw_eps(observations.shape[0], b.flat.device)
+        with torch.no_grad():
+            return float(self._loss(observations, labels, eps).item())
+
+
+class SVI:
+    """pyro.infer.SVI stand-in: ``SVI(var_model.model, var_model.guide, optimizer, loss=elbo)``.  ``step(**batch)`` /
+    ``evaluate_loss(**batch)`` return -ELBO summed over the batch, like the reference call sites expect
+    (training_cvs.py:81,152-155)."""
+
+    def __init__(self, model, guide, optim, loss=None, **kwargs):
+        owner = getattr(model, "__self__", None)
+        if owner is None or not hasattr(owner, "_bind"):
+            raise TypeError("SVI expects bound methods of a MechanisticModel (model/guide or model_meta/guide_meta)")
+        self.owner, self.kind = owner, ("aux" if model.__name__ == "model_meta" else "main")
+        binding = owner._bind()
+        flat_opt = optim.for_binding(binding) if optim is not None else None
+        if self.kind == "main":
+            if getattr(owner, "LABELS_IN_MAIN", False):
+                self._impl = None
+            else:
+                self._impl = ELBOStep(binding.engine, binding.flat, flat_opt)
+        else:
+            self._impl = AuxStep(owner, flat_opt)
+
+    def _split(self, batch):
+        batch = dict(batch)
+        obs = batch.pop("observations")
+        eps = batch.pop("eps", None)
+        return obs, eps, batch
+
+    def _main_args(self, obs, eps, labels):
+        o = self.owner
+        if self._impl is None:
+            raise NotImplementedError("the %s main loss scores the labels inside the model (mechanistic_proc.py:145-146); "
+                                      "not in the fused kernel yet" % o.FAMILY)
+        if eps is None:
+            eps = o.draw_eps(obs.shape[0], obs.device)
+        return obs, eps, o.labels_to_u(**labels)
+
+    def step(self, **batch) -> float:
+        obs, eps, labels = self._split(batch)
+        if self.kind == "aux":
+            return self._impl.step(obs, eps=eps, **labels)
+        obs, eps, u = self._main_args(obs, eps, labels)
+        return self._impl.step(obs, eps=eps, u=u)
+
+    def evaluate_loss(self, **batch) -> float:
+        obs, eps, labels = self._split(batch)
+        if self.kind == "aux":
+            return self._impl.evaluate_loss(obs, eps=eps, **labels)
+        obs, eps, u = self._main_args(obs, eps, labels)
+        return self._impl.evaluate_loss(obs, eps=eps, u=u)

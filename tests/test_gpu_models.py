@@ -1,0 +1,194 @@
+"""GPU tests of the Python drop-in layer (models.*, svi.SVI/Adam/Trace_ELBO, training_cvs) against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import slode_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=1e-5):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs() / b.abs().clamp_min(1.0)).max().item() < tol
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _cvs(gauss=False, solver="midpoint", T=86, B=24):
+    from structured_latent_odes_amd.configs import load_config_cvs
+    from structured_latent_odes_amd.models.mechanistic_cvs import MechanisticModel
+    from structured_latent_odes_amd.models.mechanistic_cvs_Gauss import MechanisticModelGauss
+    from structured_latent_odes_amd.synthetic import synthetic_batch
+    dev = torch.device("cuda:0")
+    cfg = load_config_cvs()
+    cfg.update(seq_len=T, solver=solver)
+    torch.manual_seed(3)
+    times = torch.arange(0.0, T * 1.0, 1.0, device=dev)
+    m = (MechanisticModelGauss if gauss else MechanisticModel)(cfg, dev, times)
+    with torch.no_grad():                      # move the classifier nets off their N(0, 1e-3) init so the aux test is sensitive
+        for n, p in m.named_parameters():
+            if n.startswith("q_"):
+                p.add_(0.3 * torch.randn_like(p))
+    obs, labels, _ = synthetic_batch("cvs", B, T, 3, seed=7)
+    batch = {"observations": obs.to(dev), "iext": labels["iext"].to(dev), "rtpr": labels["rtpr"].to(dev)}
+    ospec = O.cvs_spec(gauss=gauss, solver=solver)
+    return m, cfg, batch, ospec, dev
+
+
+def _oracle_params(m):
+    return {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize("gauss", [False, True])
+def test_svi_main_matches_oracle_and_updates_parameters(gauss):
+    from structured_latent_odes_amd.svi import SVI, Adam, Trace_ELBO
+    m, cfg, batch, ospec, dev = _cvs(gauss=gauss)
+    p0 = _oracle_params(m)
+    svi = SVI(m.model, m.guide, Adam({"lr": 1e-3, "betas": (0.9, 0.999)}), loss=Trace_ELBO(num_particles=1))
+    eps = torch.randn(24, m.latent_dim, generator=torch.Generator().manual_seed(5))
+    u = torch.cat([batch["iext"], batch["rtpr"]], 1).cpu()
+    want, g = O.loss_and_grads(p0, ospec, batch["observations"].cpu(), u, eps, m.times.cpu())
+    ev = svi.evaluate_loss(eps=eps.to(dev), **batch)
+    assert abs(ev - want.item()) / abs(want.item()) < 1e-5
+    got = svi.step(eps=eps.to(dev), **batch)
+    assert got == ev
+    # one Adam step (first step: p -= lr * sign-ish(g)); compare against torch.optim.Adam on the oracle gradient
+    ref = {k: v.clone().requires_grad_(True) for k, v in p0.items() if k in g and not k.startswith("q_") and ".prod." not in k and ".degr." not in k}
+    opt = torch.optim.Adam(list(ref.values()), lr=1e-3, betas=(0.9, 0.999))
+    for k, v in ref.items():
+        v.grad = g[k].clone()
+    opt.step()
+    p1 = _oracle_params(m)
+    for k, v in ref.items():
+        assert (p1[k] - v.detach()).abs().max().item() < 2e-6, k
+    # parameters the main loss does not touch (auxiliary classifiers) got a zero gradient
+    for k in p0:
+        if k.startswith("q_"):
+            assert torch.equal(p0[k], p1[k]), k
+
+
+def test_aux_svi_matches_oracle():
+    from structured_latent_odes_amd.svi import SVI, Adam
+    m, cfg, batch, ospec, dev = _cvs()
+    p0 = _oracle_params(m)
+    svi = SVI(m.model_meta, m.guide_meta, Adam({"lr": 1e-3}))
+    eps = torch.randn(24, m.latent_dim, generator=torch.Generator().manual_seed(6))
+    u = torch.cat([batch["iext"], batch["rtpr"]], 1).cpu()
+    q = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+    want = O.aux_loss(q, ospec, batch["observations"].cpu(), u, eps)
+    want.backward()
+    ev = svi.evaluate_loss(eps=eps.to(dev), **batch)
+    assert abs(ev - want.item()) / abs(want.item()) < 2e-5
+    svi._impl.optimizer = None                      # inspect the raw gradient of one step
+    svi.step(eps=eps.to(dev), **batch)
+    b = m._bind()
+    for k, sl in b.slices.items():
+        if k.startswith("encoder."):
+            assert _rel(svi._impl.gbuf[sl], q[k].grad.reshape(-1)) < 5e-4, k
+    off = b.engine.n_params
+    for p_extra, (name, _) in zip(b.extra, [(n, p) for n, p in m.named_parameters() if n.startswith("q_")]):
+        n = p_extra.numel()
+        assert _rel(svi._impl.gbuf[off:off + n], q[name].grad.reshape(-1)) < 5e-4, name
+        off += n
+
+
+def test_recon_classifier_and_state_dict_roundtrip():
+    m, cfg, batch, ospec, dev = _cvs(solver="rk4")
+    for is_post in (True, False):
+        r = m.recon(is_post=is_post, **batch)
+        assert r["solution_xt"].shape == (24, 86, 5) and r["mu_50"].shape == (24, 3, 86) and r["std"].shape == (24, 3, 86)
+        assert r["z"].shape == (24, 15) and torch.isfinite(r["l1"])
+    pred = m.classifier(observations=batch["observations"])
+    assert pred["iext"].shape == (24, 1) and set(pred["iext"].unique().tolist()) <= {0.0, 1.0}
+    # decoder outputs of recon equal the oracle's for the same z
+    r = m.recon(is_post=True, **batch)
+    p = _oracle_params(m)
+    sol, mu75, mu50, mu25, std = O.decoder_ald(p, r["z"].cpu(), m.times.cpu(), "rk4")
+    assert _close(r["solution_xt"], sol)
+    assert _rel(r["mu_75"], mu75) < 1e-5 and _rel(r["mu_25"], mu25) < 1e-5 and _rel(r["std"], std) < 1e-6
+    # best-model copy (training_cvs.py:330) keeps the destination bound to its own flat vector
+    from structured_latent_odes_amd.models.mechanistic_cvs import MechanisticModel
+    best = MechanisticModel(cfg, dev, m.times)
+    best._bind()
+    best.load_state_dict(m.state_dict())
+    bb = best._bind()
+    assert torch.equal(bb.flat[:bb.engine.n_params], m._bind().flat[:bb.engine.n_params])
+    r2 = best.decoder.forward(r["z"])
+    assert torch.equal(r2[0], m.decoder.forward(r["z"])[0])
+
+
+def test_module_level_autograd_matches_oracle():
+    """EncoderCONV / OdeModel / Decoder used as ordinary autograd modules (standalone engines)."""
+    from structured_latent_odes_amd.models.blackbox_ode import OdeModel
+    from structured_latent_odes_amd.models.encoder_conv import EncoderCONV
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    enc = EncoderCONV(n_channels=3, n_filters=10, filter_size=10, pool_size=5, n_time=100, latent_dim=8, hidden_dim=50).to(dev)
+    x = torch.rand(6, 100, 3, device=dev).permute(0, 2, 1)
+    loc, scale = enc(x)
+    (loc.sum() + (scale * scale).sum()).backward()
+    p = {"encoder." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in enc.state_dict().items()}
+    wl, ws = O.encoder_conv(p, x.cpu(), 5)
+    (wl.sum() + (ws * ws).sum()).backward()
+    assert _rel(loc, wl) < 2e-5 and _rel(scale, ws) < 2e-5
+    assert _rel(enc.lin.weight.grad, p["encoder.lin.weight"].grad) < 3e-4
+    assert _rel(enc.conv.weight.grad, p["encoder.conv.weight"].grad) < 3e-4
+    assert _rel(enc.z_scale[0].bias.grad, p["encoder.z_scale.0.bias"].grad) < 3e-4
+
+    om = OdeModel()
+    times = torch.arange(0.0, 40.0, device=dev) * 0.5
+    om.init_with_params(times=times, ode_state_dim=5, latent_dim=8, ode_hidden_dim=25, adjoint_solver=True, solver="midpoint", device=dev)
+    om.to(dev)
+    z = torch.randn(7, 8, device=dev, requires_grad=True)
+    sol = om.solve_ODE(z)
+    w = torch.randn(7, 40, 5, device=dev)
+    (sol * w).sum().backward()
+    q = {"decoder.ode_model." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in om.state_dict().items() if ".prod." not in k and ".degr." not in k}
+    zz = z.detach().cpu().clone().requires_grad_(True)
+    want = O.solve_ode(q, zz, times.cpu(), "midpoint")
+    (want * w.cpu()).sum().backward()
+    assert _close(sol.detach(), want.detach())
+    assert _rel(z.grad, zz.grad) < 5e-4
+    assert _rel(om.dynamics.dynamics_hidden.weight.grad, q["decoder.ode_model.dynamics.dynamics_hidden.weight"].grad) < 5e-4
+    assert _rel(om.latent_to_ode_net[2].weight.grad, q["decoder.ode_model.latent_to_ode_net.2.weight"].grad) < 5e-4
+    # OdeFunc.forward(t, state) and initialize_state
+    f = om.gen_dynamics(z.detach())
+    st = torch.rand(7, 5, device=dev)
+    got = f(torch.tensor(0.75), st)
+    wantf = O.dynamics({k: v.detach() for k, v in q.items()}, torch.tensor(0.75), st.cpu(), z.detach().cpu())
+    assert (got.cpu() - wantf).abs().max().item() < 2e-6
+    assert (om.initialize_state(z.detach()).cpu() - O.initialize_state({k: v.detach() for k, v in q.items()}, z.detach().cpu())).abs().max().item() < 2e-6
+
+
+def test_adam_kernel_matches_torch_adam():
+    from structured_latent_odes_amd import engine as E
+    from structured_latent_odes_amd.svi import FlatAdam
+    dev = torch.device("cuda:0")
+    eng = E.Engine(E.cvs_spec(), 86, dev)
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(5000, generator=g)
+    flat = p0.clone().to(dev)
+    opt = FlatAdam(eng, flat, lr=3e-4)
+    ref = p0.clone().requires_grad_(True)
+    ropt = torch.optim.Adam([ref], lr=3e-4, betas=(0.9, 0.999))
+    for i in range(5):
+        gr = torch.randn(5000, generator=g) * (1.0 if i != 3 else 0.0)     # incl. a zero-gradient step (two-SVI case)
+        opt.step(gr.to(dev))
+        ref.grad = gr.clone()
+        ropt.step()
+    assert (flat.cpu() - ref.detach()).abs().max().item() < 1e-6
+
+
+def test_training_entry_point_runs_and_learns():
+    import training_cvs as tc
+    cfg = tc.load_config()
+    cfg.num_epochs, cfg.mini_batch_size = 3, 64
+    var_model, best_model, best_epoch = tc.train(cfg, batches_per_epoch=4)
+    assert 0 <= best_epoch <= 3
+    assert all(torch.isfinite(p).all() for p in var_model.parameters())

@@ -1,0 +1,119 @@
+"""Host-side logic that needs no GPU: the C ABI library loads and exports every symbol include/slode.h declares, the
+parameter layout, loud failure without a device, state_dict compatibility of the mirrored modules.  (No compute calls.)"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from structured_latent_odes_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "slode.h")).read()
+    declared = sorted(set(re.findall(r"\b(slode_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 16
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), "libslode.so does not export %s" % name
+    assert sorted(_lib.EXPORTS) == declared
+
+
+def _shape(**kw):
+    from structured_latent_odes_amd import _lib as L
+    d = dict(B=4, T=200, C=3, L=8, S=5, H=25, F=10, K=10, P=5, Hc=50, n_u=2, n_groups=2, method=L.RK4, likelihood=L.ALD,
+             quantile_diff=0.475, rtol=1e-7, atol=1e-9)
+    d.update(kw)
+    s = L.Shape(**d)
+    s.groups[0] = L.Group(0, 3, 0, 1)
+    s.groups[1] = L.Group(3, 3, 1, 1)
+    return s
+
+
+def test_layout_matches_hand_count_and_rejects_bad_shapes():
+    from structured_latent_odes_amd import _lib as L
+    lib = L.load()
+    lay = L.Layout()
+    assert lib.slode_layout_init(C.byref(_shape()), C.byref(lay)) == 0
+    # C1 has 96,462 parameters of which 2 x 126 belong to the auxiliary classifiers (not in the hot-path layout)
+    assert lay.n_params == 96462 - 252
+    assert lay.lin_w == 310 and lay.lin_b == 310 + 50 * 1870 and lay.ode_end == lay.n_params
+    assert lib.slode_num_stage_times(C.byref(_shape())) == 3 * 199 + 1
+    for bad in (dict(T=1), dict(C=5), dict(S=9), dict(L=65), dict(T=12), dict(method=7), dict(n_groups=5)):
+        assert lib.slode_layout_init(C.byref(_shape(**bad)), C.byref(lay)) == -1, bad
+        assert lib.slode_last_error(None)
+    s = _shape()
+    s.groups[1] = L.Group(2, 3, 1, 1)          # overlaps group 0
+    assert lib.slode_layout_init(C.byref(s), C.byref(lay)) == -1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device behaviour")
+def test_no_cpu_fallback():
+    from structured_latent_odes_amd import _lib as L, engine as E
+    lib = L.load()
+    h = C.c_void_p()
+    assert lib.slode_create(C.byref(h), 0) == -2          # SLODE_EHIP: no HIP device, and no CPU backend to fall back to
+    assert b"no CPU fallback" in lib.slode_last_error(None)
+    with pytest.raises(L.SlodeError):
+        E.Engine(E.cvs_spec(), 86)
+    from structured_latent_odes_amd.configs import load_config_cvs
+    from structured_latent_odes_amd.models.mechanistic_cvs import MechanisticModel
+    m = MechanisticModel(load_config_cvs(), torch.device("cpu"), torch.arange(0.0, 86.0))
+    with pytest.raises(L.SlodeError):
+        m.recon(observations=torch.zeros(2, 3, 86), iext=torch.zeros(2, 1), rtpr=torch.zeros(2, 1), is_post=True)
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from structured_latent_odes_amd import _lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(L.SlodeError):
+        L.load()
+
+
+def test_state_dict_keys_and_counts_match_the_reference(golden_dir):
+    from structured_latent_odes_amd.configs import load_config_challenge, load_config_cvs, load_config_proc
+    from structured_latent_odes_amd.models.mechanistic_challenge import MechanisticModel as MC
+    from structured_latent_odes_amd.models.mechanistic_cvs import MechanisticModel
+    from structured_latent_odes_amd.models.mechanistic_cvs_Gauss import MechanisticModelGauss
+    from structured_latent_odes_amd.models.mechanistic_proc import MechanisticModel as MP
+    m = MechanisticModel(load_config_cvs(), torch.device("cpu"), torch.arange(0.0, 86.0))
+    assert sum(p.numel() for p in m.parameters()) == 40300                   # SURVEY 8(a) hand count
+    sd = m.state_dict()
+    g3 = np.load(os.path.join(golden_dir, "g3_dynamics.npz"))
+    ref = sorted(k[len("d2.p."):] for k in g3.files if k.startswith("d2.p."))
+    assert sorted(k for k in sd if k.startswith("decoder.ode_model.")) == ref  # incl. the aliased prod.* / degr.* keys
+    assert sd["decoder.ode_model.dynamics.prod.0.weight"].data_ptr() == sd["decoder.ode_model.dynamics.dynamics_hidden.weight"].data_ptr()
+    g1 = np.load(os.path.join(golden_dir, "g1_encoder_conv.npz"))
+    assert sorted(k for k in sd if k.startswith("encoder.")) == sorted("encoder." + k[len("c0.p."):] for k in g1.files if k.startswith("c0.p."))
+    g2 = np.load(os.path.join(golden_dir, "g2_encoder_mlp.npz"))
+    assert sorted(k[len("q_iext_given_z_iext."):] for k in sd if k.startswith("q_iext_given_z_iext.")) == sorted(
+        k[len("sig.p."):] for k in g2.files if k.startswith("sig.p."))
+    assert sorted(k[len("p_z_iext_given_iext."):] for k in sd if k.startswith("p_z_iext_given_iext.")) == sorted(
+        k[len("prior1.p."):] for k in g2.files if k.startswith("prior1.p."))
+    g4 = np.load(os.path.join(golden_dir, "g4_decoders.npz"))
+    dec_ref = sorted(k[len("ald.p."):] for k in g4.files if k.startswith("ald.p.") and "ode_model" not in k)
+    assert sorted(k for k in sd if k.startswith("decoder.") and "ode_model" not in k) == dec_ref
+    mg = MechanisticModelGauss(load_config_cvs(), torch.device("cpu"), torch.arange(0.0, 86.0))
+    assert "decoder.output_mean.0.weight" in mg.state_dict()
+    mp = MP(load_config_proc(), torch.device("cpu"), torch.arange(0.0, 86.0))
+    assert {"constant_std_C_12", "constant_std_C_6", "q_C12_given_z_C12.sequential_mlp.3.0.0.weight"} <= set(mp.state_dict())
+    assert mp.latent_dim == 50 and mp.model_spec().n_u == 9
+    mc = MC(load_config_challenge(), torch.device("cpu"), torch.arange(0.0, 142.0))
+    assert mc.model_spec().prior_groups[0].z_dim == 10 and mc.labels_to_u(symptoms=torch.ones(2, 1), shedding=torch.zeros(2, 1)).tolist() == [[1.0, 0.0]] * 2
+    # load_state_dict round trip (best-model copy, training_cvs.py:330)
+    m2 = MechanisticModel(load_config_cvs(), torch.device("cpu"), torch.arange(0.0, 86.0))
+    m2.load_state_dict(m.state_dict())
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_synthetic_batches_have_the_reference_layouts():
+    from structured_latent_odes_amd.synthetic import synthetic_batch
+    obs, labels, times = synthetic_batch("cvs", 8, 200, 3)
+    assert obs.shape == (8, 3, 200) and obs.stride() == (600, 1, 3) and set(labels) == {"iext", "rtpr"}
+    assert float(obs.min()) >= 0 and float(obs.max()) <= 1 and times.shape == (200,)
+    obs, labels, times = synthetic_batch("proc", 4, 100, 4)
+    assert obs.is_contiguous() and labels["aR"].sum(1).tolist() == [1.0] * 4 and float((times[1:] - times[:-1]).min()) > 0.19
