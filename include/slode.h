@@ -30,6 +30,7 @@ extern "C" {
 
 #define SLODE_MAX_GROUPS 4
 #define SLODE_MAX_HEADS 3
+#define SLODE_MAX_AUX 4
 
 typedef enum slode_status {
   SLODE_OK = 0,
@@ -51,6 +52,17 @@ typedef struct slode_group {
   int32_t u_off, u_dim; /* label columns [u_off, u_off + u_dim) of u[B, n_u] */
 } slode_group;
 
+/* A label head q(label | z_g) scored INSIDE the main loss at `aux_mult` x (the proc family: q_label / q_continous on the
+ * replayed z, models/mechanistic_proc.py:145-146,334-353): EncoderMLP([z_dim, U, u_dim]) with one Softplus hidden layer.
+ *   SLODE_AUX_SIGMOID: Bernoulli(probs = sigmoid(.));  SLODE_AUX_SOFTMAX: OneHotCategorical(probs = softmax(.));
+ *   SLODE_AUX_EXPEXP:  two Exp heads [loc, unused], Laplace(loc, softplus(constant_std_*)) on the label. */
+typedef enum slode_aux_kind { SLODE_AUX_SIGMOID = 0, SLODE_AUX_SOFTMAX = 1, SLODE_AUX_EXPEXP = 2 } slode_aux_kind;
+typedef struct slode_aux {
+  int32_t kind;
+  int32_t z_off, z_dim; /* latent dims the head reads */
+  int32_t u_off, u_dim; /* label columns it scores   */
+} slode_aux;
+
 typedef struct slode_shape {
   int32_t B;  /* trajectories in this call (per GPU)                                   */
   int32_t T;  /* time points (len(times))                                              */
@@ -69,6 +81,10 @@ typedef struct slode_shape {
   int32_t likelihood; /* slode_likelihood                                              */
   float quantile_diff; /* config.quantile_diff (ALD only), data/cvs/config_cvs.py:48    */
   float rtol, atol;    /* dopri5 only (torchdiffeq defaults 1e-7 / 1e-9)                */
+  int32_t n_aux;       /* label heads scored inside the main loss (0 for cvs / challenge)  */
+  int32_t U;           /* config.u_hidden_dim (<= 32)                                      */
+  float aux_mult;      /* config.aux_loss_multiplier                                       */
+  slode_aux aux[SLODE_MAX_AUX];
 } slode_shape;
 
 /* Offsets (in floats) of each parameter tensor inside the flat parameter / gradient vector.
@@ -87,6 +103,10 @@ typedef struct slode_layout {
   int32_t dyn_wg, dyn_bg;   /* ...dynamics.dyanamics_growth.{weight[S,H], bias[S]}                   */
   int32_t dyn_wd, dyn_bd;   /* ...dynamics.dyanmics_degradation.{weight[S,H], bias[S]}               */
   int32_t head_w[SLODE_MAX_HEADS]; /* decoder.output_{q50,q75,q25}.0.weight[C,S] | output_mean (Gauss) */
+  /* label heads of the main loss: <head>.sequential_mlp.1.module.{weight[U,z_dim],bias[U]}, .3.{weight[u_dim,U],bias}
+   * (EXPEXP: .3.0.0.* then .3.1.0.*), and for EXPEXP the scalar constant_std_C_* */
+  int32_t aux_w1[SLODE_MAX_AUX], aux_b1[SLODE_MAX_AUX], aux_w2[SLODE_MAX_AUX], aux_b2[SLODE_MAX_AUX];
+  int32_t aux_w3[SLODE_MAX_AUX], aux_b3[SLODE_MAX_AUX], aux_c[SLODE_MAX_AUX];
   int32_t cstd;             /* decoder.constant_std[C,T]                                             */
   int32_t ode_end;          /* end of that segment                                                   */
   int32_t n_params;         /* total floats covered by this layout; callers may append their own      */

@@ -6,7 +6,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SLODE_LIB_PATH") or os.path.join(_HERE, "libslode.so")  # env override: diagnostics only
 
-MAX_GROUPS, MAX_HEADS = 4, 3
+MAX_GROUPS, MAX_HEADS, MAX_AUX = 4, 3, 4
+AUX_KINDS = {"sigmoid": 0, "softmax": 1, "expexp": 2}
 EULER, MIDPOINT, RK4, DOPRI5 = 0, 1, 2, 3
 ALD, GAUSS = 0, 1
 METHODS = {"euler": EULER, "midpoint": MIDPOINT, "rk4": RK4, "dopri5": DOPRI5}
@@ -16,10 +17,15 @@ class Group(C.Structure):
     _fields_ = [("z_off", C.c_int32), ("z_dim", C.c_int32), ("u_off", C.c_int32), ("u_dim", C.c_int32)]
 
 
+class Aux(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "z_off", "z_dim", "u_off", "u_dim")]
+
+
 class Shape(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "T", "C", "L", "S", "H", "F", "K", "P", "Hc", "n_u", "n_groups")] + [
         ("groups", Group * MAX_GROUPS), ("method", C.c_int32), ("likelihood", C.c_int32),
-        ("quantile_diff", C.c_float), ("rtol", C.c_float), ("atol", C.c_float)]
+        ("quantile_diff", C.c_float), ("rtol", C.c_float), ("atol", C.c_float), ("n_aux", C.c_int32), ("U", C.c_int32),
+        ("aux_mult", C.c_float), ("aux", Aux * MAX_AUX)]
 
 
 class Layout(C.Structure):
@@ -29,7 +35,8 @@ class Layout(C.Structure):
         ("pls_w", C.c_int32 * MAX_GROUPS), ("pls_b", C.c_int32 * MAX_GROUPS)] + [
         (n, C.c_int32) for n in ("init_w1", "init_b1", "init_w2", "init_b2", "dyn_wh", "dyn_bh", "dyn_wg", "dyn_bg",
                                  "dyn_wd", "dyn_bd")] + [
-        ("head_w", C.c_int32 * MAX_HEADS), ("cstd", C.c_int32), ("ode_end", C.c_int32), ("n_params", C.c_int32)]
+        ("head_w", C.c_int32 * MAX_HEADS)] + [(n, C.c_int32 * MAX_AUX) for n in ("aux_w1", "aux_b1", "aux_w2", "aux_b2", "aux_w3", "aux_b3", "aux_c")] + [
+        ("cstd", C.c_int32), ("ode_end", C.c_int32), ("n_params", C.c_int32)]
 
 
 EXPORTS = ["slode_version", "slode_create", "slode_destroy", "slode_last_error", "slode_layout_init",

@@ -47,6 +47,10 @@ struct OdeK {
   int o_ploc_w[SLODE_MAX_GROUPS], o_ploc_b[SLODE_MAX_GROUPS], o_pls_w[SLODE_MAX_GROUPS], o_pls_b[SLODE_MAX_GROUPS];
   int o_w1, o_b1, o_w2, o_b2, o_wh, o_bh, o_wg, o_bg, o_wd, o_bd, o_head[SLODE_MAX_HEADS], o_cstd;
   int nseg;
+  int n_aux, U;        // label heads scored inside the main loss (proc family)
+  float aux_mult;
+  slode_aux aux[SLODE_MAX_AUX];
+  int o_aux_w1[SLODE_MAX_AUX], o_aux_b1[SLODE_MAX_AUX], o_aux_w2[SLODE_MAX_AUX], o_aux_b2[SLODE_MAX_AUX], o_aux_c[SLODE_MAX_AUX];
   int npar;            // floats of the segment staged in LDS: [ode_begin, cstd) = priors | init net | dynamics | heads
   const float* pseg;   // params + ode_begin
   const float *times, *stage_t, *obs, *u, *eps, *loc, *scale, *z_in, *gx_in;
@@ -56,7 +60,7 @@ struct OdeK {
 };
 
 struct LdsMap {  // offsets in floats
-  int ts, dt, sig, A, x, lam, st, acc, par, uu, z, gzl, gpl, gls, u, wt, pre0, hid0, x0, go, gp0, gu, gup, red, total;
+  int ts, dt, sig, A, x, lam, st, acc, par, uu, auxh, auxd, auxgo, z, gzl, gpl, gls, u, wt, pre0, hid0, x0, go, gp0, gu, gup, red, total;
 };
 
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
@@ -78,6 +82,9 @@ __host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int
   m.acc = o; o += pad4(npar + 1);  // [loss | priors | init net | dynamics | heads]; constant_std goes straight to the slab
   m.par = o; o += pad4(npar);
   m.uu = o; o += SLODE_MAX_NU;
+  m.auxh = o; o += SLODE_MAX_AUX * 32;
+  m.auxd = o; o += SLODE_MAX_AUX * 32;
+  m.auxgo = o; o += SLODE_MAX_AUX * 12;
   m.z = o; o += pad4(L);
   m.gzl = o; o += pad4(L);
   m.gpl = o; o += pad4(2 * L);  // [d(-log p)/d prior loc | eps]
@@ -261,6 +268,9 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
   float* s_acc = smem + m.acc;
   float* s_par = smem + m.par;  // small weights, staged once per workgroup (cold phases read LDS, not HBM/L2)
   float* s_uu = smem + m.uu;  // this trajectory's label row u[b, :]
+  float* s_auxh = smem + m.auxh;    // label heads: hidden activations [head][32]
+  float* s_auxd = smem + m.auxd;    //              softplus' then dLoss/d(hidden pre-activation)
+  float* s_auxgo = smem + m.auxgo;  //              dLoss/d(output logits) [head][12] (slot 8: d/d constant_std_*)
   float* s_z = smem + m.z;
   float* s_gzl = smem + m.gzl;
   float* s_gpl = smem + m.gpl;
@@ -402,6 +412,16 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
     } else if (tid < 32) {
       s_u[tid] = 0.f;
     }
+    if (k.n_aux > 0 && tid < k.n_aux * 32) {  // label heads of the main loss: hidden layer (Softplus), thread (head, j)
+      const int hd = tid >> 5, j = tid & 31;
+      if (j < k.U) {
+        const slode_aux ax = k.aux[hd];
+        float pre = s_par[k.o_aux_b1[hd] + j];
+        for (int l = 0; l < ax.z_dim; ++l) pre = fmaf(s_par[k.o_aux_w1[hd] + j * ax.z_dim + l], s_z[ax.z_off + l], pre);
+        s_auxh[hd * 32 + j] = softplusf(pre);
+        s_auxd[hd * 32 + j] = 1.f / (1.f + expf(-pre));
+      }
+    }
     __syncthreads();
     // ---- P0c: x0 = sigmoid(W2 relu(.) + b2)  (blackbox_ode.py:19-22) ------------------------------------
     if (tid < S) {
@@ -412,6 +432,53 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
       const float x0 = sigmoidf_fast(o);
       s_x0[tid] = x0;
       s_x[tid] = x0;
+    }
+    if (k.n_aux > 0 && tid >= 64 && tid < 64 + k.n_aux) {
+      // q(label | z_g) on the replayed z at aux_mult x (mechanistic_proc.py:145-146,334-353); one thread per head
+      const int hd = tid - 64;
+      const slode_aux ax = k.aux[hd];
+      const float* w2 = s_par + k.o_aux_w2[hd];
+      const float* b2 = s_par + k.o_aux_b2[hd];
+      const float* hv = s_auxh + hd * 32;
+      auto logit = [&](int q) {
+        float o = b2[q];
+        for (int j = 0; j < k.U; ++j) o = fmaf(w2[q * k.U + j], hv[j], o);
+        return o;
+      };
+      float lp = 0.f;
+      if (ax.kind == SLODE_AUX_SOFTMAX) {
+        float mx = -3.0e38f, ysum = 0.f;
+        for (int q = 0; q < ax.u_dim; ++q) mx = fmaxf(mx, logit(q));
+        float se = 0.f;
+        for (int q = 0; q < ax.u_dim; ++q) { se += expf(logit(q) - mx); ysum += s_uu[ax.u_off + q]; }
+        const float lse = mx + logf(se);
+        for (int q = 0; q < ax.u_dim; ++q) {
+          const float lq = logit(q) - lse, y = s_uu[ax.u_off + q];
+          lp = fmaf(y, lq, lp);
+          s_auxgo[hd * 12 + q] = k.aux_mult * (expf(lq) * ysum - y);
+        }
+      } else if (ax.kind == SLODE_AUX_SIGMOID) {
+        for (int q = 0; q < ax.u_dim; ++q) {
+          const float o = logit(q), y = s_uu[ax.u_off + q];
+          const float sp_pos = (o > 0.f ? o : 0.f) + log1pf(expf(-fabsf(o)));  // softplus(o), stable
+          lp += y * (o - sp_pos) + (1.f - y) * (-sp_pos);
+          s_auxgo[hd * 12 + q] = k.aux_mult * (1.f / (1.f + expf(-o)) - y);
+        }
+      } else {  // EXPEXP: Laplace(loc = exp(head 0), b = softplus(constant_std_*)); the second Exp head is unused
+        const float c = s_par[k.o_aux_c[hd]];
+        const float bsc = softplusf(c), ib = 1.f / bsc;
+        float gc = 0.f;
+        for (int q = 0; q < ax.u_dim; ++q) {
+          const float loc = expf(logit(q)), y = s_uu[ax.u_off + q];
+          const float r = y - loc, ar = fabsf(r);
+          lp += -logf(2.f * bsc) - ar * ib;
+          const float sg = (r > 0.f) ? 1.f : ((r < 0.f) ? -1.f : 0.f);
+          s_auxgo[hd * 12 + q] = -k.aux_mult * sg * ib * loc;
+          gc += k.aux_mult * (ib - ar * ib * ib);
+        }
+        s_auxgo[hd * 12 + 8] = gc / (1.f + expf(-c));
+      }
+      loss_acc -= k.aux_mult * lp;
     }
 
     STAMP(2);
@@ -667,6 +734,15 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
         for (int c2 = 0; c2 < nchunk; ++c2) g += s_gup[c2 * 32 + tid];
         s_gu[tid] = g;  // dLoss/du_j for this trajectory
       }
+      if (k.n_aux > 0 && tid < k.n_aux * 32) {  // label heads: back through the output layer and the Softplus
+        const int hd = tid >> 5, j = tid & 31;
+        if (j < k.U) {
+          const slode_aux ax = k.aux[hd];
+          float gh = 0.f;
+          for (int q = 0; q < ax.u_dim; ++q) gh = fmaf(s_par[k.o_aux_w2[hd] + q * k.U + j], s_auxgo[hd * 12 + q], gh);
+          s_auxd[hd * 32 + j] *= gh;
+        }
+      }
       if (tid >= 64 && tid < 64 + S) {  // (NT >= 128 is guaranteed when BWD; see launcher)
         const int s = tid - 64;
         const float x0 = s_x0[s];
@@ -690,6 +766,11 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
           gz = fmaf(s_par[k.o_wh + j * (1 + L) + 1 + l], s_gu[j], gz);
           gz = fmaf(s_par[k.o_w1 + j * L + l], s_gp0[j], gz);
         }
+        for (int hd = 0; hd < k.n_aux; ++hd) {
+          const slode_aux ax = k.aux[hd];
+          if (l >= ax.z_off && l < ax.z_off + ax.z_dim)
+            for (int j = 0; j < k.U; ++j) gz = fmaf(s_par[k.o_aux_w1[hd] + j * ax.z_dim + (l - ax.z_off)], s_auxd[hd * 32 + j], gz);
+        }
         if (k.loc != nullptr) {
           k.g_loc[(long long)b * L + l] = gz;
           k.g_scale[(long long)b * L + l] = fmaf(gz, s_gpl[L + l], -1.0f / s_gls[L + l]);
@@ -710,6 +791,20 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
       }
       if (tid < H) { acc[k.o_bh + tid] += s_gu[tid]; acc[k.o_b1 + tid] += s_gp0[tid]; }
       if (tid < S) acc[k.o_b2 + tid] += s_go[tid];
+      for (int hd = 0; hd < k.n_aux; ++hd) {
+        const slode_aux ax = k.aux[hd];
+        for (int e = tid; e < k.U * ax.z_dim; e += NT) {
+          const int j = e / ax.z_dim, l = e - j * ax.z_dim;
+          acc[k.o_aux_w1[hd] + e] += s_auxd[hd * 32 + j] * s_z[ax.z_off + l];
+        }
+        for (int e = tid; e < ax.u_dim * k.U; e += NT) {
+          const int q = e / k.U, j = e - q * k.U;
+          acc[k.o_aux_w2[hd] + e] += s_auxgo[hd * 12 + q] * s_auxh[hd * 32 + j];
+        }
+        if (tid < k.U) acc[k.o_aux_b1[hd] + tid] += s_auxd[hd * 32 + tid];
+        if (tid < ax.u_dim) acc[k.o_aux_b2[hd] + tid] += s_auxgo[hd * 12 + tid];
+        if (tid == 0 && ax.kind == SLODE_AUX_EXPEXP) acc[k.o_aux_c[hd]] += s_auxgo[hd * 12 + 8];
+      }
       if (k.loc != nullptr) {
         for (int g = 0; g < k.ng; ++g) {
           const slode_group gr = k.grp[g];
@@ -858,6 +953,12 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   k.o_wd = lay.dyn_wd - ob; k.o_bd = lay.dyn_bd - ob; k.o_cstd = lay.cstd - ob;
   k.nseg = lay.ode_end - lay.ode_begin;
   k.npar = lay.cstd - lay.ode_begin;
+  k.n_aux = a.with_ll ? s.n_aux : 0; k.U = s.U; k.aux_mult = s.aux_mult;
+  for (int q = 0; q < SLODE_MAX_AUX; ++q) {
+    k.aux[q] = s.aux[q];
+    k.o_aux_w1[q] = lay.aux_w1[q] - ob; k.o_aux_b1[q] = lay.aux_b1[q] - ob; k.o_aux_w2[q] = lay.aux_w2[q] - ob;
+    k.o_aux_b2[q] = lay.aux_b2[q] - ob; k.o_aux_c[q] = lay.aux_c[q] - ob;
+  }
   k.pseg = p + lay.ode_begin;
   k.times = a.times; k.stage_t = a.stage_t; k.obs = a.obs; k.u = a.u; k.eps = a.eps; k.loc = a.loc; k.scale = a.scale;
   k.z_in = a.z_in; k.gx_in = a.gx_in; k.sb = a.sb; k.sc = a.sc; k.st = a.st;

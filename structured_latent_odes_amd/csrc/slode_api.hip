@@ -52,6 +52,14 @@ static const char* check_shape(const slode_shape* s) {
   if (s->method != SLODE_EULER && s->method != SLODE_MIDPOINT && s->method != SLODE_RK4)
     return "method must be euler, midpoint or rk4 for the fixed-grid kernels";
   if (s->likelihood != SLODE_ALD && s->likelihood != SLODE_GAUSS) return "likelihood must be ALD or GAUSS";
+  if (s->n_aux < 0 || s->n_aux > SLODE_MAX_AUX) return "n_aux out of range [0, 4]";
+  if (s->n_aux > 0 && (s->U < 1 || s->U > 32)) return "U (u_hidden_dim) out of range [1, 32]";
+  for (int a = 0; a < s->n_aux; ++a) {
+    const slode_aux& x = s->aux[a];
+    if (x.kind < SLODE_AUX_SIGMOID || x.kind > SLODE_AUX_EXPEXP) return "unknown aux head kind";
+    if (x.z_off < 0 || x.z_dim < 1 || x.z_off + x.z_dim > s->L) return "aux head latent range outside [0, L)";
+    if (x.u_off < 0 || x.u_dim < 1 || x.u_dim > 8 || x.u_off + x.u_dim > s->n_u) return "aux head label range outside [0, n_u) or wider than 8";
+  }
   return nullptr;
 }
 
@@ -127,6 +135,18 @@ int slode_layout_init(const slode_shape* s, slode_layout* lay) {
   for (int q = 0; q < SLODE_MAX_HEADS; ++q) {
     lay->head_w[q] = o;
     if (q < Q) o += s->C * s->S;
+  }
+  for (int a = 0; a < s->n_aux; ++a) {
+    const slode_aux& x = s->aux[a];
+    lay->aux_w1[a] = o; o += s->U * x.z_dim;
+    lay->aux_b1[a] = o; o += s->U;
+    lay->aux_w2[a] = o; o += x.u_dim * s->U;
+    lay->aux_b2[a] = o; o += x.u_dim;
+    if (x.kind == SLODE_AUX_EXPEXP) {
+      lay->aux_w3[a] = o; o += x.u_dim * s->U;
+      lay->aux_b3[a] = o; o += x.u_dim;
+      lay->aux_c[a] = o; o += 1;
+    }
   }
   lay->cstd = o; o += s->C * s->T;
   lay->ode_end = o;

@@ -23,6 +23,19 @@ class PriorGroup:
 
 
 @dataclass
+class AuxHead:
+    """A label head scored inside the MAIN loss (proc family): `prefix` = reference attribute (e.g. 'q_aR_given_z_aR'),
+    kind in sigmoid | softmax | expexp; `std_key` = the scalar std parameter of an expexp (Laplace) head."""
+    prefix: str
+    kind: str
+    z_off: int
+    z_dim: int
+    u_off: int
+    u_dim: int
+    std_key: str = ""
+
+
+@dataclass
 class ModelSpec:
     """Shape of one of the reference's three model families (models/mechanistic_{cvs,proc,challenge}[_Gauss].py)."""
     name: str
@@ -40,6 +53,9 @@ class ModelSpec:
     cnn_hidden_dim: int = 50
     solver: str = "midpoint"
     quantile_diff: float = 0.475
+    aux_in_main: List[AuxHead] = field(default_factory=list)
+    u_hidden_dim: int = 25
+    aux_mult: float = 46.0
 
     @property
     def head_names(self) -> List[str]:
@@ -88,7 +104,10 @@ class Engine:
             s = L.Shape(B=B, T=self.T, C=sp.n_channels, L=sp.latent_dim, S=sp.ode_state_dim, H=sp.ode_hidden_dim,
                         F=sp.n_filters, K=sp.filter_size, P=sp.pool_size, Hc=sp.cnn_hidden_dim, n_u=sp.n_u,
                         n_groups=len(sp.prior_groups), method=L.METHODS[sp.solver],
-                        likelihood=L.GAUSS if sp.gauss else L.ALD, quantile_diff=sp.quantile_diff, rtol=1e-7, atol=1e-9)
+                        likelihood=L.GAUSS if sp.gauss else L.ALD, quantile_diff=sp.quantile_diff, rtol=1e-7, atol=1e-9,
+                        n_aux=len(sp.aux_in_main), U=sp.u_hidden_dim, aux_mult=sp.aux_mult)
+            for i, a in enumerate(sp.aux_in_main):
+                s.aux[i] = L.Aux(L.AUX_KINDS[a.kind], a.z_off, a.z_dim, a.u_off, a.u_dim)
             for i, g in enumerate(sp.prior_groups):
                 s.groups[i] = L.Group(g.z_off, g.z_dim, g.u_off, g.u_dim)
             self._shapes[B] = s
@@ -116,6 +135,16 @@ class Engine:
               (o + "dynamics.dyanmics_degradation.weight", lay.dyn_wd, (S, H)), (o + "dynamics.dyanmics_degradation.bias", lay.dyn_bd, (S,))]
         for i, hn in enumerate(sp.head_names):
             t.append(("decoder.%s.0.weight" % hn, lay.head_w[i], (C_, S)))
+        U = sp.u_hidden_dim
+        for i, a in enumerate(sp.aux_in_main):
+            t += [(a.prefix + ".sequential_mlp.1.module.weight", lay.aux_w1[i], (U, a.z_dim)),
+                  (a.prefix + ".sequential_mlp.1.module.bias", lay.aux_b1[i], (U,))]
+            if a.kind == "expexp":
+                t += [(a.prefix + ".sequential_mlp.3.0.0.weight", lay.aux_w2[i], (a.u_dim, U)), (a.prefix + ".sequential_mlp.3.0.0.bias", lay.aux_b2[i], (a.u_dim,)),
+                      (a.prefix + ".sequential_mlp.3.1.0.weight", lay.aux_w3[i], (a.u_dim, U)), (a.prefix + ".sequential_mlp.3.1.0.bias", lay.aux_b3[i], (a.u_dim,)),
+                      (a.std_key, lay.aux_c[i], (1,))]
+            else:
+                t += [(a.prefix + ".sequential_mlp.3.weight", lay.aux_w2[i], (a.u_dim, U)), (a.prefix + ".sequential_mlp.3.bias", lay.aux_b2[i], (a.u_dim,))]
         t.append(("decoder.constant_std", lay.cstd, (C_, T)))
         return t
 
@@ -280,5 +309,8 @@ def challenge_spec(z_shed=5, z_symp=5, z_eps=5, gauss=False, solver="midpoint", 
 
 def proc_spec(z_g=10, z_eps=10, gauss=False, solver="midpoint", quantile_diff=0.475) -> ModelSpec:
     """data/proc/config_proc.py; u = cat(aR[3], aS[4], C12, C6) (models/mechanistic_proc.py:196-198)."""
+    aux = [AuxHead("q_aR_given_z_aR", "softmax", 0, z_g, 0, 3), AuxHead("q_aS_given_z_aS", "softmax", z_g, z_g, 3, 4),
+           AuxHead("q_C12_given_z_C12", "expexp", 2 * z_g, z_g, 7, 1, "constant_std_C_12"),
+           AuxHead("q_C6_given_z_C6", "expexp", 3 * z_g, z_g, 8, 1, "constant_std_C_6")]
     return ModelSpec("proc", gauss, 4, 4 * z_g + z_eps, z_eps, 9, [PriorGroup("p_z_u_given_u", 0, 4 * z_g, 0, 9)],
-                     ode_state_dim=8, solver=solver, quantile_diff=quantile_diff)
+                     ode_state_dim=8, solver=solver, quantile_diff=quantile_diff, aux_in_main=aux)

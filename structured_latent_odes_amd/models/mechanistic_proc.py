@@ -1,9 +1,9 @@
 """models/mechanistic_proc.py of the reference (kwargs ``observations, aR, aS, C12, C6``; prior input cat(aR, aS, C12, C6),
 mechanistic_proc.py:196-198; latent layout [z_aR, z_aS, z_C12, z_C6, z_epsilon], :282-311).
 
-The proc MAIN loss additionally scores the labels on the replayed z at 46x (mechanistic_proc.py:145-146); that term is not
-in the fused kernel yet, so ``SVI(model, guide).step`` raises for this family.  Construction,
-``state_dict`` compatibility, ``recon`` and ``pred_inputs`` work."""
+The proc MAIN loss additionally scores the labels on the replayed z at 46x (mechanistic_proc.py:145-146,334-353); those
+four heads (two softmax/OneHotCategorical, two Exp/Laplace) are evaluated and differentiated inside ``ode_elbo_kernel``
+(phases P0/P7), so their parameters live in the kernel's layout for this family."""
 from ._mechanistic import MechanisticBase
 
 

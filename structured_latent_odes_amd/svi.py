@@ -172,10 +172,7 @@ class SVI:
         binding = owner._bind()
         flat_opt = optim.for_binding(binding) if optim is not None else None
         if self.kind == "main":
-            if getattr(owner, "LABELS_IN_MAIN", False):
-                self._impl = None
-            else:
-                self._impl = ELBOStep(binding.engine, binding.flat, flat_opt)
+            self._impl = ELBOStep(binding.engine, binding.flat, flat_opt)
         else:
             self._impl = AuxStep(owner, flat_opt)
 
@@ -187,9 +184,6 @@ class SVI:
 
     def _main_args(self, obs, eps, labels):
         o = self.owner
-        if self._impl is None:
-            raise NotImplementedError("the %s main loss scores the labels inside the model (mechanistic_proc.py:145-146); "
-                                      "not in the fused kernel yet" % o.FAMILY)
         if eps is None:
             eps = o.draw_eps(obs.shape[0], obs.device)
         return obs, eps, o.labels_to_u(**labels)

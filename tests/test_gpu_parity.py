@@ -20,15 +20,18 @@ CASES = {
     "cvs_gauss_euler": ("cvs", dict(gauss=True, solver="euler"), 16, 86),
     "challenge_c4_rk4_gauss": ("challenge", dict(gauss=True, solver="rk4"), 12, 300),       # BASELINE config[4] shapes
     "challenge_ald_midpoint": ("challenge", dict(solver="midpoint"), 9, 142),
+    "proc_c2_rk4": ("proc", dict(z_g=10, z_eps=10, solver="rk4"), 16, 100),                 # BASELINE config[2] shapes (fixed grid)
+    "proc_gauss_midpoint": ("proc", dict(z_g=3, z_eps=2, gauss=True, solver="midpoint"), 7, 86),
 }
 
 
 def _mk(case):
     from structured_latent_odes_amd import engine as E
     fam, kw, B, T = CASES[case]
-    ospec = {"cvs": O.cvs_spec, "challenge": O.challenge_spec}[fam](**kw)
-    espec = {"cvs": E.cvs_spec, "challenge": E.challenge_spec}[fam](**kw)
-    p = O.init_params(ospec, T=T)
+    ospec = {"cvs": O.cvs_spec, "challenge": O.challenge_spec, "proc": O.proc_spec}[fam](**kw)
+    espec = {"cvs": E.cvs_spec, "challenge": E.challenge_spec, "proc": E.proc_spec}[fam](**kw)
+    S = 8 if fam == "proc" else 5
+    p = O.init_params(ospec, T=T, S=S)
     g = torch.Generator().manual_seed(11)
     # move off the near-zero initialisation so every gradient path is exercised; keep std params positive-ish
     p = {k: v + 0.05 * torch.randn(v.shape, generator=g) for k, v in p.items()}
@@ -39,7 +42,7 @@ def _mk(case):
     flat = eng.pack(p)
     obs_d = obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)   # [B,C,T] view of contiguous [B,T,C]
     return dict(ospec=ospec, p=p, obs=obs, u=u, eps=eps, times=times, eng=eng, flat=flat, obs_d=obs_d,
-                u_d=u.to(dev).contiguous(), eps_d=eps.to(dev).contiguous(), dev=dev, B=B, T=T)
+                u_d=u.to(dev).contiguous(), eps_d=eps.to(dev).contiguous(), dev=dev, B=B, T=T, S=S)
 
 
 @pytest.fixture(scope="module", params=list(CASES))
@@ -91,7 +94,7 @@ def test_ode_solve_forward(ctx):
 
 def test_decode_heads(ctx):
     g = torch.Generator().manual_seed(4)
-    x = torch.rand(ctx["B"], ctx["T"], 5, generator=g)
+    x = torch.rand(ctx["B"], ctx["T"], ctx["S"], generator=g)
     mu, std = ctx["eng"].decode_heads(ctx["flat"], x.to(ctx["dev"]))
     import torch.nn.functional as F
     names = ["decoder.output_mean.0.weight"] if ctx["ospec"].gauss else ["decoder.output_%s.0.weight" % q for q in ("q50", "q75", "q25")]
@@ -103,7 +106,7 @@ def test_decode_heads(ctx):
 def test_elbo_loss_and_trajectories(ctx):
     eng, dev = ctx["eng"], ctx["dev"]
     loss = torch.zeros(1, device=dev)
-    x = torch.empty(ctx["B"], ctx["T"], 5, device=dev)
+    x = torch.empty(ctx["B"], ctx["T"], ctx["S"], device=dev)
     z = torch.empty(ctx["B"], ctx["ospec"].latent_dim, device=dev)
     eng.elbo_step(ctx["flat"], ctx["obs_d"], ctx["u_d"], ctx["eps_d"], loss, grads=None, x_out=x, z_out=z)
     with torch.no_grad():
@@ -166,7 +169,7 @@ def test_ode_solve_backward_standalone(ctx):
     eng, dev, B, T = ctx["eng"], ctx["dev"], ctx["B"], ctx["T"]
     g = torch.Generator().manual_seed(9)
     z = torch.randn(B, ctx["ospec"].latent_dim, generator=g)
-    gx = torch.randn(B, T, 5, generator=g)
+    gx = torch.randn(B, T, ctx["S"], generator=g)
     grads = torch.zeros(eng.n_params, device=dev)
     gz = eng.ode_solve_bwd(ctx["flat"], z.to(dev), gx.to(dev), grads)
     q = {k: v.double().requires_grad_("ode_model" in k) for k, v in ctx["p"].items()}
