@@ -9,6 +9,7 @@ __global__ void stage_times_kernel(const float* __restrict__ times, float* __res
   const int R = method == SLODE_EULER ? 1 : (method == SLODE_MIDPOINT ? 2 : 3);
   const int nt = R * (T - 1) + 1;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (method == SLODE_DOPRI5) { if (i == 0) out[0] = times[T - 1]; return; }
   if (i >= nt) return;
   if (i == nt - 1) { out[i] = times[T - 1]; return; }
   const int n = i / R, r = i - n * R;

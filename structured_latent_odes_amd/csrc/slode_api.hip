@@ -49,8 +49,7 @@ static const char* check_shape(const slode_shape* s) {
       if (gr.z_off < o.z_off + o.z_dim && o.z_off < gr.z_off + gr.z_dim) return "prior groups overlap";
     }
   }
-  if (s->method != SLODE_EULER && s->method != SLODE_MIDPOINT && s->method != SLODE_RK4)
-    return "method must be euler, midpoint or rk4 for the fixed-grid kernels";
+  if (s->method < SLODE_EULER || s->method > SLODE_DOPRI5) return "unknown method";
   if (s->likelihood != SLODE_ALD && s->likelihood != SLODE_GAUSS) return "likelihood must be ALD or GAUSS";
   if (s->n_aux < 0 || s->n_aux > SLODE_MAX_AUX) return "n_aux out of range [0, 4]";
   if (s->n_aux > 0 && (s->U < 1 || s->U > 32)) return "U (u_hidden_dim) out of range [1, 32]";
@@ -156,6 +155,7 @@ int slode_layout_init(const slode_shape* s, slode_layout* lay) {
 
 int slode_num_stage_times(const slode_shape* s) {
   if (!s || s->T < 2) return SLODE_EINVAL;
+  if (s->method == SLODE_DOPRI5) return 1;  // adaptive: no table (a 1-element dummy keeps callers uniform)
   return stages_per_step(s->method) * (s->T - 1) + 1;
 }
 
@@ -276,7 +276,14 @@ int slode_ode_solve_fwd(slode_handle h, const slode_shape* s, const slode_layout
                         const float* times, const float* stage_t, const float* z, float* x, void* stream) {
   const char* why = check_common(h, s, lay, params);
   if (why) return fail(h, SLODE_EINVAL, "%s", why);
-  if (!times || !stage_t || !z || !x) return fail(h, SLODE_EINVAL, "times / stage_t / z / x is NULL");
+  if (!times || !z || !x) return fail(h, SLODE_EINVAL, "times / z / x is NULL");
+  if (s->method == SLODE_DOPRI5) {  // adaptive solve: per-trajectory controller, no stage-time table
+    hipError_t e5 = slode_launch_dopri5(*s, *lay, params, times, z, x, (hipStream_t)stream);
+    if (e5 == hipErrorInvalidValue) return fail(h, SLODE_EINVAL, "dopri5 kernel is instantiated for (S,H) in {(5,25),(8,25)}");
+    HIP_TRY(h, e5);
+    return SLODE_OK;
+  }
+  if (!stage_t) return fail(h, SLODE_EINVAL, "stage_t is NULL");
   // forward-only solve needs one loss slot per workgroup; borrow the head of x? no: use a tiny static scratch in x's tail
   // is not possible => the kernel writes its (zero) loss partial into slabs; give it the first floats of a scratch we own.
   static thread_local float* scratch = nullptr;
@@ -302,6 +309,7 @@ int slode_ode_solve_bwd(slode_handle h, const slode_shape* s, const slode_layout
   const char* why = check_common(h, s, lay, params);
   if (why) return fail(h, SLODE_EINVAL, "%s", why);
   if (!times || !stage_t || !z || !g_x || !g_z || !grads || !workspace) return fail(h, SLODE_EINVAL, "a required pointer is NULL");
+  if (s->method == SLODE_DOPRI5) return fail(h, SLODE_EINVAL, "dopri5 is forward-only (slode_ode_solve_fwd); gradients need a fixed-grid method");
   Workspace w = carve(h, *s, *lay, workspace);
   if (workspace_bytes < w.bytes) return fail(h, SLODE_ENOSPC, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
   OdeLaunch a{};
@@ -333,6 +341,7 @@ int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* la
   if (!times || !stage_t || !obs || !obs_strides || !eps || !loss_out || !workspace)
     return fail(h, SLODE_EINVAL, "a required pointer is NULL");
   if (s->n_groups > 0 && !u) return fail(h, SLODE_EINVAL, "u is NULL but the shape has conditional prior groups");
+  if (s->method == SLODE_DOPRI5) return fail(h, SLODE_EINVAL, "dopri5 is forward-only (slode_ode_solve_fwd); the ELBO step needs a fixed-grid method");
   Workspace w = carve(h, *s, *lay, workspace);
   if (workspace_bytes < w.bytes) return fail(h, SLODE_ENOSPC, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
   hipStream_t st = (hipStream_t)stream;

@@ -140,5 +140,7 @@ hipError_t slode_launch_decode_heads(const slode_shape& s, const slode_layout& l
                                      const float* x, float* mu, float* std_ct, hipStream_t stream);
 hipError_t slode_launch_dynamics_eval(const slode_shape& s, const slode_layout& lay, const float* params, float t,
                                       const float* state, const float* z, float* out, hipStream_t stream);
+hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const float* z,
+                               float* x, hipStream_t stream);
 hipError_t slode_launch_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2,
                              float eps, int64_t step, hipStream_t stream);

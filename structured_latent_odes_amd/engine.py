@@ -56,6 +56,8 @@ class ModelSpec:
     aux_in_main: List[AuxHead] = field(default_factory=list)
     u_hidden_dim: int = 25
     aux_mult: float = 46.0
+    rtol: float = 1e-7      # dopri5 only (torchdiffeq defaults)
+    atol: float = 1e-9
 
     @property
     def head_names(self) -> List[str]:
@@ -104,7 +106,7 @@ class Engine:
             s = L.Shape(B=B, T=self.T, C=sp.n_channels, L=sp.latent_dim, S=sp.ode_state_dim, H=sp.ode_hidden_dim,
                         F=sp.n_filters, K=sp.filter_size, P=sp.pool_size, Hc=sp.cnn_hidden_dim, n_u=sp.n_u,
                         n_groups=len(sp.prior_groups), method=L.METHODS[sp.solver],
-                        likelihood=L.GAUSS if sp.gauss else L.ALD, quantile_diff=sp.quantile_diff, rtol=1e-7, atol=1e-9,
+                        likelihood=L.GAUSS if sp.gauss else L.ALD, quantile_diff=sp.quantile_diff, rtol=sp.rtol, atol=sp.atol,
                         n_aux=len(sp.aux_in_main), U=sp.u_hidden_dim, aux_mult=sp.aux_mult)
             for i, a in enumerate(sp.aux_in_main):
                 s.aux[i] = L.Aux(L.AUX_KINDS[a.kind], a.z_off, a.z_dim, a.u_off, a.u_dim)
