@@ -267,7 +267,7 @@ def odeint_dopri5(f, y0: Tensor, times: Tensor, rtol: float = 1e-7, atol: float 
             # step-size update (only for controllers that took part)
             safe = torch.where(ratio == 0, torch.full_like(ratio, 10.0),
                                0.9 * ratio.clamp_min(1e-300) ** (-1.0 / 5.0))
-            factor = torch.where(ratio <= 1, safe.clamp(1.0, 10.0), safe.clamp(0.2, 1.0))
+            factor = torch.where(ratio < 1, safe.clamp(1.0, 10.0), safe.clamp(0.2, 10.0))   # dfactor = 1 iff ratio < 1 (torchdiffeq)
             factor = torch.where(ratio == 0, torch.full_like(ratio, 10.0), factor)
             dt = torch.where(active, dt * factor, dt)
         # dense output at tj through the last accepted step of each controller

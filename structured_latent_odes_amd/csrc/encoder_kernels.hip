@@ -114,8 +114,12 @@ __global__ void __launch_bounds__(ENC_NT) enc_fwd_kernel(const EncK k) {
       const int tb = row / F, f = row - tb * F;
       const float* cr = s_conv + row * n_conv;
       for (int q = lane; q < n_pool; q += 64) {
+        float tap[SLODE_MAX_P];
+#pragma unroll
+        for (int j = 0; j < SLODE_MAX_P; ++j) tap[j] = cr[min(q + j, n_conv - 1)];
         float sum = 0.f;
-        for (int j = 0; j < k.P; ++j) sum += cr[q + j];
+#pragma unroll
+        for (int j = 0; j < SLODE_MAX_P; ++j) sum += (j < k.P) ? tap[j] : 0.f;
         const float v = sum / fP;
         s_pool[tb * FQ + f * n_pool + q] = v;
         if (k.pooled && b0 + tb < k.B) k.pooled[(long long)(b0 + tb) * FQ + f * n_pool + q] = v;
@@ -341,11 +345,12 @@ __global__ void __launch_bounds__(ENC_NT_BWD) enc_bwd_kernel(const EncK k) {
       const int tb = row / F, f = row - tb * F;
       const float* gr = s_gpool + tb * FQ + f * n_pool;
       for (int p = lane; p < n_conv; p += 64) {
+        float tap[SLODE_MAX_P];
+#pragma unroll
+        for (int j = 0; j < SLODE_MAX_P; ++j) tap[j] = gr[min(max(p - j, 0), n_pool - 1)];
         float sum = 0.f;
-        for (int j = 0; j < k.P; ++j) {
-          const int q = p - j;
-          if (q >= 0 && q < n_pool) sum += gr[q];
-        }
+#pragma unroll
+        for (int j = 0; j < SLODE_MAX_P; ++j) sum += (j < k.P && p - j >= 0 && p - j < n_pool) ? tap[j] : 0.f;
         s_gconv[row * n_conv + p] = sum / fP;
       }
     }
@@ -368,14 +373,18 @@ __global__ void __launch_bounds__(ENC_NT_BWD) enc_bwd_kernel(const EncK k) {
         float G[PB];
 #pragma unroll
         for (int dp = 0; dp < PB; ++dp) {
-          G[dp] = (p0 + dp < n_conv) ? s_gconv[(tb * F + f) * n_conv + p0 + dp] : 0.f;
+          const float gv = s_gconv[(tb * F + f) * n_conv + min(p0 + dp, n_conv - 1)];
+          G[dp] = (p0 + dp < n_conv) ? gv : 0.f;
           accb += G[dp];
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           float X[PB + K - 1];
 #pragma unroll
-          for (int j = 0; j < PB + K - 1; ++j) X[j] = (p0 + j < T) ? s_x[(tb * C + c) * T + p0 + j] : 0.f;
+          for (int j = 0; j < PB + K - 1; ++j) {
+            const float xv = s_x[(tb * C + c) * T + min(p0 + j, T - 1)];
+            X[j] = (p0 + j < T) ? xv : 0.f;
+          }
 #pragma unroll
           for (int kk = 0; kk < K; ++kk)
 #pragma unroll

@@ -314,12 +314,33 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
   prefetch(blockIdx.x);
 
   // ---- per-workgroup setup (shared by all trajectories this workgroup integrates) ----------------------
-  for (int i = tid; i < k.nt; i += NT) s_ts[i] = k.stage_t[i];
-  for (int i = tid; i < T - 1; i += NT) s_dt[i] = k.times[i + 1] - k.times[i];
-  if (k.with_ll)
-    for (int i = tid; i < C * T; i += NT) s_sig[i] = softplusf(k.cstd[i]);
+  // all global loads of the setup are issued before the first use (4 per array and thread in flight; clamped addresses,
+  // no predicated loads) -- issued one by one they cost ~10 serial L2/HBM round trips per workgroup
+  {
+    constexpr int DEPTH = 4;
+    auto stage = [&](float* dst, const float* src, int n, bool sp) {
+      for (int i0 = tid; i0 < n; i0 += DEPTH * NT) {
+        float v[DEPTH];
+#pragma unroll
+        for (int q = 0; q < DEPTH; ++q) v[q] = src[min(i0 + q * NT, n - 1)];
+#pragma unroll
+        for (int q = 0; q < DEPTH; ++q)
+          if (i0 + q * NT < n) dst[i0 + q * NT] = sp ? softplusf(v[q]) : v[q];
+      }
+    };
+    stage(s_ts, k.stage_t, k.nt, false);
+    stage(s_par, k.pseg, k.npar, false);
+    if (k.with_ll) stage(s_sig, k.cstd, C * T, true);
+    for (int i0 = tid; i0 < T - 1; i0 += DEPTH * NT) {
+      float a[DEPTH], bq[DEPTH];
+#pragma unroll
+      for (int q = 0; q < DEPTH; ++q) { const int i = min(i0 + q * NT, T - 2); a[q] = k.times[i]; bq[q] = k.times[i + 1]; }
+#pragma unroll
+      for (int q = 0; q < DEPTH; ++q)
+        if (i0 + q * NT < T - 1) s_dt[i0 + q * NT] = bq[q] - a[q];
+    }
+  }
   for (int i = tid; i < k.npar + 1; i += NT) s_acc[i] = 0.f;
-  for (int i = tid; i < k.npar; i += NT) s_par[i] = k.pseg[i];
   __syncthreads();
   if (tid < 32) s_wt[tid] = (tid < H) ? s_par[k.o_wh + tid * (1 + L)] : 0.f;  // time column of dynamics_hidden (col 0)
 
