@@ -30,11 +30,13 @@ B_PER_GPU, T, Z_SPLIT = 1024, 200, (3, 3, 2)
 # Algorithmic FLOPs per trajectory of the forward pass (hidden z-part hoisted, each distinct stage time
 # evaluated once), fwd+bwd = 3x.  Per kernel:
 FLOP_FWD = {"enc": 312_550, "ode": 335_280 + 7_960 + 18_000 + 18_000}
-KERNEL_FLOPS = {  # fwd+bwd algorithmic FLOPs per trajectory attributed to each kernel of the step
+KERNEL_FLOPS = {  # fwd+bwd ALGORITHMIC FLOPs per trajectory (the reference's layer-by-layer count) attributed to each kernel
+    "fold": 0,                                               # W_eff fold: per-step, not per-trajectory work
     "enc_fwd": FLOP_FWD["enc"],
     "ode_elbo": 3 * FLOP_FWD["ode"],
-    "enc_bwd": 2 * FLOP_FWD["enc"] - 2 * 10 * 187 * 50,      # everything of the encoder backward but the lin.weight GEMM
-    "enc_bwd_lin": 2 * 10 * 187 * 50,                        # [Hc x B] x [B x F*n_pool] on the f32 MFMA
+    "enc_bwd": 3_200,                                        # heads + tanh backward
+    "gemm": 2 * 10 * 187 * 50,                               # the lin.weight GEMM's share, on the f32 MFMA
+    "chain": 2 * FLOP_FWD["enc"] - 2 * 10 * 187 * 50 - 3_200,
     "reduce": 0,
 }
 BYTES_PER_TRAJ = 4 * (3 * T + 8 + 2)            # algorithmic HBM bytes: obs once + eps + labels = 2,440 B

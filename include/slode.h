@@ -184,8 +184,10 @@ int slode_adam_step(slode_handle h, int64_t n, float* params, const float* grads
 
 /* Measurement aid for bench.py's roofline block (no reference counterpart): when enabled, slode_elbo_step records HIP
  * events on `stream` around each of its kernels; slode_profile_read waits for the last one and returns the durations in
- * milliseconds of [encoder_fwd, ode_elbo (fused solve + ELBO fwd/bwd), encoder_bwd, encoder_bwd_lin (MFMA), reduce]. */
-#define SLODE_PROFILE_SLOTS 5
+ * milliseconds of [fold (W_eff), encoder_fwd, ode_elbo (fused solve + ELBO fwd/bwd), encoder_bwd (heads),
+ * gemm (MFMA g_pre^T X), chain (back to lin/conv weights), reduce].  With non-dense observation strides the layer-by-layer
+ * encoder runs instead: slot 0 = 0, slot 3 = its backward, slot 4 = its MFMA lin.weight GEMM, slot 5 = 0. */
+#define SLODE_PROFILE_SLOTS 7
 int slode_profile_enable(slode_handle h, int on);
 int slode_profile_read(slode_handle h, float ms[SLODE_PROFILE_SLOTS]);
 

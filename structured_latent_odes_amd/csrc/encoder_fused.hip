@@ -1,0 +1,420 @@
+// Folded encoder path used by slode_elbo_step (gfx950).
+//
+// The reference's EncoderCONV applies conv1d -> avg_pool1d -> flatten -> Linear with NO nonlinearity in between
+// (models/encoder_conv.py:44-47), so for fixed weights the pre-tanh activation is one affine map of the raw observation row:
+//     pre[b][m] = b_eff[m] + sum_kappa W_eff[m][kappa] * x[b][kappa],       kappa = memory index of (c, t) inside a trajectory
+//     W_eff[m][(c,t)] = sum_f sum_{k'} lin.weight[m][f*n_pool + (t - k')] * w'[f][c][k'],   w' = conv taps convolved with the box filter
+//     b_eff[m] = lin.bias[m] + sum_f conv.bias[f] * rowsum[m][f],            rowsum[m][f] = sum_q lin.weight[m][f*n_pool + q]
+// Folding costs Hc*C*T*F*(K+P-1) = 4.2 MFLOP once per step (weights change every step) and removes, per trajectory, the
+// conv/pool stack and the 374 KB lin.weight stream: the forward becomes a [B x C*T] x [C*T x Hc] product on the raw rows (5x
+// fewer FLOPs), the backward a K = B MFMA GEMM with N = C*T followed by the chain rule back to lin.weight / conv.weight.
+// Results differ from the layer-by-layer evaluation only by fp32 summation order (~1e-6 relative; tests bound it at 2e-5).
+//
+// Requires each trajectory's C*T observations to be one dense block (sb == C*T, {sc, st} == {1, C} or {T, 1}); other strides
+// use the layer-by-layer kernels of encoder_kernels.hip.
+#include "slode_common.h"
+
+typedef const __attribute__((address_space(4))) float* cptr;
+
+#ifdef SLODE_STAMPS
+#define STAMP(i) do { } while (0)
+#endif
+
+namespace {
+
+constexpr int TBE = 4;
+constexpr int FNT = 1024;  // enc_fwd2 threads
+constexpr int RB = 4, IU = 5;
+
+struct FoldK {
+  int B, T, C, L, F, K, P, Hc, n_conv, n_pool, FQ, CT, J;
+  int t_major;  // 1: kappa = t*C + c ([B,T,C] contiguous); 0: kappa = c*T + t ([B,C,T] contiguous)
+  const float *conv_w, *conv_b, *lin_w, *lin_b, *zloc_w, *zloc_b, *zls_w, *zls_b;
+  const float* x;       // dense rows [B][CT]
+  float *weff, *rowsum, *wprime, *beff;    // [Hc][CT], [Hc][F], [F][C][J], [Hc]
+  float *loc, *scale, *hid;                // encoder outputs / saved tanh
+  const float *scale_in, *hid_in, *g_loc, *g_scale;
+  float *g_pre, *slabs;                    // [B][64], small2 slabs
+  int small_stride;
+  const float* gslabs; int n_gslabs;       // split-K partials of G = g_pre^T X  [n][Hc*CT]
+  float* g_lin_w;                          // final lin.weight gradient (written directly)
+  float* conv_slabs;                       // [Hc][F*C*K + F]
+};
+
+__device__ __forceinline__ int kappa_of(const FoldK& k, int c, int t) { return k.t_major ? t * k.C + c : c * k.T + t; }
+
+// ---- fold: W_eff, rowsum, b_eff, w' ---------------------------------------------------------------------------------
+template <int JM>  // compile-time bound on J = K + P - 1 (14 for every reference config)
+__global__ void __launch_bounds__(256) weff_kernel(const FoldK k) {
+  __shared__ float s_wp[SLODE_MAX_F * SLODE_MAX_C * JM];
+  const int tid = threadIdx.x, J = k.J, C = k.C, K = k.K;
+  const float fP = (float)k.P;
+  // w'[f][c][j] = (1/P) * sum_{k + p = j} w[f][c][k]   (rows padded to JM, zero beyond J)
+  for (int e = tid; e < k.F * C * JM; e += 256) {
+    const int j = e % JM, fc = e / JM;
+    float s = 0.f;
+    for (int p = 0; p < k.P; ++p) {
+      const int kk = j - p;
+      if (j < J && kk >= 0 && kk < K) s += k.conv_w[fc * K + kk];
+    }
+    s = s / fP;
+    s_wp[e] = s;
+    if (blockIdx.x == 0 && j < J) k.wprime[fc * J + j] = s;
+  }
+  __syncthreads();
+  const int n_w = k.Hc * k.CT;
+  const int nb_w = (n_w + 255) / 256;
+  if ((int)blockIdx.x < nb_w) {
+    const int e = min((int)blockIdx.x * 256 + tid, n_w - 1);
+    const int m = e / k.CT, kap = e - m * k.CT;
+    int c, t;
+    if (k.t_major) { t = kap / C; c = kap - t * C; } else { c = kap / k.T; t = kap - c * k.T; }
+    float acc0 = 0.f, acc1 = 0.f;
+    const float* wlm = k.lin_w + (long long)m * k.FQ;
+#pragma unroll 2
+    for (int f = 0; f < k.F; ++f) {
+      const float* wl = wlm + f * k.n_pool;
+      const float* wp = s_wp + (f * C + c) * JM;
+      float v[JM];
+#pragma unroll
+      for (int j = 0; j < JM; ++j) v[j] = wl[min(max(t - j, 0), k.n_pool - 1)];   // unconditional, clamped
+#pragma unroll
+      for (int j = 0; j < JM; j += 2) {
+        acc0 = fmaf((t - j >= 0 && t - j < k.n_pool) ? v[j] : 0.f, wp[j], acc0);
+        if (j + 1 < JM) acc1 = fmaf((t - j - 1 >= 0 && t - j - 1 < k.n_pool) ? v[j + 1] : 0.f, wp[j + 1], acc1);
+      }
+    }
+    if ((int)blockIdx.x * 256 + tid < n_w) k.weff[e] = acc0 + acc1;
+  } else {
+    // one wave per hidden unit m: rowsum[m][f] for every f, then b_eff[m]
+    const int m = ((int)blockIdx.x - nb_w) * 4 + (tid >> 6), lane = tid & 63;
+    if (m < k.Hc) {
+      // all F partial sums advance together so F loads are in flight per pass (a serial f loop costs one HBM round trip per filter)
+      float sv[SLODE_MAX_F];
+#pragma unroll
+      for (int f = 0; f < SLODE_MAX_F; ++f) sv[f] = 0.f;
+      const float* wlm = k.lin_w + (long long)m * k.FQ;
+      for (int q = lane; q < k.n_pool; q += 64) {
+#pragma unroll
+        for (int f = 0; f < SLODE_MAX_F; ++f) {
+          const float v = wlm[min(f, k.F - 1) * k.n_pool + q];
+          sv[f] += (f < k.F) ? v : 0.f;
+        }
+      }
+      float be = k.lin_b[m];
+#pragma unroll
+      for (int f = 0; f < SLODE_MAX_F; ++f) {
+        const float sf = wave_sum(sv[f]);
+        if (f < k.F) {
+          if (lane == 0) k.rowsum[m * k.F + f] = sf;
+          be = fmaf(k.conv_b[f], sf, be);
+        }
+      }
+      if (lane == 0) k.beff[m] = be;
+    }
+  }
+}
+
+// ---- forward: hid = tanh(W_eff x + b_eff), heads --------------------------------------------------------------------
+__global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const FoldK k) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, NT = blockDim.x, CT = k.CT, Hc = k.Hc, L = k.L;
+  float* s_x = smem;                 // [TBE][CT]   raw rows in memory order (= kappa order)
+  float* s_hid = s_x + TBE * CT;     // [TBE][64]
+  float* s_hw = s_hid + TBE * 64;    // [2][L][Hc]
+  float* s_be = s_hw + 2 * L * Hc;   // [64] b_eff
+  const int b0 = blockIdx.x * TBE;
+  for (int e = tid; e < TBE * CT; e += NT) {
+    const int tb = e / CT;
+    s_x[e] = k.x[(long long)min(b0 + tb, k.B - 1) * CT + (e - tb * CT)];
+  }
+  for (int e = tid; e < 2 * L * Hc; e += NT) s_hw[e] = (e < L * Hc) ? k.zloc_w[e] : k.zls_w[e - L * Hc];
+  if (tid < Hc) s_be[tid] = k.beff[tid];
+  __syncthreads();
+  {
+    const int wave = tid >> 6, lane = tid & 63, nw = NT >> 6;
+    const int ngroups = (Hc + RB - 1) / RB;
+    for (int g = wave; g < ngroups; g += nw) {
+      const int m0 = g * RB;
+      float acc[RB][TBE];
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int tb = 0; tb < TBE; ++tb) acc[r][tb] = 0.f;
+      const float* wrow[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) wrow[r] = k.weff + (long long)min(m0 + r, Hc - 1) * CT;
+      // CT is even for C*T of every supported config; odd CT falls back to scalar columns
+      if ((CT & 1) == 0) {
+        for (int i0 = 2 * lane; i0 < CT; i0 += 128 * IU) {
+          float2 w[RB][IU];
+#pragma unroll
+          for (int u = 0; u < IU; ++u) {
+            const int ic = min(i0 + 128 * u, CT - 2);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) w[r][u] = *reinterpret_cast<const float2*>(wrow[r] + ic);
+          }
+#pragma unroll
+          for (int u = 0; u < IU; ++u) {
+            const bool in = i0 + 128 * u < CT;
+            const int i = min(i0 + 128 * u, CT - 2);
+#pragma unroll
+            for (int tb = 0; tb < TBE; ++tb) {
+              const float2 pv = *reinterpret_cast<const float2*>(s_x + tb * CT + i);
+#pragma unroll
+              for (int r = 0; r < RB; ++r) {
+                const float wx = in ? w[r][u].x : 0.f, wy = in ? w[r][u].y : 0.f;
+                acc[r][tb] = fmaf(wy, pv.y, fmaf(wx, pv.x, acc[r][tb]));
+              }
+            }
+          }
+        }
+      } else {
+        for (int i = lane; i < CT; i += 64) {
+#pragma unroll
+          for (int r = 0; r < RB; ++r) {
+            const float w = wrow[r][i];
+#pragma unroll
+            for (int tb = 0; tb < TBE; ++tb) acc[r][tb] = fmaf(w, s_x[tb * CT + i], acc[r][tb]);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int tb = 0; tb < TBE; ++tb) {
+          const float v = wave_sum(acc[r][tb]);
+          if (lane == 0 && m0 + r < Hc) {
+            const float hv = tanhf(v + s_be[m0 + r]);
+            s_hid[tb * 64 + m0 + r] = hv;
+            if (b0 + tb < k.B) k.hid[(long long)(b0 + tb) * Hc + m0 + r] = hv;
+          }
+        }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < TBE * L * 2; e += NT) {
+    const int which = e / (TBE * L), r = e - which * (TBE * L);
+    const int tb = r / L, l = r - tb * L;
+    const float* W = s_hw + which * L * Hc;
+    float acc = which ? k.zls_b[l] : k.zloc_b[l];
+#pragma unroll 10
+    for (int mm = 0; mm < Hc; ++mm) acc = fmaf(W[l * Hc + mm], s_hid[tb * 64 + mm], acc);
+    if (b0 + tb < k.B) {
+      if (which) k.scale[(long long)(b0 + tb) * L + l] = expf(acc);
+      else k.loc[(long long)(b0 + tb) * L + l] = acc;
+    }
+  }
+}
+
+// ---- backward part 1: heads + tanh -> g_pre; small slab = [lin_b Hc][zloc_w L*Hc][zloc_b L][zls_w L*Hc][zls_b L] -----------
+__global__ void __launch_bounds__(256) enc_bwd2_kernel(const FoldK k) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, NT = blockDim.x, Hc = k.Hc, L = k.L;
+  float* s_hid = smem;               // [TBE][64]
+  float* s_gl = s_hid + TBE * 64;    // [TBE][L]
+  float* s_gs = s_gl + TBE * L;      // [TBE][L]
+  float* s_gpre = s_gs + TBE * L;    // [TBE][64]
+  float* s_hw = s_gpre + TBE * 64;   // [2][L][Hc]
+  const int b0 = blockIdx.x * TBE;
+  float* slab = k.slabs + (long long)blockIdx.x * k.small_stride;
+  const int o_linb = 0, o_zlw = Hc, o_zlb = o_zlw + L * Hc, o_zsw = o_zlb + L, o_zsb = o_zsw + L * Hc;
+  for (int e = tid; e < 2 * L * Hc; e += NT) s_hw[e] = (e < L * Hc) ? k.zloc_w[e] : k.zls_w[e - L * Hc];
+  for (int e = tid; e < TBE * L; e += NT) {
+    const int tb = e / L, l = e - tb * L, b = min(b0 + tb, k.B - 1);
+    const bool ok = b0 + tb < k.B;
+    const float gl = k.g_loc[(long long)b * L + l], gs = k.g_scale[(long long)b * L + l] * k.scale_in[(long long)b * L + l];
+    s_gl[e] = ok ? gl : 0.f;
+    s_gs[e] = ok ? gs : 0.f;
+  }
+  for (int e = tid; e < TBE * 64; e += NT) {
+    const int tb = e >> 6, mm = e & 63, b = min(b0 + tb, k.B - 1);
+    const float hv = k.hid_in[(long long)b * Hc + min(mm, Hc - 1)];
+    s_hid[e] = (b0 + tb < k.B && mm < Hc) ? hv : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < TBE * 64; e += NT) {
+    const int tb = e >> 6, mm = e & 63;
+    float g = 0.f;
+    if (mm < Hc) {
+#pragma unroll 4
+      for (int l = 0; l < L; ++l) {
+        g = fmaf(s_hw[l * Hc + mm], s_gl[tb * L + l], g);
+        g = fmaf(s_hw[(L + l) * Hc + mm], s_gs[tb * L + l], g);
+      }
+      const float hv = s_hid[tb * 64 + mm];
+      g *= (1.f - hv * hv);
+    }
+    s_gpre[e] = g;
+    if (b0 + tb < k.B) k.g_pre[(long long)(b0 + tb) * 64 + mm] = g;
+  }
+  for (int e = tid; e < L * Hc; e += NT) {
+    const int l = e / Hc, mm = e - l * Hc;
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int tb = 0; tb < TBE; ++tb) {
+      a1 = fmaf(s_gl[tb * L + l], s_hid[tb * 64 + mm], a1);
+      a2 = fmaf(s_gs[tb * L + l], s_hid[tb * 64 + mm], a2);
+    }
+    slab[o_zlw + e] = a1;
+    slab[o_zsw + e] = a2;
+  }
+  for (int l = tid; l < L; l += NT) {
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int tb = 0; tb < TBE; ++tb) { a1 += s_gl[tb * L + l]; a2 += s_gs[tb * L + l]; }
+    slab[o_zlb + l] = a1;
+    slab[o_zsb + l] = a2;
+  }
+  __syncthreads();
+  for (int mm = tid; mm < Hc; mm += NT) {
+    float a = 0.f;
+#pragma unroll
+    for (int tb = 0; tb < TBE; ++tb) a += s_gpre[tb * 64 + mm];
+    slab[o_linb + mm] = a;
+  }
+}
+
+// ---- backward part 3: chain rule from G = dLoss/dW_eff back to lin.weight (final) and conv.{weight,bias} (per-m partials) ---
+// Workgroup (m, fp): hidden unit m, filters f in [fp*FPW, fp*FPW + FPW).
+constexpr int FPW = 2;    // filters per workgroup
+constexpr int QCH = 3;    // q-chunks for the w' partial sums
+template <int C, int JM>
+__global__ void __launch_bounds__(256) enc_chain_kernel(const FoldK k) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, NT = blockDim.x, m = blockIdx.x, f0 = blockIdx.y * FPW;
+  const int CT = k.CT, J = k.J, K = k.K, F = k.F, n_pool = k.n_pool, FQ = k.FQ, T = k.T;
+  float* s_G = smem;                        // [CT]          G[m][:] summed over the split-K partials
+  float* s_wl = s_G + CT;                   // [FPW][n_pool] lin.weight[m][f-block]
+  float* s_wp = s_wl + FPW * n_pool;        // [FPW][C][JM]  w' (zero padded)
+  float* s_pm = s_wp + FPW * C * JM;        // [QCH][FPW][C][JM] partial dLoss/dw'
+  float* s_red = s_pm + QCH * FPW * C * JM; // [8]
+  for (int i = tid; i < CT; i += NT) {
+    float a = 0.f;
+    for (int s = 0; s < k.n_gslabs; ++s) a += k.gslabs[((long long)s * k.Hc + m) * CT + i];   // fixed order
+    s_G[i] = a;
+  }
+  for (int i = tid; i < FPW * n_pool; i += NT) {
+    const int fl = i / n_pool, q = i - fl * n_pool;
+    s_wl[i] = (f0 + fl < F) ? k.lin_w[(long long)m * FQ + (f0 + fl) * n_pool + q] : 0.f;
+  }
+  for (int i = tid; i < FPW * C * JM; i += NT) {
+    const int j = i % JM, fc = i / JM, c = fc % C, fl = fc / C;
+    s_wp[i] = (j < J && f0 + fl < F) ? k.wprime[((f0 + fl) * C + c) * J + j] : 0.f;
+  }
+  float gb = 0.f;                           // g_beff[m] = sum_b g_pre[b][m]
+  for (int b = tid; b < k.B; b += NT) gb += k.g_pre[(long long)b * 64 + m];
+  gb = wave_sum(gb);
+  if ((tid & 63) == 0) s_red[tid >> 6] = gb;
+  __syncthreads();
+  gb = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  const int sC = k.t_major ? 1 : T, sT = k.t_major ? C : 1;   // kappa(c, t) = c*sC + t*sT
+  // (i) dLoss/d lin.weight[m][f*n_pool + q] = g_beff[m]*conv_b[f] + sum_{c,j} G[kappa(c, q+j)] * w'[f][c][j]
+  for (int q = tid; q < n_pool; q += NT) {
+    float Gw[C][JM];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int j = 0; j < JM; ++j) Gw[c][j] = s_G[c * sC + min(q + j, T - 1) * sT];   // taps beyond J meet w' == 0
+#pragma unroll
+    for (int fl = 0; fl < FPW; ++fl) {
+      if (f0 + fl >= F) continue;
+      float acc = gb * k.conv_b[f0 + fl];
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int j = 0; j < JM; ++j) acc = fmaf(Gw[c][j], s_wp[(fl * C + c) * JM + j], acc);
+      k.g_lin_w[(long long)m * FQ + (f0 + fl) * n_pool + q] = acc;
+    }
+  }
+  // (ii) partial dLoss/dw'[f][c][j] (this m) = sum_q G[kappa(c, q+j)] * lin.weight[m][f*n_pool + q]; thread (qchunk, f, c, j)
+  for (int e = tid; e < QCH * FPW * C * JM; e += NT) {
+    const int j = e % JM, r1 = e / JM, c = r1 % C, r2 = r1 / C, fl = r2 % FPW, ch = r2 / FPW;
+    const int per = (n_pool + QCH - 1) / QCH, q0 = ch * per, q1 = min(n_pool, q0 + per);
+    const float* wl = s_wl + fl * n_pool;
+    const float* gp = s_G + c * sC + j * sT;
+    float a0 = 0.f, a1 = 0.f;
+    int q = q0;
+    if (j < J) {
+      for (; q + 3 < q1; q += 4) {
+        a0 = fmaf(gp[q * sT], wl[q], a0);
+        a1 = fmaf(gp[(q + 1) * sT], wl[q + 1], a1);
+        a0 = fmaf(gp[(q + 2) * sT], wl[q + 2], a0);
+        a1 = fmaf(gp[(q + 3) * sT], wl[q + 3], a1);
+      }
+      for (; q < q1; ++q) a0 = fmaf(gp[q * sT], wl[q], a0);
+    }
+    s_pm[e] = a0 + a1;
+  }
+  __syncthreads();
+  // w' -> conv taps (adjoint of the box filter) and conv.bias; slab row m holds all filters, this workgroup fills its own
+  float* row = k.conv_slabs + (long long)m * (F * C * K + F);
+  const float fP = (float)k.P;
+  for (int e = tid; e < FPW * C * K; e += NT) {
+    const int kk = e % K, fc = e / K, c = fc % C, fl = fc / C;
+    if (f0 + fl >= F) continue;
+    float s = 0.f;
+    for (int p = 0; p < k.P; ++p) {
+      float v = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < QCH; ++ch) v += s_pm[((ch * FPW + fl) * C + c) * JM + kk + p];
+      s += v;
+    }
+    row[((f0 + fl) * C + c) * K + kk] = s / fP;
+  }
+  if (tid < FPW && f0 + tid < F) row[F * C * K + f0 + tid] = gb * k.rowsum[m * F + f0 + tid];
+}
+
+FoldK make_foldk(const FoldLaunch& a) {
+  const slode_shape& s = a.s;
+  const slode_layout& lay = a.lay;
+  const float* p = a.params;
+  FoldK k{};
+  k.B = s.B; k.T = s.T; k.C = s.C; k.L = s.L; k.F = s.F; k.K = s.K; k.P = s.P; k.Hc = s.Hc;
+  k.n_conv = s.T - s.K + 1; k.n_pool = k.n_conv - s.P + 1; k.FQ = s.F * k.n_pool; k.CT = s.C * s.T; k.J = s.K + s.P - 1;
+  k.t_major = a.t_major;
+  k.conv_w = p + lay.conv_w; k.conv_b = p + lay.conv_b; k.lin_w = p + lay.lin_w; k.lin_b = p + lay.lin_b;
+  k.zloc_w = p + lay.zloc_w; k.zloc_b = p + lay.zloc_b; k.zls_w = p + lay.zls_w; k.zls_b = p + lay.zls_b;
+  k.x = a.x; k.weff = a.weff; k.rowsum = a.rowsum; k.wprime = a.wprime; k.beff = a.beff;
+  k.loc = a.loc; k.scale = a.scale; k.hid = a.hid;
+  k.scale_in = a.scale; k.hid_in = a.hid; k.g_loc = a.g_loc; k.g_scale = a.g_scale;
+  k.g_pre = a.g_pre; k.slabs = a.small_slabs; k.small_stride = a.small_stride;
+  k.gslabs = a.gslabs; k.n_gslabs = a.n_gslabs; k.g_lin_w = a.g_lin_w; k.conv_slabs = a.conv_slabs;
+  return k;
+}
+
+}  // namespace
+
+int slode_fold_small_count(const slode_shape& s) { return s.Hc + 2 * (s.L * s.Hc + s.L); }
+
+hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream, hipEvent_t mid) {
+  FoldK k = make_foldk(a);
+  const int nb_w = (k.Hc * k.CT + 255) / 256, nb_r = (k.Hc + 3) / 4;
+  if (k.J <= 14) hipLaunchKernelGGL((weff_kernel<14>), dim3(nb_w + nb_r), dim3(256), 0, stream, k);
+  else hipLaunchKernelGGL((weff_kernel<SLODE_MAX_K + SLODE_MAX_P>), dim3(nb_w + nb_r), dim3(256), 0, stream, k);
+  if (mid) (void)hipEventRecord(mid, stream);
+  const size_t lds = sizeof(float) * ((size_t)TBE * k.CT + TBE * 64 + 2 * (size_t)k.L * k.Hc + 64);
+  (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(enc_fwd2_kernel, dim3((k.B + TBE - 1) / TBE), dim3(FNT), lds, stream, k);
+  return hipGetLastError();
+}
+
+hipError_t slode_launch_fold_bwd_heads(const FoldLaunch& a, hipStream_t stream) {
+  FoldK k = make_foldk(a);
+  const size_t lds = sizeof(float) * (2 * (size_t)TBE * 64 + 2 * (size_t)TBE * k.L + 2 * (size_t)k.L * k.Hc);
+  hipLaunchKernelGGL(enc_bwd2_kernel, dim3((k.B + TBE - 1) / TBE), dim3(256), lds, stream, k);
+  return hipGetLastError();
+}
+
+hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream) {
+  FoldK k = make_foldk(a);
+  const int JM = k.J <= 14 ? 14 : SLODE_MAX_K + SLODE_MAX_P;
+  const size_t lds = sizeof(float) * ((size_t)k.CT + (size_t)FPW * k.n_pool + (size_t)(1 + QCH) * FPW * k.C * JM + 8);
+  const dim3 grid(k.Hc, (k.F + FPW - 1) / FPW);
+  if (k.C == 3 && JM == 14) hipLaunchKernelGGL((enc_chain_kernel<3, 14>), grid, dim3(256), lds, stream, k);
+  else if (k.C == 4 && JM == 14) hipLaunchKernelGGL((enc_chain_kernel<4, 14>), grid, dim3(256), lds, stream, k);
+  else if (k.C == 3) hipLaunchKernelGGL((enc_chain_kernel<3, SLODE_MAX_K + SLODE_MAX_P>), grid, dim3(256), lds, stream, k);
+  else if (k.C == 4) hipLaunchKernelGGL((enc_chain_kernel<4, SLODE_MAX_K + SLODE_MAX_P>), grid, dim3(256), lds, stream, k);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}

@@ -509,6 +509,14 @@ size_t enc_bwd_lds(const EncK& k) {
 
 }  // namespace
 
+hipError_t slode_launch_gemm_gpre_x(const float* g_pre, const float* x, float* slabs, int B, int Hc, int N, int splitk, hipStream_t stream) {
+  const int total_splits = splitk * 4;
+  int per_wave = (B + total_splits - 1) / total_splits;
+  per_wave = (per_wave + 1) & ~1;
+  hipLaunchKernelGGL(enc_bwd_lin_kernel, dim3((N + 31) / 32, splitk), dim3(256), 0, stream, g_pre, x, slabs, B, Hc, N, per_wave);
+  return hipGetLastError();
+}
+
 int slode_enc_small_count(const slode_shape& s) { return s.F * s.C * s.K + s.F + s.Hc + 2 * (s.L * s.Hc + s.L); }
 int slode_enc_bwd_grid(const slode_shape& s) { return (s.B + TBE - 1) / TBE; }
 int slode_enc_lin_splitk(const slode_shape& s) {

@@ -187,14 +187,17 @@ hipError_t slode_launch_reduce(const ReduceLaunch& a_in, hipStream_t stream) {
     n = (n + per - 1) / per;
   };
   stage1(0, a.ode_slabs, a.ode_stride, a.ode_n, (a.lay.ode_end - a.lay.ode_begin) + 1, a.ode_part);
-  stage1(1, a.small_slabs, a.small_stride, a.small_n, slode_enc_small_count(s), a.small_part);
+  const int small_count = a.folded ? slode_fold_small_count(s) : slode_enc_small_count(s);
+  stage1(1, a.small_slabs, a.small_stride, a.small_n, small_count, a.small_part);
   if (maxcount > 0)
     hipLaunchKernelGGL(slab_stage1_kernel, dim3((maxcount + 63) / 64, SLODE_REDUCE_GROUPS, 2), dim3(256), 0, stream, fam[0], fam[1]);
   k.ode_slabs = a.ode_slabs; k.ode_stride = a.ode_stride; k.ode_n = a.ode_n;
   k.nseg = a.lay.ode_end - a.lay.ode_begin; k.ode_begin = a.lay.ode_begin;
   k.small_slabs = a.small_slabs; k.small_stride = a.small_stride; k.small_n = a.small_n;
-  k.small_count = slode_enc_small_count(s); k.n_conv_part = s.F * s.C * s.K + s.F; k.lin_b_off = a.lay.lin_b;
-  k.lin_slabs = a.lin_slabs; k.lin_n = a.lin_n; k.lin_count = s.Hc * FQ; k.lin_w_off = a.lay.lin_w;
+  k.small_count = small_count; k.n_conv_part = a.folded ? 0 : s.F * s.C * s.K + s.F; k.lin_b_off = a.lay.lin_b;
+  k.lin_slabs = a.lin_slabs; k.lin_n = a.lin_n;
+  k.lin_count = a.folded ? s.F * s.C * s.K + s.F : s.Hc * FQ;
+  k.lin_w_off = a.folded ? a.lay.conv_w : a.lay.lin_w;
   k.grads = a.grads; k.loss_out = a.loss_out; k.n_params = a.lay.n_params; k.zero_rest = a.zero_rest;
   const int n = a.grads ? a.lay.n_params : 1;
   hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, k);

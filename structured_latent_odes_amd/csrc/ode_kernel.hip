@@ -25,9 +25,14 @@ typedef const __attribute__((address_space(4))) float* cptr;  // uniform loads =
 
 #ifdef SLODE_STAMPS  // diagnostic build only: phase boundaries of workgroup 0 in 10 ns ticks (s_memrealtime)
 __device__ unsigned long long g_stamps_ode[32];
-#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps_ode[i] = wall_clock64(); } while (0)
+__device__ unsigned long long g_wg_span[2 * 4096];   // [start, end] of every workgroup
+#define STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); if (blockIdx.x == 0) g_stamps_ode[i] = t_; \
+    if ((i) == 0 && blockIdx.x < 4096) g_wg_span[2 * blockIdx.x] = t_; if ((i) == 11 && blockIdx.x < 4096) g_wg_span[2 * blockIdx.x + 1] = t_; } } while (0)
 extern "C" int slode_debug_stamps_ode(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_ode), sizeof(unsigned long long) * 32);
+}
+extern "C" int slode_debug_wg_span(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_span), sizeof(unsigned long long) * 2 * n);
 }
 #else
 #define STAMP(i) do { } while (0)

@@ -86,6 +86,7 @@ int slode_create(slode_handle* out, int device_id) {
   c->num_cu = prop.multiProcessorCount;
   c->err[0] = 0;
   c->profile = 0; c->ev_ready = 0; c->ev_valid = 0;
+  c->no_fold = getenv("SLODE_NO_FOLD") != nullptr;   // diagnostics: force the layer-by-layer encoder kernels
   *out = c;
   return SLODE_OK;
 }
@@ -164,6 +165,8 @@ int slode_num_stage_times(const slode_shape* s) {
 // ---- workspace carving -------------------------------------------------------------------------------------
 struct Workspace {
   float *loc, *scale, *pooled, *hid, *g_loc, *g_scale, *g_pre, *ode_slabs, *ode_part, *small_slabs, *small_part, *lin_slabs;
+  float *weff, *rowsum, *wprime, *beff, *gslabs, *conv_slabs;  // folded encoder path
+  int gsplit;
   int ode_grid, ode_stride, small_grid, small_stride, lin_splitk;
   size_t bytes;
 };
@@ -207,6 +210,13 @@ static Workspace carve(slode_handle h, const slode_shape& s, const slode_layout&
   w.small_slabs = take((size_t)w.small_grid * w.small_stride);
   w.small_part = take((size_t)SLODE_REDUCE_GROUPS * w.small_stride);
   w.lin_slabs = take((size_t)w.lin_splitk * s.Hc * FQ);
+  w.gsplit = w.lin_splitk;
+  w.weff = take((size_t)s.Hc * s.C * s.T);
+  w.rowsum = take((size_t)s.Hc * s.F);
+  w.wprime = take((size_t)s.F * s.C * (s.K + s.P));
+  w.beff = take(64);
+  w.gslabs = take((size_t)w.gsplit * s.Hc * s.C * s.T);
+  w.conv_slabs = take((size_t)s.Hc * (s.F * s.C * s.K + s.F));
   w.bytes = o * sizeof(float);
   return w;
 }
@@ -267,7 +277,7 @@ int slode_encoder_conv_bwd(slode_handle h, const slode_shape* s, const slode_lay
   hipError_t e = slode_launch_enc_bwd(a, (hipStream_t)stream);
   if (e == hipErrorInvalidValue) return fail(h, SLODE_EINVAL, "unsupported encoder shape C=%d K=%d T=%d", s->C, s->K, s->T);
   HIP_TRY(h, e);
-  ReduceLaunch r{*s, *lay, nullptr, 0, 0, w.small_slabs, w.small_stride, w.small_grid, w.lin_slabs, w.lin_splitk, grads, nullptr, 0, nullptr, w.small_part};
+  ReduceLaunch r{*s, *lay, nullptr, 0, 0, w.small_slabs, w.small_stride, w.small_grid, w.lin_slabs, w.lin_splitk, grads, nullptr, 0, nullptr, w.small_part, 0};
   HIP_TRY(h, slode_launch_reduce(r, (hipStream_t)stream));
   return SLODE_OK;
 }
@@ -318,7 +328,7 @@ int slode_ode_solve_bwd(slode_handle h, const slode_shape* s, const slode_layout
   hipError_t e = slode_launch_ode(a, (hipStream_t)stream, h->err, sizeof(h->err));
   if (e == hipErrorInvalidValue) return SLODE_EINVAL;
   HIP_TRY(h, e);
-  ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, nullptr, 0, 0, nullptr, 0, grads, nullptr, 0, w.ode_part, nullptr};
+  ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, nullptr, 0, 0, nullptr, 0, grads, nullptr, 0, w.ode_part, nullptr, 0};
   HIP_TRY(h, slode_launch_reduce(r, (hipStream_t)stream));
   return SLODE_OK;
 }
@@ -350,11 +360,28 @@ int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* la
 #define SLODE_MARK(i) do { if (prof) (void)hipEventRecord(h->ev[i], st); } while (0)
   SLODE_MARK(0);
 
-  EncLaunch ef{*s, *lay, params, obs, obs_strides[0], obs_strides[1], obs_strides[2], w.loc, w.scale, w.pooled, w.hid};
-  hipError_t e = slode_launch_enc_fwd(ef, st);
-  if (e == hipErrorInvalidValue) return fail(h, SLODE_EINVAL, "unsupported encoder shape C=%d K=%d T=%d", s->C, s->K, s->T);
-  HIP_TRY(h, e);
-  SLODE_MARK(1);
+  // Folded encoder (encoder_fused.hip) when every trajectory's C*T observations are one dense block; else layer by layer.
+  const long long CT = (long long)s->C * s->T;
+  const bool t_major = obs_strides[1] == 1 && obs_strides[2] == s->C;          // [B,T,C] contiguous (cvs / challenge batches)
+  const bool c_major = obs_strides[2] == 1 && obs_strides[1] == s->T;          // [B,C,T] contiguous (proc batches)
+  const bool folded = !h->no_fold && obs_strides[0] == CT && (t_major || c_major) && (s->C == 3 || s->C == 4);
+  FoldLaunch fl{};
+  hipError_t e;
+  if (folded) {
+    fl.s = *s; fl.lay = *lay; fl.params = params; fl.x = obs; fl.t_major = t_major ? 1 : 0;
+    fl.weff = w.weff; fl.rowsum = w.rowsum; fl.wprime = w.wprime; fl.beff = w.beff; fl.loc = w.loc; fl.scale = w.scale; fl.hid = w.hid;
+    fl.g_loc = w.g_loc; fl.g_scale = w.g_scale; fl.g_pre = w.g_pre; fl.small_slabs = w.small_slabs; fl.small_stride = w.small_stride;
+    fl.gslabs = w.gslabs; fl.n_gslabs = w.gsplit; fl.g_lin_w = grads ? grads + lay->lin_w : nullptr; fl.conv_slabs = w.conv_slabs;
+    e = slode_launch_fold_fwd(fl, st, prof ? h->ev[1] : nullptr);
+    HIP_TRY(h, e);
+  } else {
+    EncLaunch ef{*s, *lay, params, obs, obs_strides[0], obs_strides[1], obs_strides[2], w.loc, w.scale, w.pooled, w.hid};
+    e = slode_launch_enc_fwd(ef, st);
+    if (e == hipErrorInvalidValue) return fail(h, SLODE_EINVAL, "unsupported encoder shape C=%d K=%d T=%d", s->C, s->K, s->T);
+    HIP_TRY(h, e);
+    SLODE_MARK(1);
+  }
+  SLODE_MARK(2);
 
   OdeLaunch a{};
   a.s = *s; a.lay = *lay; a.params = params; a.times = times; a.stage_t = stage_t;
@@ -365,20 +392,33 @@ int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* la
   e = slode_launch_ode(a, st, h->err, sizeof(h->err));
   if (e == hipErrorInvalidValue) return SLODE_EINVAL;
   HIP_TRY(h, e);
-  SLODE_MARK(2);
+  SLODE_MARK(3);
 
-  if (bwd) {
+  if (bwd && folded) {
+    HIP_TRY(h, slode_launch_fold_bwd_heads(fl, st));
+    SLODE_MARK(4);
+    HIP_TRY(h, slode_launch_gemm_gpre_x(w.g_pre, obs, w.gslabs, s->B, s->Hc, (int)CT, w.gsplit, st));
+    SLODE_MARK(5);
+    HIP_TRY(h, slode_launch_fold_chain(fl, st));
+    SLODE_MARK(6);
+    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, w.small_slabs, w.small_stride, w.small_grid,
+                   w.conv_slabs, s->Hc, grads, loss_out, 0, w.ode_part, w.small_part, 1};
+    HIP_TRY(h, slode_launch_reduce(r, st));
+    SLODE_MARK(7);
+    if (prof) h->ev_valid = 1;
+  } else if (bwd) {
     EncBwdLaunch eb{*s, *lay, params, obs, obs_strides[0], obs_strides[1], obs_strides[2], w.scale, w.pooled, w.hid,
                     w.g_loc, w.g_scale, w.g_pre, w.small_slabs, w.small_stride, w.small_grid, w.lin_slabs, w.lin_splitk};
-    HIP_TRY(h, slode_launch_enc_bwd(eb, st, prof ? h->ev[3] : nullptr));
-    SLODE_MARK(4);
-    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, w.small_slabs, w.small_stride, w.small_grid,
-                   w.lin_slabs, w.lin_splitk, grads, loss_out, 1, w.ode_part, w.small_part};
-    HIP_TRY(h, slode_launch_reduce(r, st));
+    HIP_TRY(h, slode_launch_enc_bwd(eb, st, prof ? h->ev[4] : nullptr));
     SLODE_MARK(5);
+    SLODE_MARK(6);
+    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, w.small_slabs, w.small_stride, w.small_grid,
+                   w.lin_slabs, w.lin_splitk, grads, loss_out, 1, w.ode_part, w.small_part, 0};
+    HIP_TRY(h, slode_launch_reduce(r, st));
+    SLODE_MARK(7);
     if (prof) h->ev_valid = 1;
   } else {
-    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, nullptr, 0, 0, nullptr, 0, nullptr, loss_out, 0, w.ode_part, nullptr};
+    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, nullptr, 0, 0, nullptr, 0, nullptr, loss_out, 0, w.ode_part, nullptr, 0};
     HIP_TRY(h, slode_launch_reduce(r, st));
   }
   return SLODE_OK;

@@ -23,6 +23,7 @@ struct slode_ctx {
   hipEvent_t ev[SLODE_PROFILE_SLOTS + 1];
   int ev_ready;           // events created
   int ev_valid;           // a profiled step has been recorded
+  int no_fold;            // env SLODE_NO_FOLD: use the layer-by-layer encoder kernels inside slode_elbo_step
 };
 
 // ---- device helpers -------------------------------------------------------------------------------------
@@ -120,6 +121,26 @@ int slode_enc_small_count(const slode_shape& s);   // floats per small slab
 int slode_enc_bwd_grid(const slode_shape& s);
 int slode_enc_lin_splitk(const slode_shape& s);
 
+// Folded encoder path (encoder_fused.hip)
+struct FoldLaunch {
+  slode_shape s;
+  slode_layout lay;
+  const float* params;
+  const float* x;        // dense observation rows [B][C*T]
+  int t_major;           // 1: [B,T,C] contiguous, 0: [B,C,T] contiguous
+  float *weff, *rowsum, *wprime, *beff;
+  float *loc, *scale, *hid;
+  const float *g_loc, *g_scale;
+  float *g_pre, *small_slabs; int small_stride;
+  const float* gslabs; int n_gslabs;
+  float *g_lin_w, *conv_slabs;
+};
+hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream, hipEvent_t mid = nullptr);
+hipError_t slode_launch_fold_bwd_heads(const FoldLaunch& a, hipStream_t stream);
+hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream);
+hipError_t slode_launch_gemm_gpre_x(const float* g_pre, const float* x, float* slabs, int B, int Hc, int N, int splitk, hipStream_t stream);
+int slode_fold_small_count(const slode_shape& s);
+
 #define SLODE_REDUCE_GROUPS 16
 struct ReduceLaunch {
   slode_shape s;
@@ -132,6 +153,7 @@ struct ReduceLaunch {
   int zero_rest;      // also zero grads outside the written segments [0, n_params)
   float* ode_part;    // [SLODE_REDUCE_GROUPS][ode_stride] scratch for the two-stage reduction (may be null)
   float* small_part;  // [SLODE_REDUCE_GROUPS][small_stride] likewise
+  int folded;         // 1: folded-encoder families (small = [lin_b..zls_b]; `lin` family = per-m conv slabs at flat offset conv_w)
 };
 hipError_t slode_launch_reduce(const ReduceLaunch& a, hipStream_t stream);
 

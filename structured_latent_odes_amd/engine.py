@@ -290,10 +290,10 @@ class Engine:
         _check(self.lib, self.handle, self.lib.slode_profile_enable(self.handle, 1 if on else 0))
 
     def profile_read(self):
-        """Durations (ms) of the kernels of the last profiled elbo_step: enc_fwd, ode_elbo, enc_bwd, enc_bwd_lin, reduce."""
-        ms = (C.c_float * 5)()
+        """Durations (ms) of the kernels of the last profiled elbo_step (include/slode.h, slode_profile_read)."""
+        ms = (C.c_float * 7)()
         _check(self.lib, self.handle, self.lib.slode_profile_read(self.handle, ms))
-        return dict(zip(("enc_fwd", "ode_elbo", "enc_bwd", "enc_bwd_lin", "reduce"), [float(v) for v in ms]))
+        return dict(zip(("fold", "enc_fwd", "ode_elbo", "enc_bwd", "gemm", "chain", "reduce"), [float(v) for v in ms]))
 
 
 def cvs_spec(z_iext=5, z_rtpr=5, z_eps=5, gauss=False, solver="midpoint", quantile_diff=0.475) -> ModelSpec:

@@ -36,3 +36,13 @@ for name, labels in (("ode", ["setup", "P0 latent/init", "P1 eval a,d", "P1 coef
     for i, lab in enumerate(labels):
         if lab is not None and v[i + 1] and v[i]:
             print("  %-26s %8.2f" % (lab, (v[i + 1] - v[i]) / 100.0))
+
+import numpy as np
+n = 1024
+buf = (C.c_ulonglong * (2 * n))()
+if hasattr(lib, "slode_debug_wg_span") and lib.slode_debug_wg_span(buf, n) == 0:
+    a = np.array(list(buf), dtype=np.float64).reshape(n, 2) / 100.0
+    t0 = a[:, 0].min()
+    dur = a[:, 1] - a[:, 0]
+    print("== ode kernel, all %d workgroups (us): first start 0.0, last start %.2f, first end %.2f, last end %.2f; duration min/median/max %.2f / %.2f / %.2f"
+          % (n, a[:, 0].max() - t0, a[:, 1].min() - t0, a[:, 1].max() - t0, dur.min(), np.median(dur), dur.max()))
