@@ -177,6 +177,17 @@ int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* la
                     const float* u, const float* eps, float* loss_out, float* grads, float* x_out, float* z_out,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* slode_elbo_step immediately followed by slode_adam_step, with the Adam update applied by the final gradient-reduction
+ * kernel (one launch and one pass over the gradient less; identical arithmetic).  For single-process training: data-parallel
+ * runs need the gradient materialised for the all-reduce between the two, so they call the two entry points separately.
+ * params / exp_avg / exp_avg_sq hold n_total >= lay->n_params floats; entries beyond the layout (caller-appended parameters the
+ * main loss does not touch) are stepped with a zero gradient, as pyro's shared optimizer does.  grads is still
+ * written ([0, n_params)). */
+int slode_elbo_adam_step(slode_handle h, const slode_shape* s, const slode_layout* lay, float* params, const float* times,
+                         const float* stage_t, const float* obs, const int64_t obs_strides[3], const float* u, const float* eps,
+                         float* loss_out, float* grads, void* workspace, size_t workspace_bytes, int64_t n_total, float* exp_avg,
+                         float* exp_avg_sq, float lr, float beta1, float beta2, float adam_eps, int64_t step, void* stream);
+
 /* torch.optim.Adam step as pyro.optim.Adam applies it per parameter (training_cvs.py:226-227): in-place on flat
  * buffers.  step = 1-based step count. */
 int slode_adam_step(slode_handle h, int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,

@@ -26,6 +26,10 @@ struct ReduceK {
   const float* lin_slabs; int lin_n, lin_count, lin_w_off;
   float* grads; float* loss_out;
   int n_params, zero_rest;
+  // optional fused Adam (single-process training): applied to element i right after its gradient is final
+  float *adam_p, *adam_m, *adam_v;
+  float step_size, one_minus_b1, b2, one_minus_b2, sqrt_bc2, eps;
+  int n_total;  // >= n_params: parameters appended by the caller (zero main-loss gradient) are stepped too
 };
 
 __device__ __forceinline__ float strided_sum(const float* p, int stride, int n) {
@@ -78,26 +82,43 @@ __global__ void reduce_kernel(const ReduceK k) {
     for (int w = 0; w < k.ode_n; ++w) acc += (double)k.ode_slabs[(long long)w * k.ode_stride];
     k.loss_out[0] = (float)acc;
   }
-  if (i >= k.n_params || k.grads == nullptr) return;
-  // which family owns flat element i?
-  if (k.ode_slabs && i >= k.ode_begin && i < k.ode_begin + k.nseg) {
-    k.grads[i] = strided_sum(k.ode_slabs + 1 + (i - k.ode_begin), k.ode_stride, k.ode_n);
-    return;
-  }
-  if (k.lin_slabs && i >= k.lin_w_off && i < k.lin_w_off + k.lin_count) {
-    k.grads[i] = strided_sum(k.lin_slabs + (i - k.lin_w_off), k.lin_count, k.lin_n);
-    return;
-  }
-  if (k.small_slabs) {
+  if (k.grads == nullptr) return;
+  const int n_all = k.adam_p ? k.n_total : k.n_params;
+  if (i >= n_all) return;
+  float g = 0.f;
+  bool write = false;
+  if (i < k.n_params) {
+    // which family owns flat element i?
     int j = -1;
-    if (i < k.n_conv_part) j = i;                                                       // conv_w, conv_b
-    else if (i >= k.lin_b_off && i < k.lin_b_off + (k.small_count - k.n_conv_part)) j = k.n_conv_part + (i - k.lin_b_off);
-    if (j >= 0) {
-      k.grads[i] = strided_sum(k.small_slabs + j, k.small_stride, k.small_n);
-      return;
+    if (k.small_slabs) {
+      if (i < k.n_conv_part) j = i;                                                     // conv_w, conv_b
+      else if (i >= k.lin_b_off && i < k.lin_b_off + (k.small_count - k.n_conv_part)) j = k.n_conv_part + (i - k.lin_b_off);
     }
+    if (k.ode_slabs && i >= k.ode_begin && i < k.ode_begin + k.nseg) {
+      g = strided_sum(k.ode_slabs + 1 + (i - k.ode_begin), k.ode_stride, k.ode_n);
+      write = true;
+    } else if (k.lin_slabs && i >= k.lin_w_off && i < k.lin_w_off + k.lin_count) {
+      g = strided_sum(k.lin_slabs + (i - k.lin_w_off), k.lin_count, k.lin_n);
+      write = true;
+    } else if (j >= 0) {
+      g = strided_sum(k.small_slabs + j, k.small_stride, k.small_n);
+      write = true;
+    } else if (k.zero_rest) {
+      write = true;
+    } else {
+      g = k.grads[i];  // already final (folded path: lin.weight gradient written by the chain kernel)
+    }
+    if (write) k.grads[i] = g;
   }
-  if (k.zero_rest) k.grads[i] = 0.f;
+  if (k.adam_p) {  // torch.optim.Adam single-tensor formulas (see adam_kernel)
+    float mi = k.adam_m[i], vi = k.adam_v[i];
+    mi = mi + k.one_minus_b1 * (g - mi);
+    vi = vi * k.b2 + k.one_minus_b2 * g * g;
+    const float denom = sqrtf(vi) / k.sqrt_bc2 + k.eps;
+    k.adam_p[i] = k.adam_p[i] - k.step_size * (mi / denom);
+    k.adam_m[i] = mi;
+    k.adam_v[i] = vi;
+  }
 }
 
 // Decoder heads on a given trajectory tensor: models/decoders.py:45-47 (ALD: q50, q75, q25) / :86 (Gauss: mean),
@@ -199,7 +220,15 @@ hipError_t slode_launch_reduce(const ReduceLaunch& a_in, hipStream_t stream) {
   k.lin_count = a.folded ? s.F * s.C * s.K + s.F : s.Hc * FQ;
   k.lin_w_off = a.folded ? a.lay.conv_w : a.lay.lin_w;
   k.grads = a.grads; k.loss_out = a.loss_out; k.n_params = a.lay.n_params; k.zero_rest = a.zero_rest;
-  const int n = a.grads ? a.lay.n_params : 1;
+  int n = a.grads ? a.lay.n_params : 1;
+  if (a.adam_p && a.grads) {
+    const double bc1 = 1.0 - pow((double)a.adam_b1, (double)a.adam_step), bc2 = 1.0 - pow((double)a.adam_b2, (double)a.adam_step);
+    k.adam_p = a.adam_p; k.adam_m = a.adam_m; k.adam_v = a.adam_v;
+    k.step_size = (float)((double)a.adam_lr / bc1); k.one_minus_b1 = 1.0f - a.adam_b1; k.b2 = a.adam_b2;
+    k.one_minus_b2 = 1.0f - a.adam_b2; k.sqrt_bc2 = (float)sqrt(bc2); k.eps = a.adam_eps;
+    k.n_total = a.adam_n > a.lay.n_params ? (int)a.adam_n : a.lay.n_params;
+    n = k.n_total;
+  }
   hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, k);
   return hipGetLastError();
 }

@@ -342,10 +342,12 @@ int slode_decode_heads(slode_handle h, const slode_shape* s, const slode_layout*
   return SLODE_OK;
 }
 
-int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* times,
-                    const float* stage_t, const float* obs, const int64_t obs_strides[3], const float* u, const float* eps,
-                    float* loss_out, float* grads, float* x_out, float* z_out, void* workspace, size_t workspace_bytes,
-                    void* stream) {
+struct AdamArgs { float *p, *m, *v; float lr, b1, b2, eps; int64_t step, n; };
+
+static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* times,
+                          const float* stage_t, const float* obs, const int64_t obs_strides[3], const float* u, const float* eps,
+                          float* loss_out, float* grads, float* x_out, float* z_out, void* workspace, size_t workspace_bytes,
+                          void* stream, const AdamArgs* adam) {
   const char* why = check_common(h, s, lay, params);
   if (why) return fail(h, SLODE_EINVAL, "%s", why);
   if (!times || !stage_t || !obs || !obs_strides || !eps || !loss_out || !workspace)
@@ -403,6 +405,8 @@ int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* la
     SLODE_MARK(6);
     ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, w.small_slabs, w.small_stride, w.small_grid,
                    w.conv_slabs, s->Hc, grads, loss_out, 0, w.ode_part, w.small_part, 1};
+    if (adam) { r.adam_p = adam->p; r.adam_m = adam->m; r.adam_v = adam->v; r.adam_lr = adam->lr; r.adam_b1 = adam->b1;
+                r.adam_b2 = adam->b2; r.adam_eps = adam->eps; r.adam_step = adam->step; r.adam_n = adam->n; }
     HIP_TRY(h, slode_launch_reduce(r, st));
     SLODE_MARK(7);
     if (prof) h->ev_valid = 1;
@@ -414,6 +418,8 @@ int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* la
     SLODE_MARK(6);
     ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, w.small_slabs, w.small_stride, w.small_grid,
                    w.lin_slabs, w.lin_splitk, grads, loss_out, 1, w.ode_part, w.small_part, 0};
+    if (adam) { r.adam_p = adam->p; r.adam_m = adam->m; r.adam_v = adam->v; r.adam_lr = adam->lr; r.adam_b1 = adam->b1;
+                r.adam_b2 = adam->b2; r.adam_eps = adam->eps; r.adam_step = adam->step; r.adam_n = adam->n; }
     HIP_TRY(h, slode_launch_reduce(r, st));
     SLODE_MARK(7);
     if (prof) h->ev_valid = 1;
@@ -422,6 +428,25 @@ int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* la
     HIP_TRY(h, slode_launch_reduce(r, st));
   }
   return SLODE_OK;
+}
+
+int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* times,
+                    const float* stage_t, const float* obs, const int64_t obs_strides[3], const float* u, const float* eps,
+                    float* loss_out, float* grads, float* x_out, float* z_out, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+  return elbo_step_impl(h, s, lay, params, times, stage_t, obs, obs_strides, u, eps, loss_out, grads, x_out, z_out, workspace,
+                        workspace_bytes, stream, nullptr);
+}
+
+int slode_elbo_adam_step(slode_handle h, const slode_shape* s, const slode_layout* lay, float* params, const float* times,
+                         const float* stage_t, const float* obs, const int64_t obs_strides[3], const float* u, const float* eps,
+                         float* loss_out, float* grads, void* workspace, size_t workspace_bytes, int64_t n_total, float* exp_avg,
+                         float* exp_avg_sq, float lr, float beta1, float beta2, float adam_eps, int64_t step, void* stream) {
+  if (!grads || !exp_avg || !exp_avg_sq || step < 1 || !lay || n_total < lay->n_params)
+    return fail(h, SLODE_EINVAL, "slode_elbo_adam_step needs grads, Adam moments, step >= 1 and n_total >= layout n_params");
+  const AdamArgs ad{params, exp_avg, exp_avg_sq, lr, beta1, beta2, adam_eps, step, n_total};
+  return elbo_step_impl(h, s, lay, params, times, stage_t, obs, obs_strides, u, eps, loss_out, grads, nullptr, nullptr, workspace,
+                        workspace_bytes, stream, &ad);
 }
 
 int slode_dynamics_eval(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, float t,

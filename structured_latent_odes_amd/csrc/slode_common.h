@@ -154,6 +154,9 @@ struct ReduceLaunch {
   float* ode_part;    // [SLODE_REDUCE_GROUPS][ode_stride] scratch for the two-stage reduction (may be null)
   float* small_part;  // [SLODE_REDUCE_GROUPS][small_stride] likewise
   int folded;         // 1: folded-encoder families (small = [lin_b..zls_b]; `lin` family = per-m conv slabs at flat offset conv_w)
+  float *adam_p = nullptr, *adam_m = nullptr, *adam_v = nullptr;  // optional fused Adam (after the positional members)
+  float adam_lr = 0.f, adam_b1 = 0.f, adam_b2 = 0.f, adam_eps = 0.f;
+  int64_t adam_step = 0, adam_n = 0;
 };
 hipError_t slode_launch_reduce(const ReduceLaunch& a, hipStream_t stream);
 

@@ -280,6 +280,17 @@ class Engine:
             self._p(ws), ws.numel() * 4, self._stream()))
         return loss_out
 
+    def elbo_adam_step(self, params, obs, u, eps, loss_out, grads, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), adam_eps=1e-8):
+        """elbo_step + Adam with the update fused into the gradient reduction (single-process training)."""
+        B = obs.shape[0]
+        ws = self.workspace(B)
+        _check(self.lib, self.handle, self.lib.slode_elbo_adam_step(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._times), self._p(self._stage_t),
+            self._p(obs), self._obs_strides(obs), self._p(u), self._p(eps), self._p(loss_out), self._p(grads), self._p(ws), ws.numel() * 4,
+            params.numel(), self._p(exp_avg), self._p(exp_avg_sq), float(lr), float(betas[0]), float(betas[1]), float(adam_eps), int(step),
+            self._stream()))
+        return loss_out
+
     def adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-8):
         _check(self.lib, self.handle, self.lib.slode_adam_step(
             self.handle, params.numel(), self._p(params), self._p(grads), self._p(exp_avg), self._p(exp_avg_sq),

@@ -54,13 +54,20 @@ class ELBOStep:
     def step_async(self, observations, eps=None, **labels):
         """Enqueue one optimisation step on the current stream; returns the device tensor holding -ELBO (global sum)."""
         obs, u, eps = self._inputs(observations, eps, labels)
-        if self.params.numel() != self.engine.n_params:
-            self.gbuf[self.engine.n_params:self.params.numel()].zero_()   # appended (aux) parameters get no main-loss gradient
+        # parameters appended after engine.n_params (auxiliary heads) get no main-loss gradient: that region of gbuf is
+        # zero-initialised and never written by slode_elbo_step, so it needs no per-step fill
+        opt = self.optimizer
+        if self.world == 1 and opt is not None and hasattr(self.engine, "elbo_adam_step"):
+            # single process: Adam applied by the final gradient-reduction kernel (slode_elbo_adam_step)
+            opt.t += 1
+            self.engine.elbo_adam_step(self.params, obs, u, eps, self.loss, self.grads, opt.exp_avg, opt.exp_avg_sq, opt.lr, opt.t,
+                                       opt.betas, opt.eps)
+            return self.loss
         self.engine.elbo_step(self.params, obs, u, eps, self.loss, self.grads)
         if self.world > 1:
             torch.distributed.all_reduce(self.gbuf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
-        if self.optimizer is not None:
-            self.optimizer.step(self.gbuf[:self.params.numel()])
+        if opt is not None:
+            opt.step(self.gbuf[:self.params.numel()])
         return self.loss
 
     def step(self, observations, eps=None, **labels) -> float:
