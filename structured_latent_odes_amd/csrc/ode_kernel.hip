@@ -22,6 +22,7 @@
 #include "slode_common.h"
 
 typedef const __attribute__((address_space(4))) float* cptr;  // uniform loads => s_load + SGPR operands
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #ifdef SLODE_STAMPS  // diagnostic build only: phase boundaries of workgroup 0 in 10 ns ticks (s_memrealtime)
 __device__ unsigned long long g_stamps_ode[32];
@@ -295,28 +296,34 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
   STAMP(0);
   // Prefetch of a trajectory's per-thread inputs: issued before the setup (first trajectory) and before the tail of the
   // previous trajectory, so their HBM latency is off the critical path of P0.
-  float pf_loc = 0.f, pf_sc = 1.f, pf_eps = 0.f, pf_u = 0.f, pf_ob[SLODE_MAX_C];
-  auto prefetch = [&](int b) {
-    if (b >= k.B) return;
-    if (tid < L) {
-      if (k.loc != nullptr) {
-        pf_loc = k.loc[(long long)b * L + tid];
-        pf_sc = k.scale[(long long)b * L + tid];
-        pf_eps = k.eps[(long long)b * L + tid];
-      } else {
-        pf_loc = k.z_in[(long long)b * L + tid];
-      }
-    }
-    if (k.u != nullptr && tid < k.nu) pf_u = k.u[(long long)b * k.nu + tid];
-    if (k.with_ll && tid < T) {
-#pragma unroll
-      for (int c = 0; c < SLODE_MAX_C; ++c)
-        pf_ob[c] = (c < C) ? k.obs[(long long)b * k.sb + (long long)c * k.sc + (long long)tid * k.st] : 0.f;
-    }
-  };
-#pragma unroll
-  for (int c = 0; c < SLODE_MAX_C; ++c) pf_ob[c] = 0.f;
-  prefetch(blockIdx.x);
+  float pf_loc = 0.f, pf_sc = 1.f, pf_eps = 0.f, pf_u = 0.f;
+  float pf_ob0 = 0.f, pf_ob1 = 0.f, pf_ob2 = 0.f, pf_ob3 = 0.f;
+  // (a macro, not a lambda: by-reference captures were kept in scratch memory)
+#define SLODE_PREFETCH(bb)                                                                                               \
+  do {                                                                                                                   \
+    const int b_ = (bb);                                                                                                 \
+    if (b_ < k.B) {                                                                                                      \
+      if (tid_outer < L) {                                                                                               \
+        if (k.loc != nullptr) {                                                                                          \
+          pf_loc = k.loc[(long long)b_ * L + tid_outer];                                                                 \
+          pf_sc = k.scale[(long long)b_ * L + tid_outer];                                                                \
+          pf_eps = k.eps[(long long)b_ * L + tid_outer];                                                                 \
+        } else {                                                                                                         \
+          pf_loc = k.z_in[(long long)b_ * L + tid_outer];                                                                \
+        }                                                                                                                \
+      }                                                                                                                  \
+      if (k.u != nullptr && tid_outer < k.nu) pf_u = k.u[(long long)b_ * k.nu + tid_outer];                              \
+      if (k.with_ll && tid_outer < T) {                                                                                  \
+        const float* op_ = k.obs + (long long)b_ * k.sb + (long long)tid_outer * k.st;                                   \
+        pf_ob0 = op_[0];                                                                                                 \
+        pf_ob1 = op_[(long long)min(1, C - 1) * k.sc];                                                                   \
+        pf_ob2 = op_[(long long)min(2, C - 1) * k.sc];                                                                   \
+        pf_ob3 = op_[(long long)min(3, C - 1) * k.sc];                                                                   \
+      }                                                                                                                  \
+    }                                                                                                                    \
+  } while (0)
+  const int tid_outer = tid;
+  SLODE_PREFETCH(blockIdx.x);
 
   // ---- per-workgroup setup (shared by all trajectories this workgroup integrates) ----------------------
   // all global loads of the setup are issued before the first use (4 per array and thread in flight; clamped addresses,
@@ -369,7 +376,6 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
   __syncthreads();
   STAMP(1);
 
-  const int tid_outer = tid;
   for (int b = blockIdx.x; b < k.B; b += gridDim.x) {
     // Launder the thread id once per trajectory: with it opaque, the compiler cannot hoist the dozens of per-thread
     // address computations of the phases below out of this loop (which only lengthens live ranges and spills).
@@ -577,7 +583,7 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
           if (c >= C) continue;
           const float sig = s_sig[c * T + t];
           const float inv = 1.0f / sig;
-          const float obv = pf_ob[c];
+          const float obv = (c == 0) ? pf_ob0 : ((c == 1) ? pf_ob1 : ((c == 2) ? pf_ob2 : pf_ob3));
           float gsig = 0.f;
           for (int q = 0; q < Q; ++q) {
             const cptr W = (cptr)k.head[q] + c * S;
@@ -617,7 +623,7 @@ __global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
       for (int i = tid; i < T * S; i += NT) s_lam[i] = gi[i];
     }
 
-    prefetch(b + gridDim.x);
+    SLODE_PREFETCH(b + gridDim.x);
     if (BWD) {
       __syncthreads();
       STAMP(6);
