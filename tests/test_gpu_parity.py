@@ -324,3 +324,42 @@ def test_elbo_other_observation_layouts(layout):
     got = eng.unpack(grads)
     bad = {k: _rel(v, want[k]) for k, v in got.items() if _rel(v, want[k]) > 5e-4}
     assert not bad, bad
+
+
+def test_more_trajectories_than_workgroups():
+    """B > grid (= CUs x occupancy): every workgroup integrates several trajectories in its persistent loop, carrying the register
+    accumulators and the input prefetch across them.  Loss/gradient must equal the sum over chunks that each fit one pass, and a
+    slice must match the oracle."""
+    from structured_latent_odes_amd import engine as E
+    dev = torch.device("cuda:0")
+    ospec = O.cvs_spec(3, 3, 2, solver="rk4")
+    B, T = 2500, 86                      # 2500 trajectories over <= 1024..2048 workgroups, ragged
+    p = O.init_params(ospec, T=T)
+    g = torch.Generator().manual_seed(4)
+    p = {k: v + 0.03 * torch.randn(v.shape, generator=g) for k, v in p.items()}
+    obs, u, eps, times = O.synthetic_batch(ospec, B, T)
+    eng = E.Engine(E.cvs_spec(3, 3, 2, solver="rk4"), T, dev)
+    eng.set_times(times)
+    flat = eng.pack(p)
+    obs_d = obs.to(dev)
+    u_d, eps_d = u.to(dev), eps.to(dev)
+
+    def run(sl):
+        loss, grads = torch.zeros(1, device=dev), torch.zeros(eng.n_params, device=dev)
+        eng.elbo_step(flat, obs_d[sl], u_d[sl].contiguous(), eps_d[sl].contiguous(), loss, grads)
+        return loss.double().cpu(), grads.double().cpu()
+    l_all, g_all = run(slice(0, B))
+    parts = [run(slice(i, min(B, i + 500))) for i in range(0, B, 500)]
+    l_sum, g_sum = sum(x[0] for x in parts), sum(x[1] for x in parts)
+    assert abs((l_sum - l_all).item()) / abs(l_all.item()) < 1e-6
+    assert ((g_sum - g_all).norm() / g_all.norm()).item() < 1e-5
+    sl = slice(2400, 2432)               # trajectories handled late in the persistent loops
+    with torch.no_grad():
+        want = O.main_loss(p, ospec, obs[sl], u[sl], eps[sl], times)
+    assert abs(run(sl)[0].item() - want.item()) / abs(want.item()) < 1e-5
+    x = torch.empty(B, T, 5, device=dev)
+    loss = torch.zeros(1, device=dev)
+    eng.elbo_step(flat, obs_d, u_d, eps_d, loss, None, x_out=x)
+    with torch.no_grad():
+        _, pr = O.main_loss(p, ospec, obs[sl], u[sl], eps[sl], times, return_parts=True)
+    assert _close(x[sl], pr["dec"][0])
