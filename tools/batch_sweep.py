@@ -1,0 +1,36 @@
+"""Batch sweep: trajectories/s of the full step (ELBO fwd+bwd + Adam) vs per-GPU batch size, CVS shapes T=200."""
+import json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from structured_latent_odes_amd.configs import load_config_cvs
+from structured_latent_odes_amd.models.mechanistic_cvs import MechanisticModel
+from structured_latent_odes_amd.svi import ELBOStep, FlatAdam
+from structured_latent_odes_amd.synthetic import synthetic_batch
+from structured_latent_odes_amd.utils.utils import set_seed
+
+dev = torch.device("cuda:0")
+cfg = load_config_cvs(); cfg.update(seq_len=200, z_iext_dim=3, z_rtpr_dim=3, z_epsilon_dim=2, solver="rk4")
+set_seed(12)
+times = torch.arange(0.0, 200.0, device=dev)
+m = MechanisticModel(cfg, dev, times); b = m._bind(); eng, flat = b.engine, b.flat
+out = []
+for B in (256, 1024, 4096, 16384, 65536, 262144):
+    obs, labels, _ = synthetic_batch("cvs", min(B, 4096), 200, 3)
+    reps = B // obs.shape[0]
+    obs_d = obs.to(dev).repeat(reps, 1, 1) if reps > 1 else obs.to(dev)
+    obs_d = obs_d.permute(0, 2, 1).contiguous().permute(0, 2, 1)
+    u_d = m.labels_to_u(**{k: v.to(dev).repeat(reps, 1) for k, v in labels.items()})
+    eps_d = torch.randn(B, 8, device=dev)
+    svi = ELBOStep(eng, flat, FlatAdam(eng, flat, lr=1e-4))
+    n = max(5, min(200, 2_000_000 // B))
+    for _ in range(2):
+        for _ in range(max(3, n // 4)): svi.step_async(obs_d, eps=eps_d, u=u_d)
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n): svi.step_async(obs_d, eps=eps_d, u=u_d)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    eng.profile_enable(True); svi.step_async(obs_d, eps=eps_d, u=u_d); pr = eng.profile_read(); eng.profile_enable(False)
+    row = {"B": B, "us_per_step": 1e6 * dt / n, "traj_per_s": B * n / dt, "ode_elbo_us": 1e3 * pr["ode_elbo"],
+           "ode_frac_fp32": 1137720 * B / (pr["ode_elbo"] * 1e-3) / 157.3e12, "step_frac_fp32": 2075370 * B / (dt / n) / 157.3e12}
+    out.append(row); print(json.dumps(row), flush=True)
+json.dump(out, open("gpurun_out/batch_sweep.json", "w"), indent=1)
