@@ -3,7 +3,7 @@
 
 A "step" is one pass of the hot path over one synthetic CVS-shaped minibatch shard: encoder -> latent sample -> rk4
 (3/8-rule) latent-ODE solve over T=200 -> 3 quantile heads -> asymmetric-Laplace likelihood + latent log-probs ->
--ELBO -> exact gradient of all 96,210 hot-path parameters (one slode_elbo_step call) -> [N>1: one RCCL SUM all-reduce of the flat
+-ELBO -> exact gradient of all 96,462 parameters (one slode_elbo_step call) -> [N>1: one RCCL SUM all-reduce of the flat
 gradient + loss scalar] -> Adam (one slode_adam_step call).  Workload = BASELINE config[1] "Synthetic CVS batch=1024,
 T=200, latent_dim=8, blackbox_ode RK4" per GPU; N GPUs run N such shards (config[3]: 8 x 1024 = 8192) => weak scaling.
 Inputs are generated on the host from a seed and are resident in HBM before the timed region starts.
@@ -151,7 +151,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE config[1]: synthetic CVS, B=1024/GPU, T=200, C=3, latent_dim=8 (3,3,2), S=5, "
-                               "rk4(3/8) fixed grid dt=1, ALD 3-quantile likelihood; step = ELBO fwd+bwd (all 96,210 hot-path params) "
+                               "rk4(3/8) fixed grid dt=1, ALD 3-quantile likelihood; step = ELBO fwd+bwd (all 96,462 parameters) "
                                "+ grad all-reduce (N>1) + Adam",
                    "global_batch": world * B_PER_GPU, "T": T, "parallelism": "dp%d" % world},
         "final_loss_per_traj": final_loss / (world * B_PER_GPU),

@@ -52,8 +52,10 @@ typedef struct slode_group {
   int32_t u_off, u_dim; /* label columns [u_off, u_off + u_dim) of u[B, n_u] */
 } slode_group;
 
-/* A label head q(label | z_g) scored INSIDE the main loss at `aux_mult` x (the proc family: q_label / q_continous on the
- * replayed z, models/mechanistic_proc.py:145-146,334-353): EncoderMLP([z_dim, U, u_dim]) with one Softplus hidden layer.
+/* A label head q(label | z_g): EncoderMLP([z_dim, U, u_dim]) with one Softplus hidden layer.  Scored at `aux_mult` x by the
+ * auxiliary loss (model_meta: mechanistic_cvs.py:240-270, mechanistic_proc.py:313-353, mechanistic_challenge.py:264-291) and,
+ * when `aux_in_main` is set (the proc family: q_label / q_continous on the replayed z, mechanistic_proc.py:145-146), also
+ * inside the main loss.
  *   SLODE_AUX_SIGMOID: Bernoulli(probs = sigmoid(.));  SLODE_AUX_SOFTMAX: OneHotCategorical(probs = softmax(.));
  *   SLODE_AUX_EXPEXP:  two Exp heads [loc, unused], Laplace(loc, softplus(constant_std_*)) on the label. */
 typedef enum slode_aux_kind { SLODE_AUX_SIGMOID = 0, SLODE_AUX_SOFTMAX = 1, SLODE_AUX_EXPEXP = 2 } slode_aux_kind;
@@ -81,10 +83,11 @@ typedef struct slode_shape {
   int32_t likelihood; /* slode_likelihood                                              */
   float quantile_diff; /* config.quantile_diff (ALD only), data/cvs/config_cvs.py:48    */
   float rtol, atol;    /* dopri5 only (torchdiffeq defaults 1e-7 / 1e-9)                */
-  int32_t n_aux;       /* label heads scored inside the main loss (0 for cvs / challenge)  */
+  int32_t n_aux;       /* label heads (auxiliary loss; also the main loss iff aux_in_main)  */
   int32_t U;           /* config.u_hidden_dim (<= 32)                                      */
   float aux_mult;      /* config.aux_loss_multiplier                                       */
   slode_aux aux[SLODE_MAX_AUX];
+  int32_t aux_in_main; /* 1: the main model scores the label heads too (proc family)       */
 } slode_shape;
 
 /* Offsets (in floats) of each parameter tensor inside the flat parameter / gradient vector.
@@ -187,6 +190,16 @@ int slode_elbo_adam_step(slode_handle h, const slode_shape* s, const slode_layou
                          const float* stage_t, const float* obs, const int64_t obs_strides[3], const float* u, const float* eps,
                          float* loss_out, float* grads, void* workspace, size_t workspace_bytes, int64_t n_total, float* exp_avg,
                          float* exp_avg_sq, float lr, float beta1, float beta2, float adam_eps, int64_t step, void* stream);
+
+/* One step of the reference's SECOND SVI object, SVI(model_meta, guide_meta) (training_cvs.py:244-249,152): encoder ->
+ * group latents z_g = loc_g + scale_g * eps_g sampled in the model -> -[sum log N(z_g; loc_g, scale_g) + aux_mult * sum_heads
+ * log p(label | head(z_g))], summed over the batch, and its exact gradient (encoder and label-head parameters; every other
+ * entry of grads[0, n_params) is written as 0).  grads == NULL: loss only (evaluate_loss).  If exp_avg != NULL the Adam update
+ * of all n_total >= n_params parameters is applied by the final reduction kernel (as slode_elbo_adam_step). */
+int slode_aux_step(slode_handle h, const slode_shape* s, const slode_layout* lay, float* params, const float* obs,
+                   const int64_t obs_strides[3], const float* u, const float* eps, float* loss_out, float* grads, void* workspace,
+                   size_t workspace_bytes, int64_t n_total, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                   float adam_eps, int64_t step, void* stream);
 
 /* torch.optim.Adam step as pyro.optim.Adam applies it per parameter (training_cvs.py:226-227): in-place on flat
  * buffers.  step = 1-based step count. */

@@ -25,7 +25,7 @@ class Shape(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "T", "C", "L", "S", "H", "F", "K", "P", "Hc", "n_u", "n_groups")] + [
         ("groups", Group * MAX_GROUPS), ("method", C.c_int32), ("likelihood", C.c_int32),
         ("quantile_diff", C.c_float), ("rtol", C.c_float), ("atol", C.c_float), ("n_aux", C.c_int32), ("U", C.c_int32),
-        ("aux_mult", C.c_float), ("aux", Aux * MAX_AUX)]
+        ("aux_mult", C.c_float), ("aux", Aux * MAX_AUX), ("aux_in_main", C.c_int32)]
 
 
 class Layout(C.Structure):
@@ -42,7 +42,7 @@ class Layout(C.Structure):
 EXPORTS = ["slode_version", "slode_create", "slode_destroy", "slode_last_error", "slode_layout_init",
            "slode_num_stage_times", "slode_workspace_bytes", "slode_stage_times", "slode_encoder_conv_fwd",
            "slode_encoder_conv_bwd", "slode_ode_solve_fwd", "slode_ode_solve_bwd", "slode_decode_heads",
-           "slode_elbo_step", "slode_adam_step", "slode_profile_enable", "slode_profile_read", "slode_dynamics_eval", "slode_elbo_adam_step"]
+           "slode_elbo_step", "slode_adam_step", "slode_profile_enable", "slode_profile_read", "slode_dynamics_eval", "slode_elbo_adam_step", "slode_aux_step"]
 
 _lib = None
 
@@ -80,6 +80,8 @@ def load():
     lib.slode_adam_step.argtypes = [VP, C.c_int64, VP, VP, VP, VP, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, VP]
     lib.slode_elbo_adam_step.argtypes = [VP, P(Shape), P(Layout), VP, VP, VP, VP, I64P, VP, VP, VP, VP, VP, C.c_size_t, C.c_int64, VP, VP,
                                          C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, VP]
+    lib.slode_aux_step.argtypes = [VP, P(Shape), P(Layout), VP, VP, I64P, VP, VP, VP, VP, VP, C.c_size_t, C.c_int64, VP, VP,
+                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, VP]
     lib.slode_dynamics_eval.argtypes = [VP, P(Shape), P(Layout), VP, C.c_float, VP, VP, VP, VP]
     lib.slode_profile_enable.argtypes = [VP, C.c_int]
     lib.slode_profile_read.argtypes = [VP, P(C.c_float)]

@@ -985,7 +985,7 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   k.o_wd = lay.dyn_wd - ob; k.o_bd = lay.dyn_bd - ob; k.o_cstd = lay.cstd - ob;
   k.nseg = lay.ode_end - lay.ode_begin;
   k.npar = lay.cstd - lay.ode_begin;
-  k.n_aux = a.with_ll ? s.n_aux : 0; k.U = s.U; k.aux_mult = s.aux_mult;
+  k.n_aux = (a.with_ll && s.aux_in_main) ? s.n_aux : 0; k.U = s.U; k.aux_mult = s.aux_mult;
   for (int q = 0; q < SLODE_MAX_AUX; ++q) {
     k.aux[q] = s.aux[q];
     k.o_aux_w1[q] = lay.aux_w1[q] - ob; k.o_aux_b1[q] = lay.aux_b1[q] - ob; k.o_aux_w2[q] = lay.aux_w2[q] - ob;

@@ -347,13 +347,15 @@ struct AdamArgs { float *p, *m, *v; float lr, b1, b2, eps; int64_t step, n; };
 static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* times,
                           const float* stage_t, const float* obs, const int64_t obs_strides[3], const float* u, const float* eps,
                           float* loss_out, float* grads, float* x_out, float* z_out, void* workspace, size_t workspace_bytes,
-                          void* stream, const AdamArgs* adam) {
+                          void* stream, const AdamArgs* adam, int aux_mode = 0) {
   const char* why = check_common(h, s, lay, params);
   if (why) return fail(h, SLODE_EINVAL, "%s", why);
-  if (!times || !stage_t || !obs || !obs_strides || !eps || !loss_out || !workspace)
+  if ((!aux_mode && (!times || !stage_t)) || !obs || !obs_strides || !eps || !loss_out || !workspace)
     return fail(h, SLODE_EINVAL, "a required pointer is NULL");
+  if (aux_mode && (s->n_aux < 1 || !u)) return fail(h, SLODE_EINVAL, "the auxiliary loss needs label heads (n_aux >= 1) and labels u");
   if (s->n_groups > 0 && !u) return fail(h, SLODE_EINVAL, "u is NULL but the shape has conditional prior groups");
-  if (s->method == SLODE_DOPRI5) return fail(h, SLODE_EINVAL, "dopri5 is forward-only (slode_ode_solve_fwd); the ELBO step needs a fixed-grid method");
+  if (!aux_mode && s->method == SLODE_DOPRI5)
+    return fail(h, SLODE_EINVAL, "dopri5 is forward-only (slode_ode_solve_fwd); the ELBO step needs a fixed-grid method");
   Workspace w = carve(h, *s, *lay, workspace);
   if (workspace_bytes < w.bytes) return fail(h, SLODE_ENOSPC, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
   hipStream_t st = (hipStream_t)stream;
@@ -385,15 +387,23 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
   }
   SLODE_MARK(2);
 
-  OdeLaunch a{};
-  a.s = *s; a.lay = *lay; a.params = params; a.times = times; a.stage_t = stage_t;
-  a.obs = obs; a.sb = obs_strides[0]; a.sc = obs_strides[1]; a.st = obs_strides[2];
-  a.u = u; a.eps = eps; a.loc = w.loc; a.scale = w.scale; a.x_out = x_out; a.z_out = z_out;
-  a.g_loc = w.g_loc; a.g_scale = w.g_scale; a.slabs = w.ode_slabs; a.slab_stride = w.ode_stride; a.grid = w.ode_grid;
-  a.backward = bwd ? 1 : 0; a.with_ll = 1;
-  e = slode_launch_ode(a, st, h->err, sizeof(h->err));
-  if (e == hipErrorInvalidValue) return SLODE_EINVAL;
-  HIP_TRY(h, e);
+  int n_slabs = w.ode_grid;
+  if (aux_mode) {
+    AuxLaunch al{*s, *lay, params, w.loc, w.scale, eps, u, w.g_loc, w.g_scale, w.ode_slabs, w.ode_stride,
+                 w.ode_grid < 512 ? w.ode_grid : 512, bwd ? 1 : 0};
+    n_slabs = al.grid;
+    HIP_TRY(h, slode_launch_aux(al, st));
+  } else {
+    OdeLaunch a{};
+    a.s = *s; a.lay = *lay; a.params = params; a.times = times; a.stage_t = stage_t;
+    a.obs = obs; a.sb = obs_strides[0]; a.sc = obs_strides[1]; a.st = obs_strides[2];
+    a.u = u; a.eps = eps; a.loc = w.loc; a.scale = w.scale; a.x_out = x_out; a.z_out = z_out;
+    a.g_loc = w.g_loc; a.g_scale = w.g_scale; a.slabs = w.ode_slabs; a.slab_stride = w.ode_stride; a.grid = w.ode_grid;
+    a.backward = bwd ? 1 : 0; a.with_ll = 1;
+    e = slode_launch_ode(a, st, h->err, sizeof(h->err));
+    if (e == hipErrorInvalidValue) return SLODE_EINVAL;
+    HIP_TRY(h, e);
+  }
   SLODE_MARK(3);
 
   if (bwd && folded) {
@@ -403,7 +413,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     SLODE_MARK(5);
     HIP_TRY(h, slode_launch_fold_chain(fl, st));
     SLODE_MARK(6);
-    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, w.small_slabs, w.small_stride, w.small_grid,
+    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, n_slabs, w.small_slabs, w.small_stride, w.small_grid,
                    w.conv_slabs, s->Hc, grads, loss_out, 0, w.ode_part, w.small_part, 1};
     if (adam) { r.adam_p = adam->p; r.adam_m = adam->m; r.adam_v = adam->v; r.adam_lr = adam->lr; r.adam_b1 = adam->b1;
                 r.adam_b2 = adam->b2; r.adam_eps = adam->eps; r.adam_step = adam->step; r.adam_n = adam->n; }
@@ -416,7 +426,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     HIP_TRY(h, slode_launch_enc_bwd(eb, st, prof ? h->ev[4] : nullptr));
     SLODE_MARK(5);
     SLODE_MARK(6);
-    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, w.small_slabs, w.small_stride, w.small_grid,
+    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, n_slabs, w.small_slabs, w.small_stride, w.small_grid,
                    w.lin_slabs, w.lin_splitk, grads, loss_out, 1, w.ode_part, w.small_part, 0};
     if (adam) { r.adam_p = adam->p; r.adam_m = adam->m; r.adam_v = adam->v; r.adam_lr = adam->lr; r.adam_b1 = adam->b1;
                 r.adam_b2 = adam->b2; r.adam_eps = adam->eps; r.adam_step = adam->step; r.adam_n = adam->n; }
@@ -424,7 +434,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     SLODE_MARK(7);
     if (prof) h->ev_valid = 1;
   } else {
-    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, w.ode_grid, nullptr, 0, 0, nullptr, 0, nullptr, loss_out, 0, w.ode_part, nullptr, 0};
+    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, n_slabs, nullptr, 0, 0, nullptr, 0, nullptr, loss_out, 0, w.ode_part, nullptr, 0};
     HIP_TRY(h, slode_launch_reduce(r, st));
   }
   return SLODE_OK;
@@ -447,6 +457,18 @@ int slode_elbo_adam_step(slode_handle h, const slode_shape* s, const slode_layou
   const AdamArgs ad{params, exp_avg, exp_avg_sq, lr, beta1, beta2, adam_eps, step, n_total};
   return elbo_step_impl(h, s, lay, params, times, stage_t, obs, obs_strides, u, eps, loss_out, grads, nullptr, nullptr, workspace,
                         workspace_bytes, stream, &ad);
+}
+
+int slode_aux_step(slode_handle h, const slode_shape* s, const slode_layout* lay, float* params, const float* obs,
+                   const int64_t obs_strides[3], const float* u, const float* eps, float* loss_out, float* grads, void* workspace,
+                   size_t workspace_bytes, int64_t n_total, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                   float adam_eps, int64_t step, void* stream) {
+  const bool with_adam = exp_avg != nullptr;
+  if (with_adam && (!grads || !exp_avg_sq || step < 1 || !lay || n_total < lay->n_params))
+    return fail(h, SLODE_EINVAL, "slode_aux_step with Adam needs grads, both moments, step >= 1 and n_total >= layout n_params");
+  const AdamArgs ad{params, exp_avg, exp_avg_sq, lr, beta1, beta2, adam_eps, step, n_total};
+  return elbo_step_impl(h, s, lay, params, nullptr, nullptr, obs, obs_strides, u, eps, loss_out, grads, nullptr, nullptr, workspace,
+                        workspace_bytes, stream, with_adam ? &ad : nullptr, 1);
 }
 
 int slode_dynamics_eval(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, float t,

@@ -141,6 +141,16 @@ hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream);
 hipError_t slode_launch_gemm_gpre_x(const float* g_pre, const float* x, float* slabs, int B, int Hc, int N, int splitk, hipStream_t stream);
 int slode_fold_small_count(const slode_shape& s);
 
+struct AuxLaunch {
+  slode_shape s;
+  slode_layout lay;
+  const float* params;
+  const float *loc, *scale, *eps, *u;
+  float *g_loc, *g_scale, *slabs;
+  int slab_stride, grid, backward;
+};
+hipError_t slode_launch_aux(const AuxLaunch& a, hipStream_t stream);
+
 #define SLODE_REDUCE_GROUPS 16
 struct ReduceLaunch {
   slode_shape s;

@@ -24,8 +24,8 @@ class PriorGroup:
 
 @dataclass
 class AuxHead:
-    """A label head scored inside the MAIN loss (proc family): `prefix` = reference attribute (e.g. 'q_aR_given_z_aR'),
-    kind in sigmoid | softmax | expexp; `std_key` = the scalar std parameter of an expexp (Laplace) head."""
+    """A label head q(label | z_g) (auxiliary loss; also the main loss for the proc family): `prefix` = reference attribute
+    (e.g. 'q_aR_given_z_aR'), kind in sigmoid | softmax | expexp; `std_key` = the scalar std parameter of an expexp head."""
     prefix: str
     kind: str
     z_off: int
@@ -53,7 +53,8 @@ class ModelSpec:
     cnn_hidden_dim: int = 50
     solver: str = "midpoint"
     quantile_diff: float = 0.475
-    aux_in_main: List[AuxHead] = field(default_factory=list)
+    aux_heads: List[AuxHead] = field(default_factory=list)
+    labels_in_main: bool = False   # proc: the main model also scores the label heads (mechanistic_proc.py:145-146)
     u_hidden_dim: int = 25
     aux_mult: float = 46.0
     rtol: float = 1e-7      # dopri5 only (torchdiffeq defaults)
@@ -107,8 +108,8 @@ class Engine:
                         F=sp.n_filters, K=sp.filter_size, P=sp.pool_size, Hc=sp.cnn_hidden_dim, n_u=sp.n_u,
                         n_groups=len(sp.prior_groups), method=L.METHODS[sp.solver],
                         likelihood=L.GAUSS if sp.gauss else L.ALD, quantile_diff=sp.quantile_diff, rtol=sp.rtol, atol=sp.atol,
-                        n_aux=len(sp.aux_in_main), U=sp.u_hidden_dim, aux_mult=sp.aux_mult)
-            for i, a in enumerate(sp.aux_in_main):
+                        n_aux=len(sp.aux_heads), U=sp.u_hidden_dim, aux_mult=sp.aux_mult, aux_in_main=int(sp.labels_in_main))
+            for i, a in enumerate(sp.aux_heads):
                 s.aux[i] = L.Aux(L.AUX_KINDS[a.kind], a.z_off, a.z_dim, a.u_off, a.u_dim)
             for i, g in enumerate(sp.prior_groups):
                 s.groups[i] = L.Group(g.z_off, g.z_dim, g.u_off, g.u_dim)
@@ -138,7 +139,7 @@ class Engine:
         for i, hn in enumerate(sp.head_names):
             t.append(("decoder.%s.0.weight" % hn, lay.head_w[i], (C_, S)))
         U = sp.u_hidden_dim
-        for i, a in enumerate(sp.aux_in_main):
+        for i, a in enumerate(sp.aux_heads):
             t += [(a.prefix + ".sequential_mlp.1.module.weight", lay.aux_w1[i], (U, a.z_dim)),
                   (a.prefix + ".sequential_mlp.1.module.bias", lay.aux_b1[i], (U,))]
             if a.kind == "expexp":
@@ -291,6 +292,18 @@ class Engine:
             self._stream()))
         return loss_out
 
+    def aux_step(self, params, obs, u, eps, loss_out, grads=None, adam=None):
+        """-ELBO of the auxiliary loss (model_meta) and its gradient; `adam` = (exp_avg, exp_avg_sq, lr, step, betas, eps) fuses
+        the Adam update into the final reduction."""
+        B = obs.shape[0]
+        ws = self.workspace(B)
+        m, v, lr, step, betas, aeps = adam if adam is not None else (None, None, 0.0, 1, (0.9, 0.999), 1e-8)
+        _check(self.lib, self.handle, self.lib.slode_aux_step(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(obs), self._obs_strides(obs), self._p(u),
+            self._p(eps), self._p(loss_out), self._p(grads), self._p(ws), ws.numel() * 4, params.numel(), self._p(m), self._p(v), float(lr),
+            float(betas[0]), float(betas[1]), float(aeps), int(step), self._stream()))
+        return loss_out
+
     def adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-8):
         _check(self.lib, self.handle, self.lib.slode_adam_step(
             self.handle, params.numel(), self._p(params), self._p(grads), self._p(exp_avg), self._p(exp_avg_sq),
@@ -311,13 +324,17 @@ def cvs_spec(z_iext=5, z_rtpr=5, z_eps=5, gauss=False, solver="midpoint", quanti
     """data/cvs/config_cvs.py:6-52; u = [iext, rtpr] columns (models/mechanistic_cvs.py:131-135)."""
     return ModelSpec("cvs", gauss, 3, z_iext + z_rtpr + z_eps, z_eps, 2,
                      [PriorGroup("p_z_iext_given_iext", 0, z_iext, 0, 1), PriorGroup("p_z_rtprs_given_rtprs", z_iext, z_rtpr, 1, 1)],
-                     solver=solver, quantile_diff=quantile_diff)
+                     solver=solver, quantile_diff=quantile_diff,
+                     aux_heads=[AuxHead("q_iext_given_z_iext", "sigmoid", 0, z_iext, 0, 1),
+                                AuxHead("q_rtpr_given_z_rtpr", "sigmoid", z_iext, z_rtpr, 1, 1)])
 
 
 def challenge_spec(z_shed=5, z_symp=5, z_eps=5, gauss=False, solver="midpoint", quantile_diff=0.475) -> ModelSpec:
     """data/challenge/config_challenge.py; u = cat(symptoms, shedding) (models/mechanistic_challenge.py:167)."""
     return ModelSpec("challenge", gauss, 4, z_shed + z_symp + z_eps, z_eps, 2, [PriorGroup("p_z_u_given_u", 0, z_shed + z_symp, 0, 2)],
-                     solver=solver, quantile_diff=quantile_diff)
+                     solver=solver, quantile_diff=quantile_diff,
+                     aux_heads=[AuxHead("q_shedding_given_z_shedding", "sigmoid", 0, z_shed, 1, 1),
+                                AuxHead("q_symptom_given_z_symptom", "sigmoid", z_shed, z_symp, 0, 1)])
 
 
 def proc_spec(z_g=10, z_eps=10, gauss=False, solver="midpoint", quantile_diff=0.475) -> ModelSpec:
@@ -326,4 +343,4 @@ def proc_spec(z_g=10, z_eps=10, gauss=False, solver="midpoint", quantile_diff=0.
            AuxHead("q_C12_given_z_C12", "expexp", 2 * z_g, z_g, 7, 1, "constant_std_C_12"),
            AuxHead("q_C6_given_z_C6", "expexp", 3 * z_g, z_g, 8, 1, "constant_std_C_6")]
     return ModelSpec("proc", gauss, 4, 4 * z_g + z_eps, z_eps, 9, [PriorGroup("p_z_u_given_u", 0, 4 * z_g, 0, 9)],
-                     ode_state_dim=8, solver=solver, quantile_diff=quantile_diff, aux_in_main=aux)
+                     ode_state_dim=8, solver=solver, quantile_diff=quantile_diff, aux_heads=aux, labels_in_main=True)

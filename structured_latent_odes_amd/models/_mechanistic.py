@@ -94,12 +94,11 @@ class MechanisticBase(nn.Module):
             groups.append(PriorGroup(attr, self.z_off[zgroups[0]], sum(self.z_dims[g] for g in zgroups),
                                      self.u_off[labels[0]], sum(self.label_dims[l] for l in labels)))
         aux = []
-        if self.LABELS_IN_MAIN:
-            for attr, group, label, kind in self.AUX:
-                aux.append(AuxHead(attr, kind, self.z_off[group], self.z_dims[group], self.u_off[label], self.label_dims[label],
-                                   "constant_std_C_12" if label == "C12" else ("constant_std_C_6" if label == "C6" else "")))
+        for attr, group, label, kind in self.AUX:
+            aux.append(AuxHead(attr, kind, self.z_off[group], self.z_dims[group], self.u_off[label], self.label_dims[label],
+                               "constant_std_C_12" if label == "C12" else ("constant_std_C_6" if label == "C6" else "")))
         return ModelSpec(self.FAMILY, self.GAUSS, self.obs_dim, self.latent_dim, self.z_epsilon_dim, self.n_u, groups,
-                         aux_in_main=aux, u_hidden_dim=self.u_hidden_dim, aux_mult=self.aux_loss_multiplier,
+                         aux_heads=aux, labels_in_main=self.LABELS_IN_MAIN, u_hidden_dim=self.u_hidden_dim, aux_mult=self.aux_loss_multiplier,
                          ode_state_dim=cfg.ode_state_dim, ode_hidden_dim=cfg.ode_hidden_dim, n_filters=cfg.n_filters,
                          filter_size=cfg.filter_size, pool_size=cfg.pool_size, cnn_hidden_dim=cfg.cnn_hidden_dim,
                          solver=cfg.solver, quantile_diff=cfg.quantile_diff)
@@ -114,10 +113,10 @@ class MechanisticBase(nn.Module):
                 net = getattr(self, attr)
                 for k, p in net.named_parameters():
                     named["%s.%s" % (attr, k)] = p
-            if self.LABELS_IN_MAIN:     # these heads are part of the main loss => inside the kernel's layout
-                for attr, _, _, _ in self.AUX:
-                    for k, p in getattr(self, attr).named_parameters():
-                        named["%s.%s" % (attr, k)] = p
+            for attr, _, _, _ in self.AUX:   # label heads: auxiliary-loss kernel (and the main loss for proc) => in the layout
+                for k, p in getattr(self, attr).named_parameters():
+                    named["%s.%s" % (attr, k)] = p
+            if self.FAMILY == "proc":
                 named["constant_std_C_12"], named["constant_std_C_6"] = self.constant_std_C_12, self.constant_std_C_6
             hot = set(id(p) for p in named.values())
             extra = [p for p in self.parameters() if id(p) not in hot]

@@ -112,58 +112,47 @@ class Trace_ELBO:
 
 
 class AuxStep:
-    """-ELBO of SVI(model_meta, guide_meta) (mechanistic_cvs.py:240-276): encoder again (HIP, through the module-level
-    autograd functions), group latents sampled in the model, labels scored at aux_loss_multiplier.  SURVEY row N1: this
-    composition (HIP encoder fwd/bwd + a 176-parameter torch MLP per head) is functional, not yet fused."""
+    """-ELBO of SVI(model_meta, guide_meta) (mechanistic_cvs.py:240-276): one ``slode_aux_step`` call (encoder forward -> group
+    latents sampled in the model + label heads at aux_loss_multiplier -> encoder backward -> reduction [+ Adam]), all HIP."""
 
-    def __init__(self, owner, optimizer: Optional[FlatAdam]):
-        self.owner, self.optimizer = owner, optimizer
+    def __init__(self, owner, optimizer: Optional[FlatAdam], process_group=None):
+        self.owner, self.optimizer, self.pg = owner, optimizer, process_group
         b = owner._bind()
-        self.gbuf = torch.zeros(b.n_total, dtype=torch.float32, device=b.flat.device)
+        self.engine, self.params = b.engine, b.flat
+        self.world = torch.distributed.get_world_size(process_group) if (
+            torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        self.gbuf = torch.zeros(b.n_total + 1, dtype=torch.float32, device=b.flat.device)
+        self.grads, self.loss = self.gbuf[:b.n_total], self.gbuf[b.n_total:]
 
-    def _loss(self, observations, labels, eps):
-        from torch.distributions import Bernoulli, Laplace, Normal, OneHotCategorical
+    def _inputs(self, observations, eps, labels):
         o = self.owner
-        loc, scale = o.encoder.forward(observations)
-        lp = loc.new_zeros(())
-        for attr, group, label, kind in o.AUX:
-            lg, sg = o._z_group(loc, group), o._z_group(scale, group)
-            zg = lg + sg * o._z_group(eps, group)
-            lp = lp + Normal(lg, sg).log_prob(zg).sum()
-            lab = labels[label].reshape(zg.shape[0], -1).to(torch.float32)
-            out = getattr(o, attr)(zg)
-            if kind == "sigmoid":
-                term = Bernoulli(probs=out).log_prob(lab).sum()
-            elif kind == "softmax":
-                term = OneHotCategorical(probs=out).log_prob(lab).sum()
-            else:
-                std = o.softplus(o.constant_std_C_12 if label == "C12" else o.constant_std_C_6)
-                term = Laplace(out[0], std).log_prob(lab).sum()
-            lp = lp + o.aux_loss_multiplier * term
-        return -lp
+        if eps is None:
+            eps = o.draw_eps(observations.shape[0], self.params.device)
+        return observations, o.labels_to_u(**labels), eps
+
+    def step_async(self, observations, eps=None, **labels):
+        obs, u, eps = self._inputs(observations, eps, labels)
+        opt = self.optimizer
+        if self.world == 1 and opt is not None:
+            opt.t += 1
+            self.engine.aux_step(self.params, obs, u, eps, self.loss, self.grads, adam=(opt.exp_avg, opt.exp_avg_sq, opt.lr, opt.t, opt.betas, opt.eps))
+            return self.loss
+        self.engine.aux_step(self.params, obs, u, eps, self.loss, self.grads)
+        if self.world > 1:
+            torch.distributed.all_reduce(self.gbuf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        if opt is not None:
+            opt.step(self.grads)
+        return self.loss
 
     def step(self, observations, eps=None, **labels) -> float:
-        o = self.owner
-        b = o._bind()
-        if eps is None:
-            eps = o.draw_eps(observations.shape[0], b.flat.device)
-        self.gbuf.zero_()
-        b.grad_views(self.gbuf)
-        loss = self._loss(observations, labels, eps)
-        loss.backward()
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            torch.distributed.all_reduce(self.gbuf, op=torch.distributed.ReduceOp.SUM)
-        if self.optimizer is not None:
-            self.optimizer.step(self.gbuf)
-        return float(loss.item())
+        return float(self.step_async(observations, eps, **labels).item())
 
     def evaluate_loss(self, observations, eps=None, **labels) -> float:
-        o = self.owner
-        b = o._bind()
-        if eps is None:
-            eps = o.draw_eps(observations.shape[0], b.flat.device)
-        with torch.no_grad():
-            return float(self._loss(observations, labels, eps).item())
+        obs, u, eps = self._inputs(observations, eps, labels)
+        self.engine.aux_step(self.params, obs, u, eps, self.loss, None)
+        if self.world > 1:
+            torch.distributed.all_reduce(self.loss, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        return float(self.loss.item())
 
 
 class SVI:

@@ -363,3 +363,26 @@ def test_more_trajectories_than_workgroups():
     with torch.no_grad():
         _, pr = O.main_loss(p, ospec, obs[sl], u[sl], eps[sl], times, return_parts=True)
     assert _close(x[sl], pr["dec"][0])
+
+
+def test_aux_step_matches_oracle(ctx):
+    """slode_aux_step (the second SVI object: model_meta / guide_meta) vs the oracle's aux_loss and its autograd gradient."""
+    eng, dev = ctx["eng"], ctx["dev"]
+    loss = torch.zeros(1, device=dev)
+    grads = torch.full((eng.n_params,), float("nan"), device=dev)
+    eng.aux_step(ctx["flat"], ctx["obs_d"], ctx["u_d"], ctx["eps_d"], loss, grads)
+    q = {k: v.double().requires_grad_(True) for k, v in ctx["p"].items()}
+    want = O.aux_loss(q, ctx["ospec"], ctx["obs"].double(), ctx["u"].double(), ctx["eps"].double())
+    want.backward()
+    assert abs(loss.item() - want.item()) / abs(want.item()) < 1e-5, (loss.item(), want.item())
+    assert torch.isfinite(grads).all()
+    got = eng.unpack(grads)
+    for k, v in got.items():
+        w = q[k].grad if q[k].grad is not None else torch.zeros_like(q[k])
+        if float(w.abs().max()) == 0.0:
+            assert float(v.abs().max()) == 0.0, k
+        else:
+            assert _rel(v, w) < 5e-4, (k, _rel(v, w))
+    loss2 = torch.zeros(1, device=dev)
+    eng.aux_step(ctx["flat"], ctx["obs_d"], ctx["u_d"], ctx["eps_d"], loss2, None)      # evaluate_loss
+    assert loss2.item() == loss.item()
