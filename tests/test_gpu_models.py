@@ -187,36 +187,15 @@ def test_adam_kernel_matches_torch_adam():
     assert (flat.cpu() - ref.detach()).abs().max().item() < 1e-6
 
 
-def test_training_entry_point_runs_and_learns():
-    import training_cvs as tc
+@pytest.mark.parametrize("family", ["cvs", "challenge", "proc"])
+def test_training_entry_points_run(family):
+    import importlib
+    tc = importlib.import_module("training_" + family)
     cfg = tc.load_config()
-    cfg.num_epochs, cfg.mini_batch_size = 3, 64
-    var_model, best_model, best_epoch = tc.train(cfg, batches_per_epoch=4)
-    assert 0 <= best_epoch <= 3
+    cfg.num_epochs, cfg.mini_batch_size = 2, 48
+    if family == "proc":
+        cfg.solver = "rk4"
+    var_model, best_model, best_epoch = tc.train(cfg, batches_per_epoch=3)
+    assert 0 <= best_epoch <= 2
     assert all(torch.isfinite(p).all() for p in var_model.parameters())
-
-
-def test_unfused_step_path_equals_fused_adam_path():
-    """At N>1 the stepper runs slode_elbo_step -> all_reduce -> slode_adam_step; at N=1 the fused slode_elbo_adam_step.  Both must
-    leave bit-identical parameters (same arithmetic), which also covers the data-parallel code path on one GPU."""
-    from structured_latent_odes_amd.svi import ELBOStep, FlatAdam
-    outs = []
-    for fused in (True, False):
-        m, cfg, batch, ospec, dev = _cvs(solver="rk4", T=100, B=40)
-        b = m._bind()
-        svi = ELBOStep(b.engine, b.flat, FlatAdam(b.engine, b.flat, lr=1e-3))
-        if not fused:
-            svi.world = 2                     # take the unfused branch ...
-            import torch.distributed as dist
-            real = dist.all_reduce
-            dist.all_reduce = lambda t, **kw: t   # ... with the collective stubbed to the identity (single process)
-        try:
-            eps = torch.randn(40, m.latent_dim, generator=torch.Generator().manual_seed(1)).to(dev)
-            u = m.labels_to_u(iext=batch["iext"], rtpr=batch["rtpr"])
-            losses = [svi.step(batch["observations"], eps=eps, u=u) for _ in range(3)]
-        finally:
-            if not fused:
-                dist.all_reduce = real
-        outs.append((losses, b.flat.clone()))
-    assert outs[0][0] == outs[1][0]
-    assert torch.equal(outs[0][1], outs[1][1])
+    assert all(torch.isfinite(p).all() for p in best_model.parameters())

@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
-"""Entry point mirroring the reference's ``training_cvs.py`` (``train(config)``, ``run_batch``, ``batch_to_device``,
+"""Entry point mirroring the reference's ``training_proc.py`` (``train(config)``, ``run_batch``, ``batch_to_device``,
 ``input_pred_stats``) on the slode engine: both ``SVI`` objects are :class:`structured_latent_odes_amd.svi.SVI` (HIP ELBO / aux
-step + HIP Adam) instead of Pyro's.  Synthetic CVS-shaped batches unless a loader is supplied.
+step + HIP Adam) instead of Pyro's.  Synthetic proc-shaped batches unless a loader is supplied.
 
-    python training_cvs.py [--epochs N] [--batches-per-epoch M]
+    python training_proc.py [--epochs N] [--batches-per-epoch M]
 """
 from structured_latent_odes_amd import training as _t
-from structured_latent_odes_amd.configs import load_config_cvs as load_config
-from structured_latent_odes_amd.models.mechanistic_cvs import MechanisticModel
-from structured_latent_odes_amd.models.mechanistic_cvs_Gauss import MechanisticModelGauss
+from structured_latent_odes_amd.configs import load_config_proc as load_config
+from structured_latent_odes_amd.models.mechanistic_proc import MechanisticModel
+from structured_latent_odes_amd.models.mechanistic_proc_Gauss import MechanisticModelGauss
 
-FAMILY = "cvs"
+FAMILY = "proc"
 
 
 def batch_to_device(d, device):
