@@ -258,8 +258,9 @@ __device__ __forceinline__ void wave_affine_scan(const float* __restrict__ s_A, 
   }
 }
 
+// S = 8 carries 60% more live state per thread: its instantiations trade one wave/SIMD for a 168-VGPR budget (T <= 768)
 template <int S, int H, bool BWD>
-__global__ void __launch_bounds__(1024) ode_elbo_kernel(const OdeK k) {
+__global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, NT = blockDim.x;
   const int T = k.T, C = k.C, L = k.L, R = k.R, Q = k.Q;
@@ -1004,6 +1005,10 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
     return hipErrorInvalidValue;
   }
   const bool bwd = a.backward != 0;
+  if (s.S > 5 && nthreads > 768) {
+    snprintf(err, errlen, "ode kernel: ode_state_dim %d supports at most 768 time points (got T=%d)", s.S, s.T);
+    return hipErrorInvalidValue;
+  }
   if (s.H == 25 && s.S == 5) return launch_sh<5, 25>(k, a.grid, nthreads, lds, bwd, stream);
   if (s.H == 25 && s.S == 8) return launch_sh<8, 25>(k, a.grid, nthreads, lds, bwd, stream);
   snprintf(err, errlen, "ode kernel is instantiated for (ode_state_dim, ode_hidden_dim) in {(5,25),(8,25)}; got (%d,%d)", s.S, s.H);
