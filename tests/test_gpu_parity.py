@@ -386,3 +386,35 @@ def test_aux_step_matches_oracle(ctx):
     loss2 = torch.zeros(1, device=dev)
     eng.aux_step(ctx["flat"], ctx["obs_d"], ctx["u_d"], ctx["eps_d"], loss2, None)      # evaluate_loss
     assert loss2.item() == loss.item()
+
+
+def test_abi_error_paths():
+    """Status-code error convention of the C ABI: bad arguments -> SLODE_EINVAL / SLODE_ENOSPC with a message, no crash."""
+    import ctypes as C
+    from structured_latent_odes_amd import _lib as L, engine as E
+    dev = torch.device("cuda:0")
+    eng = E.Engine(E.cvs_spec(3, 3, 2, solver="rk4"), 100, dev)
+    eng.set_times(torch.arange(100.0))
+    lib, h = eng.lib, eng.handle
+    B = 8
+    flat = torch.zeros(eng.n_params, device=dev)
+    obs = torch.rand(B, 100, 3, device=dev).permute(0, 2, 1)
+    u, eps, loss, grads = torch.zeros(B, 2, device=dev), torch.zeros(B, 8, device=dev), torch.zeros(1, device=dev), torch.zeros(eng.n_params, device=dev)
+    ws = eng.workspace(B)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    strides = (C.c_int64 * 3)(*obs.stride())
+    args = lambda **kw: [h, C.byref(eng.shape(B)), C.byref(eng.layout), kw.get("params", p(flat)), p(eng._times), p(eng._stage_t), p(obs), strides,
+                         p(u), p(eps), p(loss), p(grads), None, None, p(ws), kw.get("ws_bytes", ws.numel() * 4), None]
+    assert lib.slode_elbo_step(*args()) == 0
+    assert lib.slode_elbo_step(*args(params=None)) == -1 and b"NULL" in lib.slode_last_error(h)
+    assert lib.slode_elbo_step(*args(ws_bytes=1024)) == -3 and b"workspace" in lib.slode_last_error(h)
+    bad = eng.shape(B).__class__.from_buffer_copy(eng.shape(B))
+    bad.S = 7                                   # no kernel instantiation for ode_state_dim 7
+    a = args(); a[1] = C.byref(bad)
+    assert lib.slode_elbo_step(*a) == -1 and b"instantiated" in lib.slode_last_error(h)
+    bad2 = eng.shape(B).__class__.from_buffer_copy(eng.shape(B))
+    bad2.method = L.DOPRI5
+    a = args(); a[1] = C.byref(bad2)
+    assert lib.slode_elbo_step(*a) == -1 and b"forward-only" in lib.slode_last_error(h)
+    assert lib.slode_adam_step(h, 10, p(flat), p(grads), p(flat), p(flat), 1e-3, 0.9, 0.999, 1e-8, 0, None) == -1   # step < 1
+    assert lib.slode_elbo_step(*args()) == 0 and torch.isfinite(loss).all()      # the handle stays usable after errors
