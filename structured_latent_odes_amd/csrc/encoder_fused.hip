@@ -17,6 +17,12 @@
 typedef const __attribute__((address_space(4))) float* cptr;
 
 #ifdef SLODE_STAMPS
+__device__ unsigned long long g_stamps_fold[32];
+#define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps_fold[i] = wall_clock64(); } while (0)
+extern "C" int slode_debug_stamps_fold(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_fold), sizeof(unsigned long long) * 32);
+}
+#else
 #define STAMP(i) do { } while (0)
 #endif
 
@@ -49,6 +55,7 @@ __global__ void __launch_bounds__(256) weff_kernel(const FoldK k) {
   __shared__ float s_wp[SLODE_MAX_F * SLODE_MAX_C * JM];
   const int tid = threadIdx.x, J = k.J, C = k.C, K = k.K;
   const float fP = (float)k.P;
+  STAMP(0);
   // w'[f][c][j] = (1/P) * sum_{k + p = j} w[f][c][k]   (rows padded to JM, zero beyond J)
   for (int e = tid; e < k.F * C * JM; e += 256) {
     const int j = e % JM, fc = e / JM;
@@ -62,6 +69,7 @@ __global__ void __launch_bounds__(256) weff_kernel(const FoldK k) {
     if (blockIdx.x == 0 && j < J) k.wprime[fc * J + j] = s;
   }
   __syncthreads();
+  STAMP(1);
   const int n_w = k.Hc * k.CT;
   const int nb_w = (n_w + 255) / 256;
   if ((int)blockIdx.x < nb_w) {
@@ -85,6 +93,7 @@ __global__ void __launch_bounds__(256) weff_kernel(const FoldK k) {
       }
     }
     if ((int)blockIdx.x * 256 + tid < n_w) k.weff[e] = acc0 + acc1;
+    STAMP(2);
   } else {
     // one wave per hidden unit m: rowsum[m][f] for every f, then b_eff[m]
     const int m = ((int)blockIdx.x - nb_w) * 4 + (tid >> 6), lane = tid & 63;
@@ -124,6 +133,7 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const FoldK k) {
   float* s_hw = s_hid + TBE * 64;    // [2][L][Hc]
   float* s_be = s_hw + 2 * L * Hc;   // [64] b_eff
   const int b0 = blockIdx.x * TBE;
+  STAMP(8);
   for (int e = tid; e < TBE * CT; e += NT) {
     const int tb = e / CT;
     s_x[e] = k.x[(long long)min(b0 + tb, k.B - 1) * CT + (e - tb * CT)];
@@ -131,6 +141,7 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const FoldK k) {
   for (int e = tid; e < 2 * L * Hc; e += NT) s_hw[e] = (e < L * Hc) ? k.zloc_w[e] : k.zls_w[e - L * Hc];
   if (tid < Hc) s_be[tid] = k.beff[tid];
   __syncthreads();
+  STAMP(9);
   {
     const int wave = tid >> 6, lane = tid & 63, nw = NT >> 6;
     const int ngroups = (Hc + RB - 1) / RB;
@@ -193,6 +204,7 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const FoldK k) {
     }
   }
   __syncthreads();
+  STAMP(10);
   for (int e = tid; e < TBE * L * 2; e += NT) {
     const int which = e / (TBE * L), r = e - which * (TBE * L);
     const int tb = r / L, l = r - tb * L;
@@ -205,6 +217,7 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const FoldK k) {
       else k.loc[(long long)(b0 + tb) * L + l] = acc;
     }
   }
+  STAMP(11);
 }
 
 // ---- backward part 1: heads + tanh -> g_pre; small slab = [lin_b Hc][zloc_w L*Hc][zloc_b L][zls_w L*Hc][zls_b L] -----------
@@ -276,93 +289,98 @@ __global__ void __launch_bounds__(256) enc_bwd2_kernel(const FoldK k) {
 }
 
 // ---- backward part 3: chain rule from G = dLoss/dW_eff back to lin.weight (final) and conv.{weight,bias} (per-m partials) ---
-// Workgroup (m, fp): hidden unit m, filters f in [fp*FPW, fp*FPW + FPW).
-constexpr int FPW = 2;    // filters per workgroup
-constexpr int QCH = 3;    // q-chunks for the w' partial sums
+// One 1024-thread workgroup per hidden unit m.  G's columns [0, CT) are dLoss/dW_eff[m][:], column CT is g_beff[m] = sum_b g_pre[b][m]
+// (the MFMA GEMM appends a ones-column to X), both summed here over the split-K partials in fixed order.
+constexpr int CNT = 1024;
+constexpr int QCH = 16;   // q-chunks for the w' partial sums
 template <int C, int JM>
-__global__ void __launch_bounds__(256) enc_chain_kernel(const FoldK k) {
+__global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, NT = blockDim.x, m = blockIdx.x, f0 = blockIdx.y * FPW;
-  const int CT = k.CT, J = k.J, K = k.K, F = k.F, n_pool = k.n_pool, FQ = k.FQ, T = k.T;
-  float* s_G = smem;                        // [CT]          G[m][:] summed over the split-K partials
-  float* s_wl = s_G + CT;                   // [FPW][n_pool] lin.weight[m][f-block]
-  float* s_wp = s_wl + FPW * n_pool;        // [FPW][C][JM]  w' (zero padded)
-  float* s_pm = s_wp + FPW * C * JM;        // [QCH][FPW][C][JM] partial dLoss/dw'
-  float* s_red = s_pm + QCH * FPW * C * JM; // [8]
-  for (int i = tid; i < CT; i += NT) {
+  const int tid = threadIdx.x, NT = blockDim.x, m = blockIdx.x;
+  const int CT = k.CT, J = k.J, K = k.K, F = k.F, n_pool = k.n_pool, FQ = k.FQ, T = k.T, GN = CT + 1;
+  float* s_G = smem;                          // [CT + 1]
+  float* s_wl = s_G + ((GN + 3) & ~3);        // [FQ]          lin.weight[m][:]
+  float* s_wp = s_wl + ((FQ + 3) & ~3);       // [F][C][JM]    w' (zero padded)
+  float* s_pm = s_wp + F * C * JM;            // [QCH][F][C][JM] partial dLoss/dw'
+  STAMP(16);
+  for (int i = tid; i < GN; i += NT) {
     float a = 0.f;
-    for (int s = 0; s < k.n_gslabs; ++s) a += k.gslabs[((long long)s * k.Hc + m) * CT + i];   // fixed order
+    for (int s = 0; s < k.n_gslabs; ++s) a += k.gslabs[((long long)s * k.Hc + m) * GN + i];   // fixed order
     s_G[i] = a;
   }
-  for (int i = tid; i < FPW * n_pool; i += NT) {
-    const int fl = i / n_pool, q = i - fl * n_pool;
-    s_wl[i] = (f0 + fl < F) ? k.lin_w[(long long)m * FQ + (f0 + fl) * n_pool + q] : 0.f;
+  for (int i = tid; i < FQ; i += NT) s_wl[i] = k.lin_w[(long long)m * FQ + i];
+  for (int i = tid; i < F * C * JM; i += NT) {
+    const int j = i % JM, fc = i / JM;
+    s_wp[i] = (j < J) ? k.wprime[fc * J + min(j, J - 1)] : 0.f;
   }
-  for (int i = tid; i < FPW * C * JM; i += NT) {
-    const int j = i % JM, fc = i / JM, c = fc % C, fl = fc / C;
-    s_wp[i] = (j < J && f0 + fl < F) ? k.wprime[((f0 + fl) * C + c) * J + j] : 0.f;
-  }
-  float gb = 0.f;                           // g_beff[m] = sum_b g_pre[b][m]
-  for (int b = tid; b < k.B; b += NT) gb += k.g_pre[(long long)b * 64 + m];
-  gb = wave_sum(gb);
-  if ((tid & 63) == 0) s_red[tid >> 6] = gb;
   __syncthreads();
-  gb = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  STAMP(17);
+  const float gb = s_G[CT];
   const int sC = k.t_major ? 1 : T, sT = k.t_major ? C : 1;   // kappa(c, t) = c*sC + t*sT
-  // (i) dLoss/d lin.weight[m][f*n_pool + q] = g_beff[m]*conv_b[f] + sum_{c,j} G[kappa(c, q+j)] * w'[f][c][j]
-  for (int q = tid; q < n_pool; q += NT) {
-    float Gw[C][JM];
-#pragma unroll
-    for (int c = 0; c < C; ++c)
-#pragma unroll
-      for (int j = 0; j < JM; ++j) Gw[c][j] = s_G[c * sC + min(q + j, T - 1) * sT];   // taps beyond J meet w' == 0
-#pragma unroll
-    for (int fl = 0; fl < FPW; ++fl) {
-      if (f0 + fl >= F) continue;
-      float acc = gb * k.conv_b[f0 + fl];
+  // (i) dLoss/d lin.weight[m][f*n_pool + q] = g_beff[m]*conv_b[f] + sum_{c,j} G[kappa(c, q+j)] * w'[f][c][j]; thread (fh, q)
+  {
+    const int nfh = (NT / n_pool) < 1 ? 1 : ((NT / n_pool) > F ? F : (NT / n_pool));   // filter groups handled in parallel
+    const int fper = (F + nfh - 1) / nfh;
+    for (int e = tid; e < nfh * n_pool; e += NT) {
+      const int fh = e / n_pool, q = e - fh * n_pool;
+      float Gw[C][JM];
 #pragma unroll
       for (int c = 0; c < C; ++c)
 #pragma unroll
-        for (int j = 0; j < JM; ++j) acc = fmaf(Gw[c][j], s_wp[(fl * C + c) * JM + j], acc);
-      k.g_lin_w[(long long)m * FQ + (f0 + fl) * n_pool + q] = acc;
+        for (int j = 0; j < JM; ++j) Gw[c][j] = s_G[c * sC + min(q + j, T - 1) * sT];   // taps beyond J meet w' == 0
+      for (int f = fh * fper; f < min(F, (fh + 1) * fper); ++f) {
+        float acc = gb * k.conv_b[f];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+          for (int j = 0; j < JM; ++j) acc = fmaf(Gw[c][j], s_wp[(f * C + c) * JM + j], acc);
+        k.g_lin_w[(long long)m * FQ + f * n_pool + q] = acc;
+      }
     }
   }
-  // (ii) partial dLoss/dw'[f][c][j] (this m) = sum_q G[kappa(c, q+j)] * lin.weight[m][f*n_pool + q]; thread (qchunk, f, c, j)
-  for (int e = tid; e < QCH * FPW * C * JM; e += NT) {
-    const int j = e % JM, r1 = e / JM, c = r1 % C, r2 = r1 / C, fl = r2 % FPW, ch = r2 / FPW;
-    const int per = (n_pool + QCH - 1) / QCH, q0 = ch * per, q1 = min(n_pool, q0 + per);
-    const float* wl = s_wl + fl * n_pool;
-    const float* gp = s_G + c * sC + j * sT;
-    float a0 = 0.f, a1 = 0.f;
-    int q = q0;
-    if (j < J) {
-      for (; q + 3 < q1; q += 4) {
-        a0 = fmaf(gp[q * sT], wl[q], a0);
-        a1 = fmaf(gp[(q + 1) * sT], wl[q + 1], a1);
-        a0 = fmaf(gp[(q + 2) * sT], wl[q + 2], a0);
-        a1 = fmaf(gp[(q + 3) * sT], wl[q + 3], a1);
+  STAMP(18);
+  // (ii) partial dLoss/dw'[f][c][j] (this m) = sum_q G[kappa(c, q+j)] * lin.weight[m][f*n_pool + q]; thread (qchunk, f, c) keeps all
+  // JM taps in registers and slides a JM-wide window of G along q (2 LDS reads per JM FMAs)
+  {
+    const int per = (n_pool + QCH - 1) / QCH;
+    for (int e = tid; e < QCH * F * C; e += NT) {
+      const int fc = e % (F * C), ch = e / (F * C), f = fc / C, c = fc - f * C;
+      const int q0 = ch * per, q1 = min(n_pool, q0 + per);
+      const float* wl = s_wl + f * n_pool;
+      const float* gp = s_G + c * sC;
+      float acc[JM], win[JM];
+#pragma unroll
+      for (int j = 0; j < JM; ++j) { acc[j] = 0.f; win[j] = gp[min(q0 + j, T - 1) * sT]; }
+      for (int q = q0; q < q1; ++q) {
+        const float w = wl[q];
+#pragma unroll
+        for (int j = 0; j < JM; ++j) acc[j] = fmaf(win[j], w, acc[j]);
+#pragma unroll
+        for (int j = 0; j + 1 < JM; ++j) win[j] = win[j + 1];
+        win[JM - 1] = gp[min(q + JM, T - 1) * sT];
       }
-      for (; q < q1; ++q) a0 = fmaf(gp[q * sT], wl[q], a0);
+#pragma unroll
+      for (int j = 0; j < JM; ++j) s_pm[(ch * F * C + fc) * JM + j] = (j < J) ? acc[j] : 0.f;
     }
-    s_pm[e] = a0 + a1;
   }
   __syncthreads();
-  // w' -> conv taps (adjoint of the box filter) and conv.bias; slab row m holds all filters, this workgroup fills its own
+  STAMP(19);
+  // w' -> conv taps (adjoint of the box filter) and conv.bias; one slab row per m
   float* row = k.conv_slabs + (long long)m * (F * C * K + F);
   const float fP = (float)k.P;
-  for (int e = tid; e < FPW * C * K; e += NT) {
-    const int kk = e % K, fc = e / K, c = fc % C, fl = fc / C;
-    if (f0 + fl >= F) continue;
+  for (int e = tid; e < F * C * K; e += NT) {
+    const int kk = e % K, fc = e / K;
     float s = 0.f;
     for (int p = 0; p < k.P; ++p) {
       float v = 0.f;
 #pragma unroll
-      for (int ch = 0; ch < QCH; ++ch) v += s_pm[((ch * FPW + fl) * C + c) * JM + kk + p];
+      for (int ch = 0; ch < QCH; ++ch) v += s_pm[(ch * F * C + fc) * JM + kk + p];
       s += v;
     }
-    row[((f0 + fl) * C + c) * K + kk] = s / fP;
+    row[e] = s / fP;
   }
-  if (tid < FPW && f0 + tid < F) row[F * C * K + f0 + tid] = gb * k.rowsum[m * F + f0 + tid];
+  for (int f = tid; f < F; f += NT) row[F * C * K + f] = gb * k.rowsum[m * F + f];
+  STAMP(20);
 }
 
 FoldK make_foldk(const FoldLaunch& a) {
@@ -409,12 +427,17 @@ hipError_t slode_launch_fold_bwd_heads(const FoldLaunch& a, hipStream_t stream) 
 hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream) {
   FoldK k = make_foldk(a);
   const int JM = k.J <= 14 ? 14 : SLODE_MAX_K + SLODE_MAX_P;
-  const size_t lds = sizeof(float) * ((size_t)k.CT + (size_t)FPW * k.n_pool + (size_t)(1 + QCH) * FPW * k.C * JM + 8);
-  const dim3 grid(k.Hc, (k.F + FPW - 1) / FPW);
-  if (k.C == 3 && JM == 14) hipLaunchKernelGGL((enc_chain_kernel<3, 14>), grid, dim3(256), lds, stream, k);
-  else if (k.C == 4 && JM == 14) hipLaunchKernelGGL((enc_chain_kernel<4, 14>), grid, dim3(256), lds, stream, k);
-  else if (k.C == 3) hipLaunchKernelGGL((enc_chain_kernel<3, SLODE_MAX_K + SLODE_MAX_P>), grid, dim3(256), lds, stream, k);
-  else if (k.C == 4) hipLaunchKernelGGL((enc_chain_kernel<4, SLODE_MAX_K + SLODE_MAX_P>), grid, dim3(256), lds, stream, k);
+  const size_t lds = sizeof(float) * ((size_t)k.CT + 8 + (size_t)k.FQ + 4 + (size_t)(1 + QCH) * k.F * k.C * JM);
+  const dim3 grid(k.Hc);
+#define SLODE_CHAIN(CC, JJ)                                                                                          \
+  do {                                                                                                               \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)enc_chain_kernel<CC, JJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((enc_chain_kernel<CC, JJ>), grid, dim3(CNT), lds, stream, k);                                 \
+  } while (0)
+  if (k.C == 3 && JM == 14) SLODE_CHAIN(3, 14);
+  else if (k.C == 4 && JM == 14) SLODE_CHAIN(4, 14);
+  else if (k.C == 3) SLODE_CHAIN(3, SLODE_MAX_K + SLODE_MAX_P);
+  else if (k.C == 4) SLODE_CHAIN(4, SLODE_MAX_K + SLODE_MAX_P);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

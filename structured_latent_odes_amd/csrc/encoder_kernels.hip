@@ -434,8 +434,10 @@ __global__ void __launch_bounds__(ENC_NT_BWD) enc_bwd_kernel(const EncK k) {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int KP = 16;  // batch-pairs (K = 2 each) whose operands a wave loads before issuing the MFMAs
 
+// With ones_col != 0 the right-hand matrix gets one extra all-ones column (index FQ): output column FQ = sum_b g_pre[b][m], and the
+// slabs have FQ + 1 columns per row (folded encoder path: g_beff comes for free).
 __global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restrict__ g_pre, const float* __restrict__ pooled,
-                                                          float* __restrict__ slabs, int B, int Hc, int FQ, int per_wave) {
+                                                          float* __restrict__ slabs, int B, int Hc, int FQ, int per_wave, int ones_col) {
   __shared__ float s_part[4 * 32 * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i0 = blockIdx.x * 32;
@@ -443,7 +445,9 @@ __global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restric
   const int bbeg = ks * per_wave, bend = min(B, bbeg + per_wave);
   const int col = lane & 31, kh = lane >> 5;
   const bool col_ok = i0 + col < FQ;
+  const bool col_one = ones_col && (i0 + col == FQ);
   const int icol = min(i0 + col, FQ - 1);
+  const int NO = FQ + (ones_col ? 1 : 0);   // output columns per slab row
   f32x16 acc0 = {0}, acc1 = {0};
   for (int bb = bbeg; bb < bend; bb += 2 * KP) {
     float a0[KP], a1[KP], bv[KP];
@@ -459,7 +463,7 @@ __global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restric
       const bool ok = bb + 2 * q + kh < bend;
       a0[q] = ok ? a0[q] : 0.f;
       a1[q] = ok ? a1[q] : 0.f;
-      bv[q] = (ok && col_ok) ? bv[q] : 0.f;
+      bv[q] = ok ? (col_ok ? bv[q] : (col_one ? 1.f : 0.f)) : 0.f;
     }
 #pragma unroll
     for (int q = 0; q < KP; ++q) {
@@ -473,7 +477,7 @@ __global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restric
     s_part[(wave * 32 + 16 + r) * 64 + lane] = acc1[r];
   }
   __syncthreads();
-  float* slab = slabs + (long long)blockIdx.y * Hc * FQ;
+  float* slab = slabs + (long long)blockIdx.y * Hc * NO;
   for (int e = tid; e < 32 * 64; e += 256) {
     const int reg = e >> 6, ln = e & 63;
     const float v = (s_part[(0 * 32 + reg) * 64 + ln] + s_part[(1 * 32 + reg) * 64 + ln]) +
@@ -481,7 +485,7 @@ __global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restric
     const int r16 = reg & 15, tile = reg >> 4;
     const int m = tile * 32 + (r16 & 3) + 8 * (r16 >> 2) + 4 * (ln >> 5);  // C/D map of the 32x32 MFMA
     const int i = i0 + (ln & 31);
-    if (m < Hc && i < FQ) slab[(long long)m * FQ + i] = v;
+    if (m < Hc && i < NO) slab[(long long)m * NO + i] = v;
   }
 }
 
@@ -513,7 +517,8 @@ hipError_t slode_launch_gemm_gpre_x(const float* g_pre, const float* x, float* s
   const int total_splits = splitk * 4;
   int per_wave = (B + total_splits - 1) / total_splits;
   per_wave = (per_wave + 1) & ~1;
-  hipLaunchKernelGGL(enc_bwd_lin_kernel, dim3((N + 31) / 32, splitk), dim3(256), 0, stream, g_pre, x, slabs, B, Hc, N, per_wave);
+  // N real columns + one ones-column (index N): the grid covers N + 1 output columns
+  hipLaunchKernelGGL(enc_bwd_lin_kernel, dim3((N + 1 + 31) / 32, splitk), dim3(256), 0, stream, g_pre, x, slabs, B, Hc, N, per_wave, 1);
   return hipGetLastError();
 }
 
@@ -569,6 +574,6 @@ hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream, hipEv
   int per_wave = (a.s.B + total_splits - 1) / total_splits;
   per_wave = (per_wave + 1) & ~1;
   hipLaunchKernelGGL(enc_bwd_lin_kernel, dim3((k.FQ + 31) / 32, a.splitk), dim3(256), 0, stream, a.g_pre, a.pooled,
-                     a.slabs_lin, a.s.B, a.s.Hc, k.FQ, per_wave);
+                     a.slabs_lin, a.s.B, a.s.Hc, k.FQ, per_wave, 0);
   return hipGetLastError();
 }

@@ -215,7 +215,7 @@ static Workspace carve(slode_handle h, const slode_shape& s, const slode_layout&
   w.rowsum = take((size_t)s.Hc * s.F);
   w.wprime = take((size_t)s.F * s.C * (s.K + s.P));
   w.beff = take(64);
-  w.gslabs = take((size_t)w.gsplit * s.Hc * s.C * s.T);
+  w.gslabs = take((size_t)w.gsplit * s.Hc * (s.C * s.T + 1));
   w.conv_slabs = take((size_t)s.Hc * (s.F * s.C * s.K + s.F));
   w.bytes = o * sizeof(float);
   return w;

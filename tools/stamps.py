@@ -46,3 +46,14 @@ if hasattr(lib, "slode_debug_wg_span") and lib.slode_debug_wg_span(buf, n) == 0:
     dur = a[:, 1] - a[:, 0]
     print("== ode kernel, all %d workgroups (us): first start 0.0, last start %.2f, first end %.2f, last end %.2f; duration min/median/max %.2f / %.2f / %.2f"
           % (n, a[:, 0].max() - t0, a[:, 1].min() - t0, a[:, 1].max() - t0, dur.min(), np.median(dur), dur.max()))
+
+if hasattr(lib, "slode_debug_stamps_fold"):
+    buf = (C.c_ulonglong * 32)()
+    assert lib.slode_debug_stamps_fold(buf) == 0
+    v = list(buf)
+    print("== folded-encoder kernels, workgroup 0 (us)")
+    for lab, i, j in (("weff: w' to LDS", 0, 1), ("weff: W_eff rows", 1, 2), ("enc_fwd2: loads", 8, 9), ("enc_fwd2: lin+tanh", 9, 10),
+                      ("enc_fwd2: heads", 10, 11), ("chain: staging", 16, 17), ("chain: (i) lin.w", 17, 18), ("chain: (ii) w' partial", 18, 19),
+                      ("chain: conv taps", 19, 20)):
+        if v[i] and v[j]:
+            print("  %-26s %8.2f" % (lab, (v[j] - v[i]) / 100.0))
