@@ -110,15 +110,12 @@ __global__ void __launch_bounds__(256) weff_kernel(const FoldK k) {
           sv[f] += (f < k.F) ? v : 0.f;
         }
       }
-      float be = k.lin_b[m];
-#pragma unroll
-      for (int f = 0; f < SLODE_MAX_F; ++f) {
-        const float sf = wave_sum(sv[f]);
-        if (f < k.F) {
-          if (lane == 0) k.rowsum[m * k.F + f] = sf;
-          be = fmaf(k.conv_b[f], sf, be);
-        }
-      }
+      static_assert(SLODE_MAX_F == 16, "wave_sum16 reduces the SLODE_MAX_F = 16 filter sums");
+      const float sf = wave_sum16(sv, lane);     // lane holds rowsum[m][(lane >> 2) & 15]
+      const int fl = (lane >> 2) & 15;
+      if ((lane & 3) == 0 && fl < k.F) k.rowsum[m * k.F + fl] = sf;
+      float be = ((lane & 3) == 0 && fl < k.F) ? k.conv_b[min(fl, k.F - 1)] * sf : 0.f;
+      be = wave_sum(be) + k.lin_b[m];
       if (lane == 0) k.beff[m] = be;
     }
   }
@@ -143,15 +140,15 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const FoldK k) {
   __syncthreads();
   STAMP(9);
   {
-    const int wave = tid >> 6, lane = tid & 63, nw = NT >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = NT >> 6;   // wave-uniform => row pointers in SGPRs
     const int ngroups = (Hc + RB - 1) / RB;
     for (int g = wave; g < ngroups; g += nw) {
       const int m0 = g * RB;
-      float acc[RB][TBE];
+      float acc[RB * TBE];   // [r][tb] flattened: wave_sum16 reduces it in place
 #pragma unroll
       for (int r = 0; r < RB; ++r)
 #pragma unroll
-        for (int tb = 0; tb < TBE; ++tb) acc[r][tb] = 0.f;
+        for (int tb = 0; tb < TBE; ++tb) acc[r * TBE + tb] = 0.f;
       const float* wrow[RB];
 #pragma unroll
       for (int r = 0; r < RB; ++r) wrow[r] = k.weff + (long long)min(m0 + r, Hc - 1) * CT;
@@ -175,7 +172,7 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const FoldK k) {
 #pragma unroll
               for (int r = 0; r < RB; ++r) {
                 const float wx = in ? w[r][u].x : 0.f, wy = in ? w[r][u].y : 0.f;
-                acc[r][tb] = fmaf(wy, pv.y, fmaf(wx, pv.x, acc[r][tb]));
+                acc[r * TBE + tb] = fmaf(wy, pv.y, fmaf(wx, pv.x, acc[r * TBE + tb]));
               }
             }
           }
@@ -186,21 +183,24 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const FoldK k) {
           for (int r = 0; r < RB; ++r) {
             const float w = wrow[r][i];
 #pragma unroll
-            for (int tb = 0; tb < TBE; ++tb) acc[r][tb] = fmaf(w, s_x[tb * CT + i], acc[r][tb]);
+            for (int tb = 0; tb < TBE; ++tb) acc[r * TBE + tb] = fmaf(w, s_x[tb * CT + i], acc[r * TBE + tb]);
           }
         }
       }
-#pragma unroll
-      for (int r = 0; r < RB; ++r)
-#pragma unroll
-        for (int tb = 0; tb < TBE; ++tb) {
-          const float v = wave_sum(acc[r][tb]);
-          if (lane == 0 && m0 + r < Hc) {
-            const float hv = tanhf(v + s_be[m0 + r]);
-            s_hid[tb * 64 + m0 + r] = hv;
-            if (b0 + tb < k.B) k.hid[(long long)(b0 + tb) * Hc + m0 + r] = hv;
-          }
+      __builtin_amdgcn_sched_barrier(0);   // keep the reduction's temporaries out of the load/FMA phase (spills otherwise)
+      STAMP(12);
+      static_assert(RB * TBE == 16, "wave_sum16 reduces RB x TBE = 16 partial sums");
+      const float v = wave_sum16(acc, lane);
+      {
+        const int idx = (lane >> 2) & 15, r = idx / TBE, tb = idx - r * TBE;
+        const int mm = min(m0 + r, Hc - 1);
+        const float hv = tanhf(v + s_be[mm]);
+        if ((lane & 3) == 0 && m0 + r < Hc) {
+          s_hid[tb * 64 + mm] = hv;
+          if (b0 + tb < k.B) k.hid[(long long)(b0 + tb) * Hc + mm] = hv;
         }
+      }
+      STAMP(13);
     }
   }
   __syncthreads();

@@ -186,17 +186,22 @@ __global__ void __launch_bounds__(ENC_NT) enc_fwd_kernel(const EncK k) {
           }
         }
       }
+      static_assert(RB * TBE == 16, "wave_sum16 reduces RB x TBE = 16 partial sums");
+      float flat[16];
 #pragma unroll
       for (int r = 0; r < RB; ++r)
 #pragma unroll
-        for (int tb = 0; tb < TBE; ++tb) {
-          const float v = wave_sum(acc[r][tb]);
-          if (lane == 0 && m0 + r < Hc) {
-            const float hv = tanhf(v + k.lin_b[m0 + r]);
-            s_hid[tb * 64 + m0 + r] = hv;
-            if (k.hid && b0 + tb < k.B) k.hid[(long long)(b0 + tb) * Hc + m0 + r] = hv;
-          }
+        for (int tb = 0; tb < TBE; ++tb) flat[r * TBE + tb] = acc[r][tb];
+      const float v = wave_sum16(flat, lane);
+      {
+        const int idx = (lane >> 2) & 15, r = idx / TBE, tb = idx - r * TBE;
+        const int mm = min(m0 + r, Hc - 1);
+        const float hv = tanhf(v + k.lin_b[mm]);
+        if ((lane & 3) == 0 && m0 + r < Hc) {
+          s_hid[tb * 64 + mm] = hv;
+          if (k.hid && b0 + tb < k.B) k.hid[(long long)(b0 + tb) * Hc + mm] = hv;
         }
+      }
     }
   }
   __syncthreads();

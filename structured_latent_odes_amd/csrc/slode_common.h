@@ -41,6 +41,28 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Sixteen wave-wide sums for the price of 17 shuffles (instead of 96): a halving butterfly over lane bits 5..2 leaves ONE of the
+// sixteen values per lane, two more exchanges finish it.  Returns sum over the wave of a[(lane >> 2) & 15] (fixed order).
+template <int HALF, int OFF>
+__device__ __forceinline__ void wave_halve(float (&a)[16], int lane) {   // compile-time indices only (register arrays)
+  const bool hi = (lane & OFF) != 0;
+#pragma unroll
+  for (int v = 0; v < HALF; ++v) {
+    const float keep = hi ? a[v + HALF] : a[v], send = hi ? a[v] : a[v + HALF];
+    a[v] = keep + __shfl_xor(send, OFF, 64);
+  }
+}
+__device__ __forceinline__ float wave_sum16(float (&a)[16], int lane) {
+  wave_halve<8, 32>(a, lane);
+  wave_halve<4, 16>(a, lane);
+  wave_halve<2, 8>(a, lane);
+  wave_halve<1, 4>(a, lane);
+  float r = a[0];
+  r += __shfl_xor(r, 2, 64);
+  r += __shfl_xor(r, 1, 64);
+  return r;
+}
+
 // Deterministic block-wide sum (fixed tree).  `scratch` needs blockDim.x/64 floats.  Result valid in every thread.
 __device__ __forceinline__ float block_sum(float v, float* scratch) {
   v = wave_sum(v);

@@ -52,8 +52,8 @@ if hasattr(lib, "slode_debug_stamps_fold"):
     assert lib.slode_debug_stamps_fold(buf) == 0
     v = list(buf)
     print("== folded-encoder kernels, workgroup 0 (us)")
-    for lab, i, j in (("weff: w' to LDS", 0, 1), ("weff: W_eff rows", 1, 2), ("enc_fwd2: loads", 8, 9), ("enc_fwd2: lin+tanh", 9, 10),
+    for lab, i, j in (("weff: w' to LDS", 0, 1), ("weff: W_eff rows", 1, 2), ("enc_fwd2: loads", 8, 9), ("enc_fwd2: lin+tanh", 9, 10), ("enc_fwd2:   W_eff stream+FMA (wave 0)", 9, 12), ("enc_fwd2:   wave sums+tanh (wave 0)", 12, 13), ("enc_fwd2:   wait for other waves", 13, 10),
                       ("enc_fwd2: heads", 10, 11), ("chain: staging", 16, 17), ("chain: (i) lin.w", 17, 18), ("chain: (ii) w' partial", 18, 19),
                       ("chain: conv taps", 19, 20)):
         if v[i] and v[j]:
-            print("  %-26s %8.2f" % (lab, (v[j] - v[i]) / 100.0))
+            print("  %-42s %8.2f" % (lab, (v[j] - v[i]) / 100.0))
