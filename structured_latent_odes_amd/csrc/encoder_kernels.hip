@@ -441,11 +441,27 @@ constexpr int KP = 16;  // batch-pairs (K = 2 each) whose operands a wave loads 
 
 // With ones_col != 0 the right-hand matrix gets one extra all-ones column (index FQ): output column FQ = sum_b g_pre[b][m], and the
 // slabs have FQ + 1 columns per row (folded encoder path: g_beff comes for free).
-__global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restrict__ g_pre, const float* __restrict__ pooled,
-                                                          float* __restrict__ slabs, int B, int Hc, int FQ, int per_wave, int ones_col) {
+struct GemmProb { const float* A; int lda; const float* X; float* slabs; int M, N, ntiles; };   // A: [B][lda], rows m < 64 used
+struct GemmProbs { GemmProb p[3]; int n_gemm_x; Stage1 rider; int rider_bx; };   // rider: stage-1 slab reduction in extra blocks
+__global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const GemmProbs ps, int B, int per_wave, int ones_col) {
   __shared__ float s_part[4 * 32 * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int i0 = blockIdx.x * 32;
+  if ((int)blockIdx.x >= ps.n_gemm_x) {   // rider blocks: (bx, group) = stage 1 of the ODE-slab reduction, independent of the GEMMs
+    const int r = ((int)blockIdx.x - ps.n_gemm_x) * gridDim.y + blockIdx.y;
+    const int bx = r % ps.rider_bx, g = r / ps.rider_bx;
+    if (g < SLODE_REDUCE_GROUPS) slab_stage1_block(ps.rider, bx, g, s_part);
+    return;
+  }
+  // up to three independent products share the launch (column tiles laid end to end along blockIdx.x)
+  int tile = (int)blockIdx.x;
+  const int which = tile < ps.p[0].ntiles ? 0 : (tile < ps.p[0].ntiles + ps.p[1].ntiles ? 1 : 2);
+  tile -= which == 0 ? 0 : (which == 1 ? ps.p[0].ntiles : ps.p[0].ntiles + ps.p[1].ntiles);
+  const GemmProb p = which == 0 ? ps.p[0] : (which == 1 ? ps.p[1] : ps.p[2]);
+  const float* __restrict__ g_pre = p.A;
+  const float* __restrict__ pooled = p.X;
+  float* __restrict__ slabs = p.slabs;
+  const int Hc = p.M, FQ = p.N, lda = p.lda;
+  const int i0 = tile * 32;
   const int ks = blockIdx.y * 4 + wave;
   const int bbeg = ks * per_wave, bend = min(B, bbeg + per_wave);
   const int col = lane & 31, kh = lane >> 5;
@@ -459,8 +475,8 @@ __global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restric
 #pragma unroll
     for (int q = 0; q < KP; ++q) {
       const int b = min(bb + 2 * q + kh, B - 1);  // unconditional clamped loads, masked by selects below
-      a0[q] = g_pre[(long long)b * 64 + col];
-      a1[q] = g_pre[(long long)b * 64 + 32 + col];
+      a0[q] = g_pre[(long long)b * lda + col];
+      a1[q] = g_pre[(long long)b * lda + 32 + col];
       bv[q] = pooled[(long long)b * FQ + icol];
     }
 #pragma unroll
@@ -523,7 +539,35 @@ hipError_t slode_launch_gemm_gpre_x(const float* g_pre, const float* x, float* s
   int per_wave = (B + total_splits - 1) / total_splits;
   per_wave = (per_wave + 1) & ~1;
   // N real columns + one ones-column (index N): the grid covers N + 1 output columns
-  hipLaunchKernelGGL(enc_bwd_lin_kernel, dim3((N + 1 + 31) / 32, splitk), dim3(256), 0, stream, g_pre, x, slabs, B, Hc, N, per_wave, 1);
+  GemmProbs ps{};
+  ps.p[0] = GemmProb{g_pre, 64, x, slabs, Hc, N, (N + 1 + 31) / 32};
+  ps.n_gemm_x = ps.p[0].ntiles;
+  hipLaunchKernelGGL(enc_bwd_lin_kernel, dim3(ps.p[0].ntiles, splitk), dim3(256), 0, stream, ps, B, per_wave, 1);
+  return hipGetLastError();
+}
+
+hipError_t slode_launch_gemm_tail(const float* g_pre, const float* x, float* gslabs, int Hc, int CT, const float* glat, const float* hid,
+                                  float* gslabs_loc, float* gslabs_ls, int L, int B, int splitk, const float* ode_slabs, int ode_stride,
+                                  int ode_n, int ode_count, float* ode_part, const float** ode_part_out, int* ode_n_out,
+                                  hipStream_t stream) {
+  const int total_splits = splitk * 4;
+  int per_wave = (B + total_splits - 1) / total_splits;
+  per_wave = (per_wave + 1) & ~1;
+  GemmProbs ps{};
+  ps.p[0] = GemmProb{g_pre, 64, x, gslabs, Hc, CT, (CT + 1 + 31) / 32};
+  ps.p[1] = GemmProb{glat, 128, hid, gslabs_loc, L, Hc, (Hc + 1 + 31) / 32};
+  ps.p[2] = GemmProb{glat + 64, 128, hid, gslabs_ls, L, Hc, (Hc + 1 + 31) / 32};
+  ps.n_gemm_x = ps.p[0].ntiles + ps.p[1].ntiles + ps.p[2].ntiles;
+  int rider_x = 0;
+  *ode_part_out = ode_slabs; *ode_n_out = ode_n;
+  if (ode_part && ode_n > 2 * SLODE_REDUCE_GROUPS) {
+    const int per = (ode_n + SLODE_REDUCE_GROUPS - 1) / SLODE_REDUCE_GROUPS;
+    ps.rider = Stage1{ode_slabs, ode_stride, ode_n, ode_count, per, ode_part};
+    ps.rider_bx = (ode_count + 63) / 64;
+    rider_x = (ps.rider_bx * SLODE_REDUCE_GROUPS + splitk - 1) / splitk;
+    *ode_part_out = ode_part; *ode_n_out = (ode_n + per - 1) / per;
+  }
+  hipLaunchKernelGGL(enc_bwd_lin_kernel, dim3(ps.n_gemm_x + rider_x, splitk), dim3(256), 0, stream, ps, B, per_wave, 1);
   return hipGetLastError();
 }
 
@@ -578,7 +622,9 @@ hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream, hipEv
   const int total_splits = a.splitk * 4;
   int per_wave = (a.s.B + total_splits - 1) / total_splits;
   per_wave = (per_wave + 1) & ~1;
-  hipLaunchKernelGGL(enc_bwd_lin_kernel, dim3((k.FQ + 31) / 32, a.splitk), dim3(256), 0, stream, a.g_pre, a.pooled,
-                     a.slabs_lin, a.s.B, a.s.Hc, k.FQ, per_wave, 0);
+  GemmProbs ps{};
+  ps.p[0] = GemmProb{a.g_pre, 64, a.pooled, a.slabs_lin, a.s.Hc, k.FQ, (k.FQ + 31) / 32};
+  ps.n_gemm_x = ps.p[0].ntiles;
+  hipLaunchKernelGGL(enc_bwd_lin_kernel, dim3(ps.p[0].ntiles, a.splitk), dim3(256), 0, stream, ps, a.s.B, per_wave, 0);
   return hipGetLastError();
 }

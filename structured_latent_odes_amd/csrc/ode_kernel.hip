@@ -63,6 +63,10 @@ struct OdeK {
   long long sb, sc, st;
   float *x_out, *z_out, *g_loc, *g_scale, *slabs;
   int slab_stride, backward, with_ll;
+  // fused encoder-head backward (folded encoder path): g_pre[b][m] = (1 - hid^2) * (zloc_w^T g_loc + zls_w^T (g_scale * scale))
+  const float *enc_hid, *enc_zloc_w, *enc_zls_w;
+  float *g_pre, *glat;   // g_pre [B][64]; glat [B][128], row = [g_loc (L) | pad to 64 | g_scale * scale (L) | pad]
+  int Hc;
 };
 
 struct LdsMap {  // offsets in floats
@@ -805,8 +809,18 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
             for (int j = 0; j < k.U; ++j) gz = fmaf(s_par[k.o_aux_w1[hd] + j * ax.z_dim + (l - ax.z_off)], s_auxd[hd * 32 + j], gz);
         }
         if (k.loc != nullptr) {
-          k.g_loc[(long long)b * L + l] = gz;
-          k.g_scale[(long long)b * L + l] = fmaf(gz, s_gpl[L + l], -1.0f / s_gls[L + l]);
+          const float sc = s_gls[L + l];
+          const float gsc = fmaf(gz, s_gpl[L + l], -1.0f / sc);
+          if (k.g_loc) {
+            k.g_loc[(long long)b * L + l] = gz;
+            k.g_scale[(long long)b * L + l] = gsc;
+          }
+          if (k.g_pre) {  // hand (g_loc, g_scale * scale) to the head-backward block after the trajectory's last barrier
+            s_gzl[l] = gz;
+            s_gpl[L + l] = gsc * sc;
+            k.glat[(long long)b * 128 + l] = gz;
+            k.glat[(long long)b * 128 + 64 + l] = gsc * sc;
+          }
         } else {
           k.g_loc[(long long)b * L + l] = gz;
         }
@@ -855,6 +869,19 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
       }
     }
     __syncthreads();
+    if (BWD && k.g_pre != nullptr && tid >= 64 && tid < 64 + k.Hc) {
+      // encoder heads + tanh, backward (models/encoder_conv.py:48-51): thread <-> hidden unit; weights stream from L2 (coalesced);
+      // s_gzl / s_gpl[L..] are next written in P0a, behind the barrier at the top of the loop
+      const int mm = tid - 64, Hc = k.Hc;
+      const float hv = k.enc_hid[(long long)b * Hc + mm];
+      float g0 = 0.f, g1 = 0.f;
+#pragma unroll 5
+      for (int l = 0; l < L; ++l) {
+        g0 = fmaf(k.enc_zloc_w[l * Hc + mm], s_gzl[l], g0);
+        g1 = fmaf(k.enc_zls_w[l * Hc + mm], s_gpl[L + l], g1);
+      }
+      k.g_pre[(long long)b * 64 + mm] = (g0 + g1) * (1.f - hv * hv);
+    }
     STAMP(10);
   }  // trajectories
 
@@ -997,6 +1024,8 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   k.z_in = a.z_in; k.gx_in = a.gx_in; k.sb = a.sb; k.sc = a.sc; k.st = a.st;
   k.x_out = a.x_out; k.z_out = a.z_out; k.g_loc = a.g_loc; k.g_scale = a.g_scale; k.slabs = a.slabs;
   k.slab_stride = a.slab_stride; k.backward = a.backward; k.with_ll = a.with_ll;
+  k.enc_hid = a.enc_hid; k.g_pre = a.g_pre; k.glat = a.glat; k.Hc = s.Hc;
+  k.enc_zloc_w = p + lay.zloc_w; k.enc_zls_w = p + lay.zls_w;
 
   const int nthreads = slode_ode_threads(s);
   const size_t lds = slode_ode_lds_bytes(s, nthreads);

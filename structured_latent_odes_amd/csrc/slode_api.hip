@@ -165,7 +165,7 @@ int slode_num_stage_times(const slode_shape* s) {
 // ---- workspace carving -------------------------------------------------------------------------------------
 struct Workspace {
   float *loc, *scale, *pooled, *hid, *g_loc, *g_scale, *g_pre, *ode_slabs, *ode_part, *small_slabs, *small_part, *lin_slabs;
-  float *weff, *rowsum, *wprime, *beff, *gslabs, *conv_slabs;  // folded encoder path
+  float *weff, *rowsum, *wprime, *beff, *gslabs, *conv_slabs, *glat, *gslabs2, *gslabs3;  // folded encoder path
   int gsplit;
   int ode_grid, ode_stride, small_grid, small_stride, lin_splitk;
   size_t bytes;
@@ -217,6 +217,9 @@ static Workspace carve(slode_handle h, const slode_shape& s, const slode_layout&
   w.beff = take(64);
   w.gslabs = take((size_t)w.gsplit * s.Hc * (s.C * s.T + 1));
   w.conv_slabs = take((size_t)s.Hc * (s.F * s.C * s.K + s.F));
+  w.glat = take((size_t)s.B * 128);
+  w.gslabs2 = take((size_t)w.gsplit * s.L * (s.Hc + 1));
+  w.gslabs3 = take((size_t)w.gsplit * s.L * (s.Hc + 1));
   w.bytes = o * sizeof(float);
   return w;
 }
@@ -400,13 +403,31 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     a.u = u; a.eps = eps; a.loc = w.loc; a.scale = w.scale; a.x_out = x_out; a.z_out = z_out;
     a.g_loc = w.g_loc; a.g_scale = w.g_scale; a.slabs = w.ode_slabs; a.slab_stride = w.ode_stride; a.grid = w.ode_grid;
     a.backward = bwd ? 1 : 0; a.with_ll = 1;
+    if (bwd && folded) { a.enc_hid = w.hid; a.g_pre = w.g_pre; a.glat = w.glat; a.g_loc = nullptr; a.g_scale = nullptr; }
     e = slode_launch_ode(a, st, h->err, sizeof(h->err));
     if (e == hipErrorInvalidValue) return SLODE_EINVAL;
     HIP_TRY(h, e);
   }
   SLODE_MARK(3);
 
-  if (bwd && folded) {
+  if (bwd && folded && !aux_mode) {
+    // Fused tail.  The ODE kernel has already run the encoder heads + tanh backward (g_pre, glat): three launches remain --
+    // split-K MFMA GEMMs (+ rider blocks: stage 1 of the ODE-slab reduction), chain rule, one final reduction (+ Adam).
+    AdamHost ah{};
+    if (adam) ah = AdamHost{adam->p, adam->m, adam->v, adam->lr, adam->b1, adam->b2, adam->eps, adam->step, adam->n};
+    const float* ode_part = nullptr;
+    int ode_pn = 0;
+    SLODE_MARK(4);
+    HIP_TRY(h, slode_launch_gemm_tail(w.g_pre, obs, w.gslabs, s->Hc, (int)CT, w.glat, w.hid, w.gslabs2, w.gslabs3, s->L, s->B, w.gsplit,
+                                      w.ode_slabs, w.ode_stride, n_slabs, (lay->ode_end - lay->ode_begin) + 1, w.ode_part, &ode_part, &ode_pn, st));
+    SLODE_MARK(5);
+    HIP_TRY(h, slode_launch_fold_chain(fl, st));
+    SLODE_MARK(6);
+    HIP_TRY(h, slode_launch_reduce_tail(*s, *lay, w.gslabs, w.gslabs2, w.gslabs3, w.gsplit, w.conv_slabs, ode_part, w.ode_stride, ode_pn,
+                                        grads, loss_out, adam ? &ah : nullptr, st));
+    SLODE_MARK(7);
+    if (prof) h->ev_valid = 1;
+  } else if (bwd && folded) {
     HIP_TRY(h, slode_launch_fold_bwd_heads(fl, st));
     SLODE_MARK(4);
     HIP_TRY(h, slode_launch_gemm_gpre_x(w.g_pre, obs, w.gslabs, s->B, s->Hc, (int)CT, w.gsplit, st));

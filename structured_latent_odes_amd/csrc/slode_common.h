@@ -63,6 +63,31 @@ __device__ __forceinline__ float wave_sum16(float (&a)[16], int lane) {
   return r;
 }
 
+// Stage 1 of the slab reduction: [n][stride] -> [G][stride] partial sums.  One 256-thread block = 64 elements x 4 sub-groups; every
+// thread keeps 4 independent loads in flight; summation order is fixed (slab index) => bitwise reproducible.  s_p: 256 floats.
+struct Stage1 { const float* slabs; int stride, n, count, per; float* out; };
+__device__ __forceinline__ void slab_stage1_block(const Stage1& f, int bx, int g, float* s_p) {
+  const int lane64 = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int e = bx * 64 + lane64;
+  const int w0 = g * f.per, w1 = min(f.n, w0 + f.per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (e < f.count) {
+    const float* p = f.slabs + e;
+    int w = w0 + q;
+    for (; w + 12 < w1; w += 16) {
+      a0 += p[(long long)w * f.stride];
+      a1 += p[(long long)(w + 4) * f.stride];
+      a2 += p[(long long)(w + 8) * f.stride];
+      a3 += p[(long long)(w + 12) * f.stride];
+    }
+    for (; w < w1; w += 4) a0 += p[(long long)w * f.stride];
+  }
+  s_p[q * 64 + lane64] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (q == 0 && e < f.count)
+    f.out[(long long)g * f.stride + e] = (s_p[lane64] + s_p[64 + lane64]) + (s_p[128 + lane64] + s_p[192 + lane64]);
+}
+
 // Deterministic block-wide sum (fixed tree).  `scratch` needs blockDim.x/64 floats.  Result valid in every thread.
 __device__ __forceinline__ float block_sum(float v, float* scratch) {
   v = wave_sum(v);
@@ -102,6 +127,10 @@ struct OdeLaunch {
   int grid;
   int backward;          // 0: forward only
   int with_ll;           // 1: likelihood + latent terms (ELBO); 0: pure ODE solve
+  // folded-encoder ELBO step: the kernel also runs the encoder heads + tanh backward and writes g_pre / glat ([B][64] each)
+  const float* enc_hid = nullptr;
+  float* g_pre = nullptr;
+  float* glat = nullptr;   // [B][128] = [g_loc (L) | pad to 64 | g_scale * scale (L) | pad]
 };
 hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, size_t errlen);
 size_t slode_ode_lds_bytes(const slode_shape& s, int nthreads);
@@ -161,6 +190,15 @@ hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream, hipEve
 hipError_t slode_launch_fold_bwd_heads(const FoldLaunch& a, hipStream_t stream);
 hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream);
 hipError_t slode_launch_gemm_gpre_x(const float* g_pre, const float* x, float* slabs, int B, int Hc, int N, int splitk, hipStream_t stream);
+// The three split-K MFMA products of the fused tail in one launch, each with a ones-column appended to its right-hand matrix:
+//   gslabs[s][m < Hc][CT + 1] = g_pre^T [x | 1];  gslabs_loc[s][l < L][Hc + 1] = glat[:, 0:L]^T [hid | 1];  gslabs_ls likewise from
+//   glat[:, 64:64+L]   (g_pre: [B][64], glat: [B][128] = [g_loc | pad | g_scale * scale | pad])
+// Extra blocks of the same launch run stage 1 of the ODE-slab reduction (ode_n slabs -> *ode_n_out partial slabs in ode_part;
+// with few slabs stage 1 is skipped and *ode_part_out = ode_slabs).
+hipError_t slode_launch_gemm_tail(const float* g_pre, const float* x, float* gslabs, int Hc, int CT, const float* glat, const float* hid,
+                                  float* gslabs_loc, float* gslabs_ls, int L, int B, int splitk, const float* ode_slabs, int ode_stride,
+                                  int ode_n, int ode_count, float* ode_part, const float** ode_part_out, int* ode_n_out,
+                                  hipStream_t stream);
 int slode_fold_small_count(const slode_shape& s);
 
 struct AuxLaunch {
@@ -191,6 +229,15 @@ struct ReduceLaunch {
   int64_t adam_step = 0, adam_n = 0;
 };
 hipError_t slode_launch_reduce(const ReduceLaunch& a, hipStream_t stream);
+
+// Fused tail of the folded-encoder ELBO step.
+struct AdamHost { float *p, *m, *v; float lr, b1, b2, eps; int64_t step, n; };
+// whole flat gradient [0, n_params) (+ caller-appended parameters [n_params, adam->n), zero gradient) + loss: ODE half from the partial
+// slabs, conv taps from the chain kernel's per-m rows, lin.bias and the head layers from the split-K GEMM slabs, lin.weight already
+// final in grads; optional Adam
+hipError_t slode_launch_reduce_tail(const slode_shape& s, const slode_layout& lay, const float* gslabs, const float* gslabs_loc,
+                                    const float* gslabs_ls, int gsplit, const float* conv_slabs, const float* ode_part, int ode_stride,
+                                    int ode_n, float* grads, float* loss_out, const AdamHost* adam, hipStream_t stream);
 
 hipError_t slode_launch_stage_times(const slode_shape& s, const float* times, float* stage_t, hipStream_t stream);
 hipError_t slode_launch_decode_heads(const slode_shape& s, const slode_layout& lay, const float* params,
