@@ -27,10 +27,14 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 #ifdef SLODE_STAMPS  // diagnostic build only: phase boundaries of workgroup 0 in 10 ns ticks (s_memrealtime)
 __device__ unsigned long long g_stamps_ode[32];
 __device__ unsigned long long g_wg_span[2 * 4096];   // [start, end] of every workgroup
+__device__ unsigned int g_wg_hw[2 * 4096];            // [HW_ID, XCC_ID] of every workgroup's wave 0
 #define STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); if (blockIdx.x == 0) g_stamps_ode[i] = t_; \
-    if ((i) == 0 && blockIdx.x < 4096) g_wg_span[2 * blockIdx.x] = t_; if ((i) == 11 && blockIdx.x < 4096) g_wg_span[2 * blockIdx.x + 1] = t_; } } while (0)
+    if ((i) == 0 && blockIdx.x < 4096) { g_wg_span[2 * blockIdx.x] = t_; g_wg_hw[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4); g_wg_hw[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } if ((i) == 11 && blockIdx.x < 4096) g_wg_span[2 * blockIdx.x + 1] = t_; } } while (0)
 extern "C" int slode_debug_stamps_ode(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_ode), sizeof(unsigned long long) * 32);
+}
+extern "C" int slode_debug_wg_hw(unsigned int* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_hw), sizeof(unsigned int) * 2 * n);
 }
 extern "C" int slode_debug_wg_span(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_span), sizeof(unsigned long long) * 2 * n);
@@ -54,6 +58,8 @@ struct OdeK {
   int o_w1, o_b1, o_w2, o_b2, o_wh, o_bh, o_wg, o_bg, o_wd, o_bd, o_head[SLODE_MAX_HEADS], o_cstd;
   int nseg;
   int n_aux, U;        // label heads scored inside the main loss (proc family)
+  int n_aux_lds;       // LDS rows reserved for them (same value on host and device)
+  int stage_encw;      // 1: P7 stages zloc_w | zls_w into LDS for the fused encoder-head backward
   float aux_mult;
   slode_aux aux[SLODE_MAX_AUX];
   int o_aux_w1[SLODE_MAX_AUX], o_aux_b1[SLODE_MAX_AUX], o_aux_w2[SLODE_MAX_AUX], o_aux_b2[SLODE_MAX_AUX], o_aux_c[SLODE_MAX_AUX];
@@ -70,12 +76,12 @@ struct OdeK {
 };
 
 struct LdsMap {  // offsets in floats
-  int ts, dt, sig, A, x, lam, st, acc, par, uu, auxh, auxd, auxgo, z, gzl, gpl, gls, u, wt, pre0, hid0, x0, go, gp0, gu, gup, red, total;
+  int ts, dt, sig, A, x, lam, st, stn, acc, par, uu, auxh, auxd, auxgo, z, gzl, gpl, gls, u, wt, pre0, hid0, x0, go, gp0, gu, gup, red, pf, meta, total;
 };
 
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
 
-__host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int Q, int nt, int nseg, int npar, int nthreads) {
+__host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int Q, int nt, int nseg, int npar, int nthreads, int naux) {
   LdsMap m;
   int o = 0;
   m.ts = o; o += pad4(nt);
@@ -85,16 +91,17 @@ __host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int
   m.x = o; o += pad4(T * S);
   m.lam = o; o += pad4(T * S);
   int stn = ((2 * S + 3) & ~3) * T; if (Q * C * T > stn) stn = Q * C * T;
-  // the epilogue's chunk-reduction scratch ((nthreads/32) x (2S+1) x 32 floats) aliases the A | x | lam | st block
-  const int eps_n = (nthreads / 32) * (2 * S + 1) * 32, have = 3 * pad4(T * S) + pad4(stn);
+  // the epilogue's scratch (chunk partials (nthreads/32) x (2S+1) x 32, then head-weight partials 4 x Q*C*S) aliases A | x | lam | st
+  const int eps_n = (nthreads / 32) * (2 * S + 1) * 32 + 4 * Q * C * S, have = 3 * pad4(T * S) + pad4(stn);
   if (eps_n > have) stn += eps_n - have;
   m.st = o; o += pad4(stn);
+  m.stn = pad4(stn);
   m.acc = o; o += pad4(npar + 1);  // [loss | priors | init net | dynamics | heads]; constant_std goes straight to the slab
   m.par = o; o += pad4(npar);
   m.uu = o; o += SLODE_MAX_NU;
-  m.auxh = o; o += SLODE_MAX_AUX * 32;
-  m.auxd = o; o += SLODE_MAX_AUX * 32;
-  m.auxgo = o; o += SLODE_MAX_AUX * 12;
+  m.auxh = o; o += naux * 32;   // label heads scored in the main loss only
+  m.auxd = o; o += naux * 32;
+  m.auxgo = o; o += pad4(naux * 12);
   m.z = o; o += pad4(L);
   m.gzl = o; o += pad4(L);
   m.gpl = o; o += pad4(2 * L);  // [d(-log p)/d prior loc | eps]
@@ -109,6 +116,8 @@ __host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int
   m.gu = o; o += 32;
   m.gup = o; o += (nthreads / 32) * 32;
   m.red = o; o += 64;
+  m.pf = o; o += 3 * pad4(L);
+  m.meta = o; o += pad4(L) * 8;   // per latent dim: prior-net offsets (ints), see setup
   m.total = o;
   return m;
 }
@@ -211,11 +220,11 @@ __device__ __forceinline__ void step_bwd(int method, float h, const float a[4], 
 //   forward (REV=false): i = k,       j = k+1, y_0 = v[0]      (x_{n+1} = A_n x_n + b_n, b_n pre-stored in v[n+1])
 //   reverse (REV=true):  i = T-2-k,   j = i,   y_0 = v[T-1]    (lambda_i = A_i lambda_{i+1} + g_i)
 // Affine maps compose, so the T-1 long dependency chain is cut into NC = 64/S chunks handled by lanes (chunk, s):
-// compose the chunk's maps (registers), chain the NC chunk start states with shuffles, replay the chunk.
+// compose the chunk's maps (registers), scan the NC composed maps across chunks in log2(NC) shuffle steps, replay the chunk.
 template <int S, bool REV>
 __device__ __forceinline__ void wave_affine_scan(const float* __restrict__ s_A, float* __restrict__ s_v, int T, int lane) {
   constexpr int NC = 64 / S;
-  constexpr int CLMAX = 12;  // steps per lane per pass (2 x CLMAX registers); longer grids take several passes
+  constexpr int CLMAX = 17;  // steps per lane per pass (2 x CLMAX registers): one pass up to T = NC * 17 + 1; longer grids take several
   const int nsteps = T - 1;
   const int c = lane / S, s = min(lane - c * S, S - 1);
   const bool lane_on = c < NC;
@@ -235,19 +244,23 @@ __device__ __forceinline__ void wave_affine_scan(const float* __restrict__ s_A, 
       Ar[q] = on ? Aq : 1.f;
       vr[q] = on ? vq : 0.f;
     }
-    float Ac = 1.f, bc = 0.f;
+    float P = 1.f, Q = 0.f;   // this chunk's composed map y -> P y + Q
 #pragma unroll
     for (int q = 0; q < CLMAX; ++q) {
-      bc = fmaf(Ar[q], bc, vr[q]);
-      Ac *= Ar[q];
+      Q = fmaf(Ar[q], Q, vr[q]);
+      P *= Ar[q];
     }
-    float ys = carry;
-    for (int cc = 1; cc < NC; ++cc) {
-      const float ye = fmaf(Ac, ys, bc);
-      const float prev = __shfl_up(ye, S, 64);
-      if (c == cc) ys = prev;
+    // inclusive scan of the composed maps over chunks (Kogge-Stone): afterwards (P, Q) maps the pass's start state to the END of chunk c
+#pragma unroll
+    for (int d = 1; d < NC; d <<= 1) {
+      const float Pp = __shfl_up(P, d * S, 64), Qp = __shfl_up(Q, d * S, 64);
+      if (c >= d) {
+        Q = fmaf(P, Qp, Q);
+        P *= Pp;
+      }
     }
-    float y = ys;
+    const float Pe = __shfl_up(P, S, 64), Qe = __shfl_up(Q, S, 64);
+    float y = (c == 0) ? carry : fmaf(Pe, carry, Qe);   // state at the start of this lane's chunk
 #pragma unroll
     for (int q = 0; q < CLMAX; ++q) {
       const int kk = k0 + q;
@@ -268,7 +281,7 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, NT = blockDim.x;
   const int T = k.T, C = k.C, L = k.L, R = k.R, Q = k.Q;
-  const LdsMap m = lds_map(T, S, H, C, L, Q, k.nt, k.nseg, k.npar, NT);
+  const LdsMap m = lds_map(T, S, H, C, L, Q, k.nt, k.nseg, k.npar, NT, k.n_aux_lds);
   float* s_ts = smem + m.ts;
   float* s_dt = smem + m.dt;
   float* s_sig = smem + m.sig;
@@ -296,76 +309,90 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
   float* s_gu = smem + m.gu;
   float* s_gup = smem + m.gup;
   float* s_red = smem + m.red;
+  int* s_meta = reinterpret_cast<int*>(smem + m.meta);
+  float* s_pf = smem + m.pf;      // [3][pad4(L)]: loc | scale | eps of the trajectory about to start (or z_in | - | -)
+  float* s_encw = s_st;   // P7: encoder head weights [2][L][Hc] staged over the (then idle) stage buffer
 
   const cptr wg = (cptr)k.wg, bg = (cptr)k.bg, wd = (cptr)k.wd, bd = (cptr)k.bd;
   STAMP(0);
-  // Prefetch of a trajectory's per-thread inputs: issued before the setup (first trajectory) and before the tail of the
-  // previous trajectory, so their HBM latency is off the critical path of P0.
-  float pf_loc = 0.f, pf_sc = 1.f, pf_eps = 0.f, pf_u = 0.f;
-  float pf_ob0 = 0.f, pf_ob1 = 0.f, pf_ob2 = 0.f, pf_ob3 = 0.f;
-  // (a macro, not a lambda: by-reference captures were kept in scratch memory)
-#define SLODE_PREFETCH(bb)                                                                                               \
-  do {                                                                                                                   \
-    const int b_ = (bb);                                                                                                 \
-    if (b_ < k.B) {                                                                                                      \
-      if (tid_outer < L) {                                                                                               \
-        if (k.loc != nullptr) {                                                                                          \
-          pf_loc = k.loc[(long long)b_ * L + tid_outer];                                                                 \
-          pf_sc = k.scale[(long long)b_ * L + tid_outer];                                                                \
-          pf_eps = k.eps[(long long)b_ * L + tid_outer];                                                                 \
-        } else {                                                                                                         \
-          pf_loc = k.z_in[(long long)b_ * L + tid_outer];                                                                \
-        }                                                                                                                \
-      }                                                                                                                  \
-      if (k.u != nullptr && tid_outer < k.nu) pf_u = k.u[(long long)b_ * k.nu + tid_outer];                              \
-      if (k.with_ll && tid_outer < T) {                                                                                  \
-        const float* op_ = k.obs + (long long)b_ * k.sb + (long long)tid_outer * k.st;                                   \
-        pf_ob0 = op_[0];                                                                                                 \
-        pf_ob1 = op_[(long long)min(1, C - 1) * k.sc];                                                                   \
-        pf_ob2 = op_[(long long)min(2, C - 1) * k.sc];                                                                   \
-        pf_ob3 = op_[(long long)min(3, C - 1) * k.sc];                                                                   \
-      }                                                                                                                  \
-    }                                                                                                                    \
-  } while (0)
+
+  // A trajectory's latent inputs (encoder loc / scale, eps, labels) go global -> LDS (s_pf, s_uu): with the setup tables for the
+  // first trajectory, at the bottom of the loop for the next one.  (Carried in registers across the loop they were spilled.)
   const int tid_outer = tid;
-  SLODE_PREFETCH(blockIdx.x);
+  STAMP(12);
 
   // ---- per-workgroup setup (shared by all trajectories this workgroup integrates) ----------------------
-  // all global loads of the setup are issued before the first use (4 per array and thread in flight; clamped addresses,
-  // no predicated loads) -- issued one by one they cost ~10 serial L2/HBM round trips per workgroup
+  // the four tables are staged with ALL their global loads in flight together (clamped addresses, no predicated loads; one L2/HBM
+  // round trip for the common sizes instead of one per table); tables longer than DEPTH * NT elements take further rounds
   {
-    constexpr int DEPTH = 4;
-    auto stage = [&](float* dst, const float* src, int n, bool sp) {
-      for (int i0 = tid; i0 < n; i0 += DEPTH * NT) {
-        float v[DEPTH];
-#pragma unroll
-        for (int q = 0; q < DEPTH; ++q) v[q] = src[min(i0 + q * NT, n - 1)];
-#pragma unroll
-        for (int q = 0; q < DEPTH; ++q)
-          if (i0 + q * NT < n) dst[i0 + q * NT] = sp ? softplusf(v[q]) : v[q];
+    constexpr int DEPTH = 8;
+    const int n_ts = k.nt, n_par = k.npar, n_sig = k.with_ll ? C * T : 0, n_dt = T - 1;
+    int rounds = 0;
+    {
+      const int nmax = max(max(n_ts, n_par), max(n_sig, n_dt));
+      rounds = (nmax + DEPTH * NT - 1) / (DEPTH * NT);
+    }
+    for (int r = 0; r < rounds; ++r) {
+      const int i0 = r * DEPTH * NT + tid;
+      float v_ts[DEPTH], v_par[DEPTH], v_sig[DEPTH], v_t0[DEPTH], v_t1[DEPTH];
+      float v_l0 = 0.f, v_l1 = 1.f, v_l2 = 0.f, v_u = 0.f;
+      const int b_first = blockIdx.x;
+      if (r == 0 && b_first < k.B) {
+        const int lc = min(tid, L - 1);
+        if (k.loc != nullptr) {
+          v_l0 = k.loc[(long long)b_first * L + lc];
+          v_l1 = k.scale[(long long)b_first * L + lc];
+          v_l2 = k.eps[(long long)b_first * L + lc];
+        } else {
+          v_l0 = k.z_in[(long long)b_first * L + lc];
+        }
+        if (k.u != nullptr) v_u = k.u[(long long)b_first * k.nu + min(tid, k.nu - 1)];
       }
-    };
-    stage(s_ts, k.stage_t, k.nt, false);
-    stage(s_par, k.pseg, k.npar, false);
-    if (k.with_ll) stage(s_sig, k.cstd, C * T, true);
-    for (int i0 = tid; i0 < T - 1; i0 += DEPTH * NT) {
-      float a[DEPTH], bq[DEPTH];
 #pragma unroll
-      for (int q = 0; q < DEPTH; ++q) { const int i = min(i0 + q * NT, T - 2); a[q] = k.times[i]; bq[q] = k.times[i + 1]; }
+      for (int q = 0; q < DEPTH; ++q) {
+        const int i = i0 + q * NT;
+        v_ts[q] = k.stage_t[min(i, n_ts - 1)];
+        v_par[q] = k.pseg[min(i, n_par - 1)];
+        v_sig[q] = k.cstd[min(i, max(n_sig, 1) - 1)];
+        v_t0[q] = k.times[min(i, T - 2)];
+        v_t1[q] = k.times[min(i, T - 2) + 1];
+      }
+      if (r == 0 && tid < L) {
+        // prior-net lookup table for latent dim l (mechanistic_cvs.py:225-237): resolved once per workgroup, while the loads fly
+        //   [0] in a conditional group  [1] loc bias  [2] log-scale bias  [3] loc weight row  [4] log-scale weight row  [5] u_off  [6] u_dim
+        const int l = tid;
+        int me[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int g = 0; g < k.ng; ++g) {
+          const slode_group gr = k.grp[g];
+          if (l >= gr.z_off && l < gr.z_off + gr.z_dim) {
+            const int ll = l - gr.z_off;
+            me[0] = 1; me[1] = k.o_ploc_b[g] + ll; me[2] = k.o_pls_b[g] + ll;
+            me[3] = k.o_ploc_w[g] + ll * gr.u_dim; me[4] = k.o_pls_w[g] + ll * gr.u_dim; me[5] = gr.u_off; me[6] = gr.u_dim;
+          }
+        }
 #pragma unroll
-      for (int q = 0; q < DEPTH; ++q)
-        if (i0 + q * NT < T - 1) s_dt[i0 + q * NT] = bq[q] - a[q];
+        for (int q = 0; q < 8; ++q) s_meta[l * 8 + q] = me[q];
+      }
+      if (r == 0 && tid < L) { s_pf[tid] = v_l0; s_pf[pad4(L) + tid] = v_l1; s_pf[2 * pad4(L) + tid] = v_l2; }
+      if (r == 0 && tid < k.nu) s_uu[tid] = v_u;
+#pragma unroll
+      for (int q = 0; q < DEPTH; ++q) {
+        const int i = i0 + q * NT;
+        if (i < n_ts) s_ts[i] = v_ts[q];
+        if (i < n_par) s_par[i] = v_par[q];
+        if (i < n_sig) s_sig[i] = softplusf(v_sig[q]);
+        if (i < n_dt) s_dt[i] = v_t1[q] - v_t0[q];
+      }
     }
   }
+  STAMP(13);
   for (int i = tid; i < k.npar + 1; i += NT) s_acc[i] = 0.f;
   __syncthreads();
+  STAMP(14);
   if (tid < 32) s_wt[tid] = (tid < H) ? s_par[k.o_wh + tid * (1 + L)] : 0.f;  // time column of dynamics_hidden (col 0)
 
   // persistent per-thread accumulators (summed over this workgroup's trajectories)
   float loss_acc = 0.f;
-  float acc_cstd[SLODE_MAX_C];
-#pragma unroll
-  for (int c = 0; c < SLODE_MAX_C; ++c) acc_cstd[c] = 0.f;
   static_assert(H < 32, "lane H of each half-wave carries the head-bias gradients");
   float acc_head = 0.f;  // one (q,c,s) head-weight entry (head-grad role)
   // hidden-unit-major role: lane jj = hidden unit, chunk = half-wave index
@@ -387,29 +414,26 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
     int tid = tid_outer;
     asm volatile("" : "+v"(tid));
     const int jj = tid & 31, chunk = tid >> 5;
-    // this trajectory's prefetched inputs (thread t <-> time point t for the observation column)
-    if (tid < k.nu) s_uu[tid] = pf_u;
-    __syncthreads();
+    __syncthreads();   // s_pf / s_uu of this trajectory are in place
 
     // ---- P0a: latent sample, log q, log p (mechanistic_cvs.py:125-135, 225-237) -------------------------
     if (tid < L) {
       const int l = tid;
       if (k.loc != nullptr) {
-        const float loc = pf_loc, sc = pf_sc, e = pf_eps;
+        const float loc = s_pf[l], sc = s_pf[pad4(L) + l], e = s_pf[2 * pad4(L) + l];
         s_gpl[L + l] = e;   // kept for the latent gradient in P7 (the registers are reused by the next prefetch)
         s_gls[L + l] = sc;
         const float z = fmaf(sc, e, loc);
         float pl = 0.f, pls = 0.f;
-        for (int g = 0; g < k.ng; ++g) {
-          const slode_group gr = k.grp[g];
-          if (l >= gr.z_off && l < gr.z_off + gr.z_dim) {
-            const int ll = l - gr.z_off;
-            pl = s_par[k.o_ploc_b[g] + ll];
-            pls = s_par[k.o_pls_b[g] + ll];
-            for (int q = 0; q < gr.u_dim; ++q) {
-              const float uv = s_uu[gr.u_off + q];
-              pl = fmaf(s_par[k.o_ploc_w[g] + ll * gr.u_dim + q], uv, pl);
-              pls = fmaf(s_par[k.o_pls_w[g] + ll * gr.u_dim + q], uv, pls);
+        {
+          const int4 m0 = reinterpret_cast<const int4*>(s_meta)[2 * l], m1 = reinterpret_cast<const int4*>(s_meta)[2 * l + 1];
+          if (m0.x) {
+            pl = s_par[m0.y];
+            pls = s_par[m0.z];
+            for (int q = 0; q < m1.z; ++q) {
+              const float uv = s_uu[m1.y + q];
+              pl = fmaf(s_par[m0.w + q], uv, pl);
+              pls = fmaf(s_par[m1.x + q], uv, pls);
             }
           }
         }
@@ -426,10 +450,11 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
         s_gls[l] = 1.f - dz * dz;   // d(-log p)/d prior log-scale
         if (k.z_out) k.z_out[(long long)b * L + l] = z;
       } else {
-        s_z[l] = pf_loc;
+        s_z[l] = s_pf[l];
         s_gzl[l] = 0.f;
       }
     }
+    STAMP(15);
     __syncthreads();
     // ---- P0b: u = W_z z + b_h (time-invariant part of the hidden layer), init-net hidden -----------------
     if (tid < H) {
@@ -459,6 +484,7 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
         s_auxd[hd * 32 + j] = 1.f / (1.f + expf(-pre));
       }
     }
+    STAMP(16);
     __syncthreads();
     // ---- P0c: x0 = sigmoid(W2 relu(.) + b2)  (blackbox_ode.py:19-22) ------------------------------------
     if (tid < S) {
@@ -566,6 +592,15 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
     }
     __syncthreads();
     STAMP(4);
+    // this trajectory's observation column (thread t <-> time point t): in flight during the scan
+    float pf_ob0 = 0.f, pf_ob1 = 0.f, pf_ob2 = 0.f, pf_ob3 = 0.f;
+    if (k.with_ll && tid < T) {
+      const float* op_ = k.obs + (long long)b * k.sb + (long long)tid * k.st;
+      pf_ob0 = op_[0];
+      pf_ob1 = op_[(long long)min(1, C - 1) * k.sc];
+      pf_ob2 = op_[(long long)min(2, C - 1) * k.sc];
+      pf_ob3 = op_[(long long)min(3, C - 1) * k.sc];
+    }
     // ---- P2: forward scan x_{n+1} = A_n x_n + b_n (the only serial part of the solve) -------------------
     if (tid < 64) wave_affine_scan<S, false>(s_A, s_x, T, tid);
     __syncthreads();
@@ -615,7 +650,11 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
               s_st[(q * C + c) * T + t] = gmu;
             }
           }
-          if (BWD) acc_cstd[c] += gsig;
+          if (BWD) {  // constant_std gradient: thread t owns slab entry (c, t); softplus'(x) = 1 - exp(-softplus(x))
+            float* dst = k.slabs + (long long)blockIdx.x * k.slab_stride + 1 + k.o_cstd + c * T + t;
+            const float val = gsig * (1.f - expf(-sig));
+            *dst = (b == (int)blockIdx.x) ? val : (*dst + val);
+          }
         }
         loss_acc -= ll;
         if (BWD) {
@@ -628,7 +667,6 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
       for (int i = tid; i < T * S; i += NT) s_lam[i] = gi[i];
     }
 
-    SLODE_PREFETCH(b + gridDim.x);
     if (BWD) {
       __syncthreads();
       STAMP(6);
@@ -785,6 +823,7 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
         const float x0 = s_x0[s];
         s_go[s] = s_lam[s] * x0 * (1.f - x0);
       }
+      STAMP(17);
       __syncthreads();
       if (tid < H) {
         float gh0 = 0.f;
@@ -794,113 +833,169 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
       } else if (tid < 32) {
         s_gp0[tid] = 0.f;
       }
+      STAMP(18);
       __syncthreads();
-      if (tid < L) {
-        const int l = tid;
-        float gz = s_gzl[l];
-#pragma unroll 5
-        for (int j = 0; j < H; ++j) {
-          gz = fmaf(s_par[k.o_wh + j * (1 + L) + 1 + l], s_gu[j], gz);
-          gz = fmaf(s_par[k.o_w1 + j * L + l], s_gp0[j], gz);
+      if (tid < 64) {
+        // latent gradient on wave 0: lane = (part, l); the sum over hidden units is split over `parts` lane groups
+        const int Lp = (L > 32) ? 64 : ((L > 16) ? 32 : ((L > 8) ? 16 : 8)), parts = 64 / Lp;
+        const int l = tid & (Lp - 1), part = tid / Lp, lc = min(l, L - 1);
+        float gz = 0.f;
+        for (int j = part; j < H; j += parts) {
+          gz = fmaf(s_par[k.o_wh + j * (1 + L) + 1 + lc], s_gu[j], gz);
+          gz = fmaf(s_par[k.o_w1 + j * L + lc], s_gp0[j], gz);
         }
+        for (int off = Lp; off < 64; off <<= 1) gz += __shfl_xor(gz, off, 64);
+        if (tid < L) {
+          gz += s_gzl[l];
+          for (int hd = 0; hd < k.n_aux; ++hd) {
+            const slode_aux ax = k.aux[hd];
+            if (l >= ax.z_off && l < ax.z_off + ax.z_dim)
+              for (int j = 0; j < k.U; ++j) gz = fmaf(s_par[k.o_aux_w1[hd] + j * ax.z_dim + (l - ax.z_off)], s_auxd[hd * 32 + j], gz);
+          }
+          if (k.loc != nullptr) {
+            const float sc = s_gls[L + l];
+            const float gsc = fmaf(gz, s_gpl[L + l], -1.0f / sc);
+            if (k.g_loc) {
+              k.g_loc[(long long)b * L + l] = gz;
+              k.g_scale[(long long)b * L + l] = gsc;
+            }
+            if (k.g_pre) {  // hand (g_loc, g_scale * scale) to the head-backward block after the trajectory's last barrier
+              s_gzl[l] = gz;
+              s_gpl[L + l] = gsc * sc;
+              k.glat[(long long)b * 128 + l] = gz;
+              k.glat[(long long)b * 128 + 64 + l] = gsc * sc;
+            }
+          } else {
+            k.g_loc[(long long)b * L + l] = gz;
+          }
+        }
+        STAMP(19);
+      } else {
+        // waves >= 1, beside the latent gradient: encoder head weights -> LDS, then the owner-thread accumulation into the LDS
+        // gradient segment (unique owner per element => no atomics)
+        const int t1 = tid - 64, n1 = NT - 64;
+        if (k.stage_encw) {
+          // encoder head layers [z_loc.weight | z_loc.bias | z_scale.0.weight] (one contiguous block of the flat vector) -> LDS by
+          // LDS-DMA loads (no registers; 64 consecutive floats per wave-instruction), in flight during the accumulation below and
+          // drained by the barrier that ends the trajectory
+          const int n_encw = 2 * L * k.Hc + L;
+          const int w1 = __builtin_amdgcn_readfirstlane((tid >> 6) - 1), nw1 = (NT >> 6) - 1, lane = tid & 63;
+          for (int base = w1 * 64; base < n_encw; base += nw1 * 64) {
+            if (base + lane < n_encw)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(k.enc_zloc_w + base + lane),
+                                               (__attribute__((address_space(3))) void*)(s_encw + base), 4, 0, 0);
+          }
+        }
+        float* acc = s_acc + 1;
+        for (int e = t1; e < H * L; e += n1) {
+          const int j = e / L, l = e - j * L;
+          acc[k.o_wh + j * (1 + L) + 1 + l] += s_gu[j] * s_z[l];
+          acc[k.o_w1 + e] += s_gp0[j] * s_z[l];
+        }
+        for (int e = t1; e < S * H; e += n1) {
+          const int s = e / H, j = e - s * H;
+          acc[k.o_w2 + e] += s_go[s] * s_hid0[j];
+        }
+        if (t1 < H) { acc[k.o_bh + t1] += s_gu[t1]; acc[k.o_b1 + t1] += s_gp0[t1]; }
+        if (t1 < S) acc[k.o_b2 + t1] += s_go[t1];
         for (int hd = 0; hd < k.n_aux; ++hd) {
           const slode_aux ax = k.aux[hd];
-          if (l >= ax.z_off && l < ax.z_off + ax.z_dim)
-            for (int j = 0; j < k.U; ++j) gz = fmaf(s_par[k.o_aux_w1[hd] + j * ax.z_dim + (l - ax.z_off)], s_auxd[hd * 32 + j], gz);
-        }
-        if (k.loc != nullptr) {
-          const float sc = s_gls[L + l];
-          const float gsc = fmaf(gz, s_gpl[L + l], -1.0f / sc);
-          if (k.g_loc) {
-            k.g_loc[(long long)b * L + l] = gz;
-            k.g_scale[(long long)b * L + l] = gsc;
+          for (int e = t1; e < k.U * ax.z_dim; e += n1) {
+            const int j = e / ax.z_dim, l = e - j * ax.z_dim;
+            acc[k.o_aux_w1[hd] + e] += s_auxd[hd * 32 + j] * s_z[ax.z_off + l];
           }
-          if (k.g_pre) {  // hand (g_loc, g_scale * scale) to the head-backward block after the trajectory's last barrier
-            s_gzl[l] = gz;
-            s_gpl[L + l] = gsc * sc;
-            k.glat[(long long)b * 128 + l] = gz;
-            k.glat[(long long)b * 128 + 64 + l] = gsc * sc;
+          for (int e = t1; e < ax.u_dim * k.U; e += n1) {
+            const int q = e / k.U, j = e - q * k.U;
+            acc[k.o_aux_w2[hd] + e] += s_auxgo[hd * 12 + q] * s_auxh[hd * 32 + j];
           }
-        } else {
-          k.g_loc[(long long)b * L + l] = gz;
+          if (t1 < k.U) acc[k.o_aux_b1[hd] + t1] += s_auxd[hd * 32 + t1];
+          if (t1 < ax.u_dim) acc[k.o_aux_b2[hd] + t1] += s_auxgo[hd * 12 + t1];
+          if (t1 == 0 && ax.kind == SLODE_AUX_EXPEXP) acc[k.o_aux_c[hd]] += s_auxgo[hd * 12 + 8];
         }
-      }
-      // owner-thread accumulation into the LDS gradient segment (unique owner per element => no atomics)
-      float* acc = s_acc + 1;
-      for (int e = tid; e < H * L; e += NT) {
-        const int j = e / L, l = e - j * L;
-        acc[k.o_wh + j * (1 + L) + 1 + l] += s_gu[j] * s_z[l];
-        acc[k.o_w1 + e] += s_gp0[j] * s_z[l];
-      }
-      for (int e = tid; e < S * H; e += NT) {
-        const int s = e / H, j = e - s * H;
-        acc[k.o_w2 + e] += s_go[s] * s_hid0[j];
-      }
-      if (tid < H) { acc[k.o_bh + tid] += s_gu[tid]; acc[k.o_b1 + tid] += s_gp0[tid]; }
-      if (tid < S) acc[k.o_b2 + tid] += s_go[tid];
-      for (int hd = 0; hd < k.n_aux; ++hd) {
-        const slode_aux ax = k.aux[hd];
-        for (int e = tid; e < k.U * ax.z_dim; e += NT) {
-          const int j = e / ax.z_dim, l = e - j * ax.z_dim;
-          acc[k.o_aux_w1[hd] + e] += s_auxd[hd * 32 + j] * s_z[ax.z_off + l];
-        }
-        for (int e = tid; e < ax.u_dim * k.U; e += NT) {
-          const int q = e / k.U, j = e - q * k.U;
-          acc[k.o_aux_w2[hd] + e] += s_auxgo[hd * 12 + q] * s_auxh[hd * 32 + j];
-        }
-        if (tid < k.U) acc[k.o_aux_b1[hd] + tid] += s_auxd[hd * 32 + tid];
-        if (tid < ax.u_dim) acc[k.o_aux_b2[hd] + tid] += s_auxgo[hd * 12 + tid];
-        if (tid == 0 && ax.kind == SLODE_AUX_EXPEXP) acc[k.o_aux_c[hd]] += s_auxgo[hd * 12 + 8];
-      }
-      if (k.loc != nullptr) {
-        for (int g = 0; g < k.ng; ++g) {
-          const slode_group gr = k.grp[g];
-          for (int e = tid; e < gr.z_dim * gr.u_dim; e += NT) {
-            const int ll = e / gr.u_dim, q = e - ll * gr.u_dim;
-            const float uv = s_uu[gr.u_off + q];
-            acc[k.o_ploc_w[g] + e] += s_gpl[gr.z_off + ll] * uv;
-            acc[k.o_pls_w[g] + e] += s_gls[gr.z_off + ll] * uv;
-          }
-          for (int e = tid; e < gr.z_dim; e += NT) {
-            acc[k.o_ploc_b[g] + e] += s_gpl[gr.z_off + e];
-            acc[k.o_pls_b[g] + e] += s_gls[gr.z_off + e];
+        if (k.loc != nullptr && t1 < L) {  // prior nets: latent dim t1 owns its bias entries and weight rows (setup's lookup table)
+          const int4 m0 = reinterpret_cast<const int4*>(s_meta)[2 * t1], m1 = reinterpret_cast<const int4*>(s_meta)[2 * t1 + 1];
+          if (m0.x) {
+            const float gpl = s_gpl[t1], gls = s_gls[t1];
+            acc[m0.y] += gpl;
+            acc[m0.z] += gls;
+            for (int q = 0; q < m1.z; ++q) {
+              const float uv = s_uu[m1.y + q];
+              acc[m0.w + q] += gpl * uv;
+              acc[m1.x + q] += gls * uv;
+            }
           }
         }
       }
+      STAMP(20);
     }
     __syncthreads();
+    STAMP(21);
     if (BWD && k.g_pre != nullptr && tid >= 64 && tid < 64 + k.Hc) {
-      // encoder heads + tanh, backward (models/encoder_conv.py:48-51): thread <-> hidden unit; weights stream from L2 (coalesced);
-      // s_gzl / s_gpl[L..] are next written in P0a, behind the barrier at the top of the loop
+      // encoder heads + tanh, backward (models/encoder_conv.py:48-51): thread <-> hidden unit.  s_gzl / s_gpl[L..] are next
+      // written in P0a and s_encw (= the stage buffer) in P1, both behind the barrier at the top of the loop
       const int mm = tid - 64, Hc = k.Hc;
       const float hv = k.enc_hid[(long long)b * Hc + mm];
       float g0 = 0.f, g1 = 0.f;
+      if (k.stage_encw) {
 #pragma unroll 5
-      for (int l = 0; l < L; ++l) {
-        g0 = fmaf(k.enc_zloc_w[l * Hc + mm], s_gzl[l], g0);
-        g1 = fmaf(k.enc_zls_w[l * Hc + mm], s_gpl[L + l], g1);
+        for (int l = 0; l < L; ++l) {
+          g0 = fmaf(s_encw[l * Hc + mm], s_gzl[l], g0);
+          g1 = fmaf(s_encw[L * Hc + L + l * Hc + mm], s_gpl[L + l], g1);
+        }
+      } else {
+#pragma unroll 5
+        for (int l = 0; l < L; ++l) {
+          g0 = fmaf(k.enc_zloc_w[l * Hc + mm], s_gzl[l], g0);
+          g1 = fmaf(k.enc_zls_w[l * Hc + mm], s_gpl[L + l], g1);
+        }
       }
       k.g_pre[(long long)b * 64 + mm] = (g0 + g1) * (1.f - hv * hv);
+    }
+    if (b + (int)gridDim.x < k.B && tid >= 64 && tid < 128) {   // next trajectory's latent inputs (wave 1; wave 0 may still read s_pf? no: P0a is long past)
+      const int bn = b + gridDim.x, t1 = tid - 64;
+      if (t1 < L) {
+        if (k.loc != nullptr) {
+          const float a0 = k.loc[(long long)bn * L + t1], a1 = k.scale[(long long)bn * L + t1], a2 = k.eps[(long long)bn * L + t1];
+          s_pf[t1] = a0; s_pf[pad4(L) + t1] = a1; s_pf[2 * pad4(L) + t1] = a2;
+        } else {
+          s_pf[t1] = k.z_in[(long long)bn * L + t1];
+        }
+      }
+      if (k.u != nullptr && t1 < k.nu) s_uu[t1] = k.u[(long long)bn * k.nu + t1];
     }
     STAMP(10);
   }  // trajectories
 
   // ---- workgroup epilogue: fold register accumulators into the LDS segment, write the slab ---------------
+  // Scratch over the (now dead) A | x | lam | st block: tmp [nchunk][2S+1][32] chunk partials, tmp2 [hsplit][n_headw] head-weight partials.
   float* slab = k.slabs + (long long)blockIdx.x * k.slab_stride;
-  const float loss = block_sum(loss_acc, s_red);
-  if (tid == 0) s_acc[0] = loss;
+  float* tmp = s_A;
+  float* tmp2 = tmp + nchunk * (2 * S + 1) * 32;
+  const float lw = wave_sum(loss_acc);
+  __syncthreads();   // last readers of the stage buffer (head-backward block) are done
+  if ((tid & 63) == 0) s_red[tid >> 6] = lw;
   if (BWD) {
-    float* acc = s_acc + 1;
-    // hidden-unit-major accumulators: reduce over chunks through the stage buffer
-    __syncthreads();
-    float* tmp = s_A;  // [nchunk][2S+1][32], aliasing the (now dead) A | x | lam | st block
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       tmp[(chunk_e * (2 * S + 1) + s) * 32 + jj_e] = acc_wg[s];
       tmp[(chunk_e * (2 * S + 1) + S + s) * 32 + jj_e] = acc_wd[s];
     }
     tmp[(chunk_e * (2 * S + 1) + 2 * S) * 32 + jj_e] = acc_wt;
-    __syncthreads();
+    if (k.with_ll) {
+      const int e = tid - hg_base;
+      if (e >= 0 && e < n_headw * hsplit) tmp2[e] = acc_head;
+    }
+  }
+  __syncthreads();
+  STAMP(22);
+  if (tid == 0) {
+    float loss = 0.f;
+    for (int w = 0; w < (NT >> 6); ++w) loss += s_red[w];   // fixed order
+    s_acc[0] = loss;
+    if (!BWD) slab[0] = loss;
+  }
+  if (BWD) {
+    float* acc = s_acc + 1;
     for (int e = tid; e < (2 * S + 1) * 32; e += NT) {
       const int row = e >> 5, j = e & 31;
       if (j < H) {
@@ -916,32 +1011,21 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
         else acc[k.o_bd + (row - S)] = v;
       }
     }
+    STAMP(23);
     if (k.with_ll) {
-      __syncthreads();  // tmp (s_st) is free again
       const int e = tid - hg_base;
-      if (e >= 0 && e < n_headw * hsplit) tmp[e] = acc_head;
-      __syncthreads();
       if (e >= 0 && e < n_headw) {
         const int qc = e / S, s = e - qc * S, q = qc / C, c = qc - q * C;
         float v = 0.f;
-        for (int part = 0; part < hsplit; ++part) v += tmp[part * n_headw + e];
+        for (int part = 0; part < hsplit; ++part) v += tmp2[part * n_headw + e];
         acc[k.o_head[q] + c * S + s] = v;
       }
-      if (tid < T) {
-#pragma unroll
-        for (int c = 0; c < SLODE_MAX_C; ++c) {
-          if (c >= C) continue;
-          const float sig = s_sig[c * T + tid];
-          slab[1 + k.o_cstd + c * T + tid] = acc_cstd[c] * (1.f - expf(-sig));  // softplus'(x) = 1 - exp(-softplus(x))
-        }
-      }
-    }
-    if (!k.with_ll)  // pure solve backward: the likelihood-only entries of the segment carry no gradient
+    } else {  // pure solve backward: the likelihood-only entries of the segment carry no gradient
       for (int i = tid; i < C * T; i += NT) slab[1 + k.o_cstd + i] = 0.f;
+    }
+    STAMP(24);
     __syncthreads();
     for (int i = tid; i < k.npar + 1; i += NT) slab[i] = s_acc[i];
-  } else {
-    if (tid == 0) slab[0] = loss;
   }
   STAMP(11);
 }
@@ -978,7 +1062,8 @@ size_t slode_ode_lds_bytes(const slode_shape& s, int nthreads) {
   slode_layout lay;
   slode_layout_init(&s, &lay);
   const int Q = s.likelihood == SLODE_GAUSS ? 1 : 3;
-  const LdsMap m = lds_map(s.T, s.S, s.H, s.C, s.L, Q, n_stage(s), lay.ode_end - lay.ode_begin, lay.cstd - lay.ode_begin, nthreads);
+  const LdsMap m = lds_map(s.T, s.S, s.H, s.C, s.L, Q, n_stage(s), lay.ode_end - lay.ode_begin, lay.cstd - lay.ode_begin, nthreads,
+                           s.aux_in_main ? s.n_aux : 0);
   return (size_t)m.total * sizeof(float);
 }
 
@@ -1014,6 +1099,7 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   k.nseg = lay.ode_end - lay.ode_begin;
   k.npar = lay.cstd - lay.ode_begin;
   k.n_aux = (a.with_ll && s.aux_in_main) ? s.n_aux : 0; k.U = s.U; k.aux_mult = s.aux_mult;
+  k.n_aux_lds = s.aux_in_main ? s.n_aux : 0;
   for (int q = 0; q < SLODE_MAX_AUX; ++q) {
     k.aux[q] = s.aux[q];
     k.o_aux_w1[q] = lay.aux_w1[q] - ob; k.o_aux_b1[q] = lay.aux_b1[q] - ob; k.o_aux_w2[q] = lay.aux_w2[q] - ob;
@@ -1029,6 +1115,12 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
 
   const int nthreads = slode_ode_threads(s);
   const size_t lds = slode_ode_lds_bytes(s, nthreads);
+  {
+    const LdsMap m = lds_map(s.T, s.S, s.H, s.C, s.L, k.Q, k.nt, k.nseg, k.npar, nthreads, k.n_aux_lds);
+    // z_loc.weight | z_loc.bias | z_scale.0.weight must be one block of the flat vector and fit the stage buffer
+    k.stage_encw = (k.g_pre != nullptr && 2 * s.L * s.Hc + s.L <= m.stn && lay.zloc_b == lay.zloc_w + s.L * s.Hc &&
+                    lay.zls_w == lay.zloc_b + s.L) ? 1 : 0;
+  }
   if (lds > 160 * 1024) {
     snprintf(err, errlen, "ode kernel needs %zu B of LDS (> 160 KiB): T=%d S=%d too large", lds, s.T, s.S);
     return hipErrorInvalidValue;

@@ -37,6 +37,17 @@ for name, labels in (("ode", ["setup", "P0 latent/init", "P1 eval a,d", "P1 coef
         if lab is not None and v[i + 1] and v[i]:
             print("  %-26s %8.2f" % (lab, (v[i + 1] - v[i]) / 100.0))
 
+if name == "ode":
+    pass
+v = None
+buf = (C.c_ulonglong * 32)()
+if lib.slode_debug_stamps_ode(buf) == 0:
+    v = list(buf)
+    for lab, i, j in (("setup: prefetch issue", 0, 12), ("setup: table loads -> LDS", 12, 13), ("setup: zero acc + barrier", 13, 14), ("setup: rest", 14, 1), ("P0a latent sample/log-probs", 1, 15), ("P0b u, init hidden, aux hidden", 15, 16), ("P0c x0, aux heads", 16, 2),
+                      ("P7: gu sum, aux, go", 9, 17), ("P7: gp0", 17, 18), ("P7: gz + stores", 18, 19), ("P7: owner accumulation", 19, 20), ("P7: last barrier", 20, 21), ("P7: g_pre block", 21, 10),
+                      ("epi: block_sum", 10, 22), ("epi: chunk reduce", 22, 23), ("epi: heads + cstd", 23, 24), ("epi: slab write", 24, 11)):
+        if v[i] and v[j]:
+            print("  %-42s %8.2f" % (lab, (v[j] - v[i]) / 100.0))
 import numpy as np
 n = 1024
 buf = (C.c_ulonglong * (2 * n))()
@@ -46,6 +57,23 @@ if hasattr(lib, "slode_debug_wg_span") and lib.slode_debug_wg_span(buf, n) == 0:
     dur = a[:, 1] - a[:, 0]
     print("== ode kernel, all %d workgroups (us): first start 0.0, last start %.2f, first end %.2f, last end %.2f; duration min/median/max %.2f / %.2f / %.2f"
           % (n, a[:, 0].max() - t0, a[:, 1].min() - t0, a[:, 1].max() - t0, dur.min(), np.median(dur), dur.max()))
+
+if hasattr(lib, "slode_debug_wg_hw"):
+    hb = (C.c_uint * (2 * n))()
+    if lib.slode_debug_wg_hw(hb, n) == 0:
+        hw = np.array(list(hb), dtype=np.int64).reshape(n, 2)
+        cu, sh, se, xcc = (hw[:, 0] >> 8) & 15, (hw[:, 0] >> 12) & 1, (hw[:, 0] >> 13) & 7, hw[:, 1] & 15
+        print("== ode kernel: workgroup duration (us) by XCC:", {int(x): round(float(np.median(dur[xcc == x])), 1) for x in np.unique(xcc)})
+        print("   by SE:", {int(x): round(float(np.median(dur[se == x])), 1) for x in np.unique(se)})
+        print("   by blockIdx>>8:", {int(x): round(float(np.median(dur[(np.arange(n) >> 8) == x])), 1) for x in range(4)})
+        key = xcc * 1000 + se * 100 + sh * 16 + cu
+        cnt = np.array([np.sum(key == kk) for kk in np.unique(key)])
+        print("   distinct (xcc,se,sh,cu):", len(np.unique(key)), "workgroups per CU min/max:", cnt.min(), cnt.max())
+        per_cu = np.array([dur[key == kk].max() for kk in np.unique(key)])
+        print("   per-CU max duration: min/median/max", per_cu.min(), np.median(per_cu), per_cu.max())
+        order = np.argsort(dur)[-8:]
+        print("   slowest workgroups:", [(int(i), round(float(dur[i]), 1), int(xcc[i]), int(se[i]), int(cu[i]), int(cnt[list(np.unique(key)).index(key[i])])) for i in order])
+        print("   start-time by blockIdx>>8 (median):", {int(x): round(float(np.median(a[(np.arange(n) >> 8) == x, 0] - t0)), 2) for x in range(4)})
 
 if hasattr(lib, "slode_debug_stamps_fold"):
     buf = (C.c_ulonglong * 32)()
