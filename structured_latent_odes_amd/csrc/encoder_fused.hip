@@ -45,6 +45,7 @@ struct FoldK {
   const float* gslabs; int n_gslabs;       // split-K partials of G = g_pre^T X  [n][Hc*CT]
   float* g_lin_w;                          // final lin.weight gradient (written directly)
   float* conv_slabs;                       // [Hc][F*C*K + F]
+  unsigned int* counter;
 };
 
 __device__ __forceinline__ int kappa_of(const FoldK& k, int c, int t) { return k.t_major ? t * k.C + c : c * k.T + t; }
@@ -55,6 +56,7 @@ __global__ void __launch_bounds__(256) weff_kernel(const FoldK k) {
   __shared__ float s_wp[SLODE_MAX_F * SLODE_MAX_C * JM];
   const int tid = threadIdx.x, J = k.J, C = k.C, K = k.K;
   const float fP = (float)k.P;
+  if (blockIdx.x == 0 && tid == 0 && k.counter) *k.counter = 0u;   // arrival counter of this step's chain blocks
   STAMP(0);
   // w'[f][c][j] = (1/P) * sum_{k + p = j} w[f][c][k]   (rows padded to JM, zero beyond J)
   for (int e = tid; e < k.F * C * JM; e += 256) {
@@ -293,15 +295,25 @@ __global__ void __launch_bounds__(256) enc_bwd2_kernel(const FoldK k) {
 // (the MFMA GEMM appends a ones-column to X), both summed here over the split-K partials in fixed order.
 constexpr int CNT = 1024;
 constexpr int QCH = 16;   // q-chunks for the w' partial sums
+// With a tail (folded ELBO step) the same launch finishes the whole flat gradient: rider blocks (blockIdx >= Hc) reduce everything
+// that does not depend on this kernel (ODE half, lin.bias, head layers, loss), the chain blocks apply Adam to their own lin.weight row,
+// and the LAST chain block to arrive (agent-scope release / counter / acquire) sums the Hc conv rows.  Fixed order => reproducible.
 template <int C, int JM>
-__global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k) {
+__global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const TailK tl, const int with_tail) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, NT = blockDim.x, m = blockIdx.x;
+  if (m >= k.Hc) {   // rider block
+    const int i = tl.lin_b + (m - k.Hc) * NT + tid;
+    if (i < tl.n_total) tail_element(tl, i);
+    else if (i == tl.n_total) tail_loss(tl);
+    return;
+  }
   const int CT = k.CT, J = k.J, K = k.K, F = k.F, n_pool = k.n_pool, FQ = k.FQ, T = k.T, GN = CT + 1;
   float* s_G = smem;                          // [CT + 1]
   float* s_wl = s_G + ((GN + 3) & ~3);        // [FQ]          lin.weight[m][:]
   float* s_wp = s_wl + ((FQ + 3) & ~3);       // [F][C][JM]    w' (zero padded)
   float* s_pm = s_wp + F * C * JM;            // [QCH][F][C][JM] partial dLoss/dw'
+  float* s_glw = s_pm + QCH * F * C * JM;     // [FQ] this row's lin.weight gradient (for the fused Adam pass)
   STAMP(16);
   for (int i = tid; i < GN; i += NT) {
     float a = 0.f;
@@ -335,6 +347,7 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k) {
 #pragma unroll
           for (int j = 0; j < JM; ++j) acc = fmaf(Gw[c][j], s_wp[(f * C + c) * JM + j], acc);
         k.g_lin_w[(long long)m * FQ + f * n_pool + q] = acc;
+        s_glw[f * n_pool + q] = acc;
       }
     }
   }
@@ -365,6 +378,9 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k) {
   }
   __syncthreads();
   STAMP(19);
+  if (with_tail && tl.ad.p != nullptr) {   // Adam on this block's lin.weight row (its weights live in s_wl from here on)
+    for (int e = tid; e < FQ; e += NT) adam_apply(tl.ad, tl.lin_w + m * FQ + e, s_glw[e]);
+  }
   // w' -> conv taps (adjoint of the box filter) and conv.bias; one slab row per m
   float* row = k.conv_slabs + (long long)m * (F * C * K + F);
   const float fP = (float)k.P;
@@ -381,6 +397,29 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k) {
   }
   for (int f = tid; f < F; f += NT) row[F * C * K + f] = gb * k.rowsum[m * F + f];
   STAMP(20);
+  if (with_tail) {
+    __shared__ int s_last;
+    __syncthreads();     // every wave's stores of this block's conv row have left the CU (s_waitcnt vmcnt(0) precedes the barrier)
+    if (tid == 0) {
+      __threadfence();   // release at agent scope (one lane: the L2 write-back covers the whole block's row)
+      s_last = (atomicAdd(tl.counter, 1u) == (unsigned)(k.Hc - 1)) ? 1 : 0;
+      if (s_last) __threadfence();   // acquire the other blocks' rows (invalidates this CU's L1, shared by all waves of the block)
+    }
+    __syncthreads();
+    if (s_last) {   // conv.weight, conv.bias: 4 lanes per element, each summing every 4th row (fixed order), combined by two exchanges
+      for (int i0 = 0; i0 < tl.lin_w; i0 += NT / 4) {
+        const int i = min(i0 + (tid >> 2), tl.lin_w - 1), part = tid & 3;
+        const int nrow = (k.Hc - part + 3) / 4;
+        float g = strided_sum(tl.conv_slabs + (long long)part * tl.n_cv + (i - tl.conv_w), 4 * tl.n_cv, nrow);
+        g += __shfl_xor(g, 1, 64);
+        g += __shfl_xor(g, 2, 64);
+        if (part == 0 && i0 + (tid >> 2) < tl.lin_w) {
+          tl.grads[i] = g;
+          if (tl.ad.p) adam_apply(tl.ad, i, g);
+        }
+      }
+    }
+  }
 }
 
 FoldK make_foldk(const FoldLaunch& a) {
@@ -397,7 +436,7 @@ FoldK make_foldk(const FoldLaunch& a) {
   k.loc = a.loc; k.scale = a.scale; k.hid = a.hid;
   k.scale_in = a.scale; k.hid_in = a.hid; k.g_loc = a.g_loc; k.g_scale = a.g_scale;
   k.g_pre = a.g_pre; k.slabs = a.small_slabs; k.small_stride = a.small_stride;
-  k.gslabs = a.gslabs; k.n_gslabs = a.n_gslabs; k.g_lin_w = a.g_lin_w; k.conv_slabs = a.conv_slabs;
+  k.gslabs = a.gslabs; k.n_gslabs = a.n_gslabs; k.g_lin_w = a.g_lin_w; k.conv_slabs = a.conv_slabs; k.counter = a.counter;
   return k;
 }
 
@@ -427,12 +466,15 @@ hipError_t slode_launch_fold_bwd_heads(const FoldLaunch& a, hipStream_t stream) 
 hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream) {
   FoldK k = make_foldk(a);
   const int JM = k.J <= 14 ? 14 : SLODE_MAX_K + SLODE_MAX_P;
-  const size_t lds = sizeof(float) * ((size_t)k.CT + 8 + (size_t)k.FQ + 4 + (size_t)(1 + QCH) * k.F * k.C * JM);
-  const dim3 grid(k.Hc);
+  const size_t lds = sizeof(float) * ((size_t)k.CT + 8 + 2 * ((size_t)k.FQ + 4) + (size_t)(1 + QCH) * k.F * k.C * JM);
+  const TailK tl = a.tail ? *a.tail : TailK{};
+  const int with_tail = a.tail ? 1 : 0;
+  const int riders = a.tail ? (tl.n_total + 1 - tl.lin_b + CNT - 1) / CNT : 0;
+  const dim3 grid(k.Hc + riders);
 #define SLODE_CHAIN(CC, JJ)                                                                                          \
   do {                                                                                                               \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)enc_chain_kernel<CC, JJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((enc_chain_kernel<CC, JJ>), grid, dim3(CNT), lds, stream, k);                                 \
+    hipLaunchKernelGGL((enc_chain_kernel<CC, JJ>), grid, dim3(CNT), lds, stream, k, tl, with_tail);                              \
   } while (0)
   if (k.C == 3 && JM == 14) SLODE_CHAIN(3, 14);
   else if (k.C == 4 && JM == 14) SLODE_CHAIN(4, 14);

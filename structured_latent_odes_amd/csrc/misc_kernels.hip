@@ -32,21 +32,6 @@ struct ReduceK {
   int n_total;  // >= n_params: parameters appended by the caller (zero main-loss gradient) are stepped too
 };
 
-__device__ __forceinline__ float strided_sum(const float* p, int stride, int n) {
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int w = 0;
-  for (; w + 3 < n; w += 4) {
-    a0 += p[(long long)w * stride];
-    a1 += p[(long long)(w + 1) * stride];
-    a2 += p[(long long)(w + 2) * stride];
-    a3 += p[(long long)(w + 3) * stride];
-  }
-  for (; w < n; ++w) a0 += p[(long long)w * stride];
-  return (a0 + a1) + (a2 + a3);
-}
-
-// Stage 1 of the slab reduction: [n][stride] -> [G][stride] partial sums.  Block = 64 elements x 4 sub-groups; every
-// thread keeps 4 independent loads in flight; summation order is fixed (slab index) => bitwise reproducible.
 __global__ void __launch_bounds__(256) slab_stage1_kernel(const Stage1 fam0, const Stage1 fam1) {
   __shared__ float s_p[4 * 64];
   const Stage1 f = blockIdx.z == 0 ? fam0 : fam1;  // two slab families reduced by one launch
@@ -99,66 +84,6 @@ __global__ void reduce_kernel(const ReduceK k) {
     k.adam_m[i] = mi;
     k.adam_v[i] = vi;
   }
-}
-
-struct AdamK { float *p, *m, *v; float step_size, one_minus_b1, b2, one_minus_b2, sqrt_bc2, eps; };
-__device__ __forceinline__ void adam_apply(const AdamK& a, int i, float g) {  // same formulas as adam_kernel below
-  float mi = a.m[i], vi = a.v[i];
-  mi = mi + a.one_minus_b1 * (g - mi);
-  vi = vi * a.b2 + a.one_minus_b2 * g * g;
-  const float denom = sqrtf(vi) / a.sqrt_bc2 + a.eps;
-  a.p[i] = a.p[i] - a.step_size * (mi / denom);
-  a.m[i] = mi;
-  a.v[i] = vi;
-}
-
-// Fused tail (folded path): the whole flat gradient (+ loss, + optional Adam) in one launch.  ODE half: partial slabs of the
-// stage-1 blocks that ride in the GEMM launch.  Encoder half:  conv taps: Hc per-m rows of the chain kernel; lin.bias = ones-column of G = g_pre^T [X|1];
-// head layers = rows of glat[:, 0:L]^T [hid|1] (z_loc) and glat[:, 64:64+L]^T [hid|1] (z_log_scale); lin.weight is final in grads already.
-struct ReduceEncK {
-  const float *gslabs, *gslabs_loc, *gslabs_ls, *conv_slabs;
-  const float* ode_part; int ode_stride, ode_n;     // partial slabs of the ODE half (element 0 = loss)
-  float* loss_out;
-  int gsplit, Hc, L, CT, n_cv;                       // n_cv = F*C*K + F
-  int conv_w, lin_w, lin_b, zloc_w, zloc_b, zls_w, zls_b, ode_begin, n_params, n_total;
-  float* grads;
-  AdamK ad;
-};
-__global__ void reduce_enc_kernel(const ReduceEncK k) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == k.n_total) {   // one extra thread: the loss scalar
-    if (k.loss_out) {
-      double acc = 0.0;
-      for (int w = 0; w < k.ode_n; ++w) acc += (double)k.ode_part[(long long)w * k.ode_stride];
-      k.loss_out[0] = (float)acc;
-    }
-    return;
-  }
-  if (i > k.n_total) return;
-  float g = 0.f;
-  if (i >= k.ode_begin && i < k.n_params) {
-    g = strided_sum(k.ode_part + 1 + (i - k.ode_begin), k.ode_stride, k.ode_n);
-    k.grads[i] = g;
-  } else if (i < k.n_params) {
-    const int Hc = k.Hc, GN = k.CT + 1, HN = Hc + 1;
-    if (i < k.lin_w) {
-      g = strided_sum(k.conv_slabs + (i - k.conv_w), k.n_cv, Hc);
-    } else if (i < k.lin_b) {
-      g = k.grads[i];
-    } else if (i < k.zloc_w) {
-      g = strided_sum(k.gslabs + (long long)(i - k.lin_b) * GN + k.CT, Hc * GN, k.gsplit);
-    } else {
-      int row, col;
-      const float* src = k.gslabs_loc;
-      if (i < k.zloc_b) { const int e = i - k.zloc_w; row = e / Hc; col = e - row * Hc; }
-      else if (i < k.zls_w) { row = i - k.zloc_b; col = Hc; }
-      else if (i < k.zls_b) { const int e = i - k.zls_w; row = e / Hc; col = e - row * Hc; src = k.gslabs_ls; }
-      else { row = i - k.zls_b; col = Hc; src = k.gslabs_ls; }
-      g = strided_sum(src + (long long)row * HN + col, k.L * HN, k.gsplit);
-    }
-    if (i < k.lin_w || i >= k.lin_b) k.grads[i] = g;
-  }
-  if (k.ad.p) adam_apply(k.ad, i, g);
 }
 
 // Decoder heads on a given trajectory tensor: models/decoders.py:45-47 (ALD: q50, q75, q25) / :86 (Gauss: mean),
@@ -270,33 +195,6 @@ hipError_t slode_launch_reduce(const ReduceLaunch& a_in, hipStream_t stream) {
     n = k.n_total;
   }
   hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, k);
-  return hipGetLastError();
-}
-
-static AdamK make_adamk(const AdamHost* a) {
-  AdamK k{};
-  if (a && a->p) {
-    const double bc1 = 1.0 - pow((double)a->b1, (double)a->step), bc2 = 1.0 - pow((double)a->b2, (double)a->step);
-    k.p = a->p; k.m = a->m; k.v = a->v;
-    k.step_size = (float)((double)a->lr / bc1); k.one_minus_b1 = 1.0f - a->b1; k.b2 = a->b2;
-    k.one_minus_b2 = 1.0f - a->b2; k.sqrt_bc2 = (float)sqrt(bc2); k.eps = a->eps;
-  }
-  return k;
-}
-
-hipError_t slode_launch_reduce_tail(const slode_shape& s, const slode_layout& lay, const float* gslabs, const float* gslabs_loc,
-                                    const float* gslabs_ls, int gsplit, const float* conv_slabs, const float* ode_part, int ode_stride,
-                                    int ode_n, float* grads, float* loss_out, const AdamHost* adam, hipStream_t stream) {
-  ReduceEncK k{};
-  k.ode_part = ode_part; k.ode_stride = ode_stride; k.ode_n = ode_n; k.loss_out = loss_out;
-  k.gslabs = gslabs; k.gslabs_loc = gslabs_loc; k.gslabs_ls = gslabs_ls; k.conv_slabs = conv_slabs; k.gsplit = gsplit; k.Hc = s.Hc; k.L = s.L; k.CT = s.C * s.T;
-  k.n_cv = s.F * s.C * s.K + s.F;
-  k.conv_w = lay.conv_w; k.lin_w = lay.lin_w; k.lin_b = lay.lin_b; k.zloc_w = lay.zloc_w; k.zloc_b = lay.zloc_b; k.zls_w = lay.zls_w;
-  k.zls_b = lay.zls_b; k.ode_begin = lay.ode_begin; k.n_params = lay.n_params;
-  k.n_total = (adam && adam->p && adam->n > lay.n_params) ? (int)adam->n : lay.n_params;
-  k.grads = grads; k.ad = make_adamk(adam);
-  const int nthr = k.n_total + 1;
-  hipLaunchKernelGGL(reduce_enc_kernel, dim3((nthr + 255) / 256), dim3(256), 0, stream, k);
   return hipGetLastError();
 }
 

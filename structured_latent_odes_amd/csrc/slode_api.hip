@@ -166,6 +166,7 @@ int slode_num_stage_times(const slode_shape* s) {
 struct Workspace {
   float *loc, *scale, *pooled, *hid, *g_loc, *g_scale, *g_pre, *ode_slabs, *ode_part, *small_slabs, *small_part, *lin_slabs;
   float *weff, *rowsum, *wprime, *beff, *gslabs, *conv_slabs, *glat, *gslabs2, *gslabs3;  // folded encoder path
+  unsigned int* counter;
   int gsplit;
   int ode_grid, ode_stride, small_grid, small_stride, lin_splitk;
   size_t bytes;
@@ -220,6 +221,7 @@ static Workspace carve(slode_handle h, const slode_shape& s, const slode_layout&
   w.glat = take((size_t)s.B * 128);
   w.gslabs2 = take((size_t)w.gsplit * s.L * (s.Hc + 1));
   w.gslabs3 = take((size_t)w.gsplit * s.L * (s.Hc + 1));
+  w.counter = reinterpret_cast<unsigned int*>(take(64));
   w.bytes = o * sizeof(float);
   return w;
 }
@@ -379,6 +381,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     fl.weff = w.weff; fl.rowsum = w.rowsum; fl.wprime = w.wprime; fl.beff = w.beff; fl.loc = w.loc; fl.scale = w.scale; fl.hid = w.hid;
     fl.g_loc = w.g_loc; fl.g_scale = w.g_scale; fl.g_pre = w.g_pre; fl.small_slabs = w.small_slabs; fl.small_stride = w.small_stride;
     fl.gslabs = w.gslabs; fl.n_gslabs = w.gsplit; fl.g_lin_w = grads ? grads + lay->lin_w : nullptr; fl.conv_slabs = w.conv_slabs;
+    fl.counter = w.counter;
     e = slode_launch_fold_fwd(fl, st, prof ? h->ev[1] : nullptr);
     HIP_TRY(h, e);
   } else {
@@ -421,10 +424,17 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     HIP_TRY(h, slode_launch_gemm_tail(w.g_pre, obs, w.gslabs, s->Hc, (int)CT, w.glat, w.hid, w.gslabs2, w.gslabs3, s->L, s->B, w.gsplit,
                                       w.ode_slabs, w.ode_stride, n_slabs, (lay->ode_end - lay->ode_begin) + 1, w.ode_part, &ode_part, &ode_pn, st));
     SLODE_MARK(5);
-    HIP_TRY(h, slode_launch_fold_chain(fl, st));
+    TailK tl{};
+    tl.gslabs = w.gslabs; tl.gslabs_loc = w.gslabs2; tl.gslabs_ls = w.gslabs3; tl.conv_slabs = w.conv_slabs;
+    tl.ode_part = ode_part; tl.ode_stride = w.ode_stride; tl.ode_n = ode_pn; tl.loss_out = loss_out;
+    tl.gsplit = w.gsplit; tl.Hc = s->Hc; tl.L = s->L; tl.CT = (int)CT; tl.n_cv = s->F * s->C * s->K + s->F;
+    tl.conv_w = lay->conv_w; tl.lin_w = lay->lin_w; tl.lin_b = lay->lin_b; tl.zloc_w = lay->zloc_w; tl.zloc_b = lay->zloc_b;
+    tl.zls_w = lay->zls_w; tl.zls_b = lay->zls_b; tl.ode_begin = lay->ode_begin; tl.n_params = lay->n_params;
+    tl.n_total = (adam && adam->n > lay->n_params) ? (int)adam->n : lay->n_params;
+    tl.grads = grads; tl.ad = make_adamk(adam ? &ah : nullptr); tl.counter = w.counter;
+    fl.tail = &tl;
+    HIP_TRY(h, slode_launch_fold_chain(fl, st));   // + rider blocks and the last-block conv reduction: the flat gradient is complete
     SLODE_MARK(6);
-    HIP_TRY(h, slode_launch_reduce_tail(*s, *lay, w.gslabs, w.gslabs2, w.gslabs3, w.gsplit, w.conv_slabs, ode_part, w.ode_stride, ode_pn,
-                                        grads, loss_out, adam ? &ah : nullptr, st));
     SLODE_MARK(7);
     if (prof) h->ev_valid = 1;
   } else if (bwd && folded) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 #include "../../include/slode.h"
 
 #define SLODE_MAX_T 1024
@@ -61,6 +62,92 @@ __device__ __forceinline__ float wave_sum16(float (&a)[16], int lane) {
   r += __shfl_xor(r, 2, 64);
   r += __shfl_xor(r, 1, 64);
   return r;
+}
+
+// sum_{w < n} p[w * stride] with 16 loads in flight; fixed order (four round-robin partial sums, combined pairwise)
+__device__ __forceinline__ float strided_sum(const float* p, int stride, int n) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int w = 0; w < n; w += 16) {
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = p[(long long)min(w + q, n - 1) * stride];   // clamped, unconditional
+#pragma unroll
+    for (int q = 0; q < 16; q += 4) {
+      a0 += (w + q < n) ? v[q] : 0.f;
+      a1 += (w + q + 1 < n) ? v[q + 1] : 0.f;
+      a2 += (w + q + 2 < n) ? v[q + 2] : 0.f;
+      a3 += (w + q + 3 < n) ? v[q + 3] : 0.f;
+    }
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+// ---- fused tail of the folded-encoder ELBO step (runs inside the chain-rule launch, encoder_fused.hip) -------------------------
+struct AdamK { float *p, *m, *v; float step_size, one_minus_b1, b2, one_minus_b2, sqrt_bc2, eps; };
+// torch.optim.Adam single-tensor formulas (see adam_kernel, misc_kernels.hip)
+__device__ __forceinline__ void adam_apply(const AdamK& a, int i, float g) {
+  float mi = a.m[i], vi = a.v[i];
+  mi = mi + a.one_minus_b1 * (g - mi);
+  vi = vi * a.b2 + a.one_minus_b2 * g * g;
+  const float denom = sqrtf(vi) / a.sqrt_bc2 + a.eps;
+  a.p[i] = a.p[i] - a.step_size * (mi / denom);
+  a.m[i] = mi;
+  a.v[i] = vi;
+}
+struct AdamHost { float *p, *m, *v; float lr, b1, b2, eps; int64_t step, n; };
+inline AdamK make_adamk(const AdamHost* a) {
+  AdamK k{};
+  if (a && a->p) {
+    const double bc1 = 1.0 - pow((double)a->b1, (double)a->step), bc2 = 1.0 - pow((double)a->b2, (double)a->step);
+    k.p = a->p; k.m = a->m; k.v = a->v;
+    k.step_size = (float)((double)a->lr / bc1); k.one_minus_b1 = 1.0f - a->b1; k.b2 = a->b2;
+    k.one_minus_b2 = 1.0f - a->b2; k.sqrt_bc2 = (float)sqrt(bc2); k.eps = a->eps;
+  }
+  return k;
+}
+// Where every flat-gradient element outside lin.weight comes from.  ODE half: partial slabs of the stage-1 rider blocks of the GEMM
+// launch (element 0 = loss).  conv taps: Hc per-m rows of the chain kernel.  lin.bias = ones-column of G = g_pre^T [x|1].  Head layers =
+// rows of glat[:, 0:L]^T [hid|1] (z_loc) and glat[:, 64:64+L]^T [hid|1] (z_log_scale).  Elements [n_params, n_total) (parameters the
+// caller appended) have zero gradient and only take the Adam step.
+struct TailK {
+  const float *gslabs, *gslabs_loc, *gslabs_ls, *conv_slabs;
+  const float* ode_part; int ode_stride, ode_n;
+  float* loss_out;
+  int gsplit, Hc, L, CT, n_cv;                       // n_cv = F*C*K + F
+  int conv_w, lin_w, lin_b, zloc_w, zloc_b, zls_w, zls_b, ode_begin, n_params, n_total;
+  float* grads;
+  AdamK ad;
+  unsigned int* counter;   // arrivals of the chain blocks (zeroed by the fold kernel at the start of the step)
+};
+__device__ __forceinline__ void tail_loss(const TailK& k) {
+  if (!k.loss_out) return;
+  double acc = 0.0;
+  for (int w = 0; w < k.ode_n; ++w) acc += (double)k.ode_part[(long long)w * k.ode_stride];   // fixed order
+  k.loss_out[0] = (float)acc;
+}
+// element i of [0, lin_w) (conv) or [lin_b, n_total): gradient, write, optional Adam
+__device__ __forceinline__ void tail_element(const TailK& k, int i) {
+  float g = 0.f;
+  if (i >= k.ode_begin && i < k.n_params) {
+    g = strided_sum(k.ode_part + 1 + (i - k.ode_begin), k.ode_stride, k.ode_n);
+  } else if (i < k.lin_w) {
+    g = strided_sum(k.conv_slabs + (i - k.conv_w), k.n_cv, k.Hc);
+  } else if (i < k.n_params) {
+    const int Hc = k.Hc, GN = k.CT + 1, HN = Hc + 1;
+    if (i < k.zloc_w) {
+      g = strided_sum(k.gslabs + (long long)(i - k.lin_b) * GN + k.CT, Hc * GN, k.gsplit);
+    } else {
+      int row, col;
+      const float* src = k.gslabs_loc;
+      if (i < k.zloc_b) { const int e = i - k.zloc_w; row = e / Hc; col = e - row * Hc; }
+      else if (i < k.zls_w) { row = i - k.zloc_b; col = Hc; }
+      else if (i < k.zls_b) { const int e = i - k.zls_w; row = e / Hc; col = e - row * Hc; src = k.gslabs_ls; }
+      else { row = i - k.zls_b; col = Hc; src = k.gslabs_ls; }
+      g = strided_sum(src + (long long)row * HN + col, k.L * HN, k.gsplit);
+    }
+  }
+  if (i < k.n_params) k.grads[i] = g;
+  if (k.ad.p) adam_apply(k.ad, i, g);
 }
 
 // Stage 1 of the slab reduction: [n][stride] -> [G][stride] partial sums.  One 256-thread block = 64 elements x 4 sub-groups; every
@@ -185,6 +272,8 @@ struct FoldLaunch {
   float *g_pre, *small_slabs; int small_stride;
   const float* gslabs; int n_gslabs;
   float *g_lin_w, *conv_slabs;
+  unsigned int* counter = nullptr;   // zeroed by the fold kernel; arrivals of the chain blocks
+  const TailK* tail = nullptr;       // chain launch also finishes the whole flat gradient (+ loss, + optional Adam)
 };
 hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream, hipEvent_t mid = nullptr);
 hipError_t slode_launch_fold_bwd_heads(const FoldLaunch& a, hipStream_t stream);
@@ -230,14 +319,6 @@ struct ReduceLaunch {
 };
 hipError_t slode_launch_reduce(const ReduceLaunch& a, hipStream_t stream);
 
-// Fused tail of the folded-encoder ELBO step.
-struct AdamHost { float *p, *m, *v; float lr, b1, b2, eps; int64_t step, n; };
-// whole flat gradient [0, n_params) (+ caller-appended parameters [n_params, adam->n), zero gradient) + loss: ODE half from the partial
-// slabs, conv taps from the chain kernel's per-m rows, lin.bias and the head layers from the split-K GEMM slabs, lin.weight already
-// final in grads; optional Adam
-hipError_t slode_launch_reduce_tail(const slode_shape& s, const slode_layout& lay, const float* gslabs, const float* gslabs_loc,
-                                    const float* gslabs_ls, int gsplit, const float* conv_slabs, const float* ode_part, int ode_stride,
-                                    int ode_n, float* grads, float* loss_out, const AdamHost* adam, hipStream_t stream);
 
 hipError_t slode_launch_stage_times(const slode_shape& s, const float* times, float* stage_t, hipStream_t stream);
 hipError_t slode_launch_decode_heads(const slode_shape& s, const slode_layout& lay, const float* params,
