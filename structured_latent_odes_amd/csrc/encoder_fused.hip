@@ -19,11 +19,13 @@ typedef const __attribute__((address_space(4))) float* cptr;
 #ifdef SLODE_STAMPS
 __device__ unsigned long long g_stamps_fold[32];
 #define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps_fold[i] = wall_clock64(); } while (0)
+#define STAMP_ANY(i) do { if (threadIdx.x == 0) g_stamps_fold[i] = wall_clock64(); } while (0)
 extern "C" int slode_debug_stamps_fold(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_fold), sizeof(unsigned long long) * 32);
 }
 #else
 #define STAMP(i) do { } while (0)
+#define STAMP_ANY(i) do { } while (0)
 #endif
 
 namespace {
@@ -304,8 +306,10 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const Tai
   const int tid = threadIdx.x, NT = blockDim.x, m = blockIdx.x;
   if (m >= k.Hc) {   // rider block
     const int i = tl.lin_b + (m - k.Hc) * NT + tid;
+    if (m == k.Hc) STAMP_ANY(26);
     if (i < tl.n_total) tail_element(tl, i);
     else if (i == tl.n_total) tail_loss(tl);
+    if (m == k.Hc) STAMP_ANY(27);
     return;
   }
   const int CT = k.CT, J = k.J, K = k.K, F = k.F, n_pool = k.n_pool, FQ = k.FQ, T = k.T, GN = CT + 1;
@@ -378,9 +382,6 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const Tai
   }
   __syncthreads();
   STAMP(19);
-  if (with_tail && tl.ad.p != nullptr) {   // Adam on this block's lin.weight row (its weights live in s_wl from here on)
-    for (int e = tid; e < FQ; e += NT) adam_apply(tl.ad, tl.lin_w + m * FQ + e, s_glw[e]);
-  }
   // w' -> conv taps (adjoint of the box filter) and conv.bias; one slab row per m
   float* row = k.conv_slabs + (long long)m * (F * C * K + F);
   const float fP = (float)k.P;
@@ -393,31 +394,97 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const Tai
       for (int ch = 0; ch < QCH; ++ch) v += s_pm[(ch * F * C + fc) * JM + kk + p];
       s += v;
     }
-    row[e] = s / fP;
+    if (with_tail) __hip_atomic_store(row + e, s / fP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the last block
+    else row[e] = s / fP;
   }
-  for (int f = tid; f < F; f += NT) row[F * C * K + f] = gb * k.rowsum[m * F + f];
+  for (int f = tid; f < F; f += NT) {
+    const float v = gb * k.rowsum[m * F + f];
+    if (with_tail) __hip_atomic_store(row + F * C * K + f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else row[F * C * K + f] = v;
+  }
   STAMP(20);
   if (with_tail) {
+    // Hand-off of the conv rows to the last block to arrive, without a cache-wide release: the rows are stored with agent-scope (sc1,
+    // write-through) stores, drained (s_waitcnt vmcnt(0) ahead of the barrier) before one lane bumps the agent-scope counter; the block
+    // that sees the final count reads them behind an acquire (invalidate-only) fence.
     __shared__ int s_last;
-    __syncthreads();     // every wave's stores of this block's conv row have left the CU (s_waitcnt vmcnt(0) precedes the barrier)
-    if (tid == 0) {
-      __threadfence();   // release at agent scope (one lane: the L2 write-back covers the whole block's row)
-      s_last = (atomicAdd(tl.counter, 1u) == (unsigned)(k.Hc - 1)) ? 1 : 0;
-      if (s_last) __threadfence();   // acquire the other blocks' rows (invalidates this CU's L1, shared by all waves of the block)
+    // conv Adam state of the (up to two) elements this lane would finish as part 0 of the last block: fetched now, off the critical path
+    constexpr int NCI = 2;
+    const bool fast_conv = tl.lin_w <= NCI * (CNT / 4);
+    float cm[NCI], cv[NCI], cp[NCI];
+#pragma unroll
+    for (int u = 0; u < NCI; ++u) {
+      const int ci = min((tid >> 2) + u * (CNT / 4), tl.lin_w - 1);
+      const bool on = fast_conv && tl.ad.p != nullptr && (tid & 3) == 0;
+      cm[u] = on ? tl.ad.m[ci] : 0.f; cv[u] = on ? tl.ad.v[ci] : 0.f; cp[u] = on ? tl.ad.p[ci] : 0.f;
     }
     __syncthreads();
-    if (s_last) {   // conv.weight, conv.bias: 4 lanes per element, each summing every 4th row (fixed order), combined by two exchanges
-      for (int i0 = 0; i0 < tl.lin_w; i0 += NT / 4) {
-        const int i = min(i0 + (tid >> 2), tl.lin_w - 1), part = tid & 3;
-        const int nrow = (k.Hc - part + 3) / 4;
-        float g = strided_sum(tl.conv_slabs + (long long)part * tl.n_cv + (i - tl.conv_w), 4 * tl.n_cv, nrow);
-        g += __shfl_xor(g, 1, 64);
-        g += __shfl_xor(g, 2, 64);
-        if (part == 0 && i0 + (tid >> 2) < tl.lin_w) {
-          tl.grads[i] = g;
-          if (tl.ad.p) adam_apply(tl.ad, i, g);
+    if (tid == 0) {
+      s_last = (__hip_atomic_fetch_add(tl.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(k.Hc - 1)) ? 1 : 0;
+      if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // invalidate only (no L2 write-back): this CU's L1 serves the whole block
+    }
+    STAMP(21);
+    if (tl.ad.p != nullptr) {   // meanwhile: Adam on this block's lin.weight row (its weights live in s_wl), two elements in flight
+      for (int e0 = tid; e0 < FQ; e0 += 2 * NT) {
+        const int e1 = min(e0 + NT, FQ - 1), i0 = tl.lin_w + m * FQ + e0, i1 = tl.lin_w + m * FQ + e1;
+        const float g0 = s_glw[e0], g1 = s_glw[e1];
+        float m0 = tl.ad.m[i0], v0 = tl.ad.v[i0], p0 = tl.ad.p[i0], m1 = tl.ad.m[i1], v1 = tl.ad.v[i1], p1 = tl.ad.p[i1];
+        m0 = m0 + tl.ad.one_minus_b1 * (g0 - m0);
+        v0 = v0 * tl.ad.b2 + tl.ad.one_minus_b2 * g0 * g0;
+        tl.ad.p[i0] = p0 - tl.ad.step_size * (m0 / (sqrtf(v0) / tl.ad.sqrt_bc2 + tl.ad.eps));
+        tl.ad.m[i0] = m0;
+        tl.ad.v[i0] = v0;
+        if (e0 + NT < FQ) {
+          m1 = m1 + tl.ad.one_minus_b1 * (g1 - m1);
+          v1 = v1 * tl.ad.b2 + tl.ad.one_minus_b2 * g1 * g1;
+          tl.ad.p[i1] = p1 - tl.ad.step_size * (m1 / (sqrtf(v1) / tl.ad.sqrt_bc2 + tl.ad.eps));
+          tl.ad.m[i1] = m1;
+          tl.ad.v[i1] = v1;
         }
       }
+    }
+    STAMP(22);
+    __syncthreads();
+    STAMP(23);
+    if (s_last) STAMP_ANY(24);
+    if (s_last && fast_conv) {   // conv.weight, conv.bias: 4 lanes per element, each summing every 4th row (fixed order)
+      const int part = tid & 3, nrow = (k.Hc - part + 3) / 4;
+#pragma unroll
+      for (int u = 0; u < NCI; ++u) {
+        const int ci = min((tid >> 2) + u * (CNT / 4), tl.lin_w - 1);
+        const float* src = tl.conv_slabs + (long long)part * tl.n_cv + (ci - tl.conv_w);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int w = 0; w < nrow; w += 16) {
+          float v[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = src[(long long)min(w + q, nrow - 1) * 4 * tl.n_cv];   // 16 loads in flight, behind the acquire above
+#pragma unroll
+          for (int q = 0; q < 16; q += 4) {
+            a0 += (w + q < nrow) ? v[q] : 0.f;
+            a1 += (w + q + 1 < nrow) ? v[q + 1] : 0.f;
+            a2 += (w + q + 2 < nrow) ? v[q + 2] : 0.f;
+            a3 += (w + q + 3 < nrow) ? v[q + 3] : 0.f;
+          }
+        }
+        float g = (a0 + a1) + (a2 + a3);
+        g += __shfl_xor(g, 1, 64);
+        g += __shfl_xor(g, 2, 64);
+        if (part == 0 && (tid >> 2) + u * (CNT / 4) < tl.lin_w) {
+          tl.grads[ci] = g;
+          if (tl.ad.p) {   // adam_apply with the prefetched state
+            const float mi = cm[u] + tl.ad.one_minus_b1 * (g - cm[u]);
+            const float vi = cv[u] * tl.ad.b2 + tl.ad.one_minus_b2 * g * g;
+            tl.ad.p[ci] = cp[u] - tl.ad.step_size * (mi / (sqrtf(vi) / tl.ad.sqrt_bc2 + tl.ad.eps));
+            tl.ad.m[ci] = mi;
+            tl.ad.v[ci] = vi;
+          }
+        }
+      }
+    } else if (s_last) {   // more conv taps than that: generic loop
+      for (int i = tid; i < tl.lin_w; i += NT) tail_element(tl, i);
+    }
+    if (s_last) {
+      STAMP_ANY(25);
     }
   }
 }

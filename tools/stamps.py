@@ -20,8 +20,10 @@ eng.set_times(times)
 flat = eng.pack(p)
 obs_d = obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)
 loss, grads = torch.zeros(1, device=dev), torch.zeros(eng.n_params, device=dev)
-for _ in range(5):
-    eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss, grads)
+m_, v_ = torch.zeros_like(flat), torch.zeros_like(flat)
+u_d, eps_d = u.to(dev), eps.to(dev)
+for it in range(5):   # the bench's step: fused Adam
+    eng.elbo_adam_step(flat, obs_d, u_d, eps_d, loss, grads, m_, v_, 1e-3, it + 1)
 torch.cuda.synchronize()
 lib = _lib.load()
 for name, labels in (("ode", ["setup", "P0 latent/init", "P1 eval a,d", "P1 coeffs", "P2 scan", "P3 heads+LL", "P4 adj scan|head grads",
@@ -82,6 +84,7 @@ if hasattr(lib, "slode_debug_stamps_fold"):
     print("== folded-encoder kernels, workgroup 0 (us)")
     for lab, i, j in (("weff: w' to LDS", 0, 1), ("weff: W_eff rows", 1, 2), ("enc_fwd2: loads", 8, 9), ("enc_fwd2: lin+tanh", 9, 10), ("enc_fwd2:   W_eff stream+FMA (wave 0)", 9, 12), ("enc_fwd2:   wave sums+tanh (wave 0)", 12, 13), ("enc_fwd2:   wait for other waves", 13, 10),
                       ("enc_fwd2: heads", 10, 11), ("chain: staging", 16, 17), ("chain: (i) lin.w", 17, 18), ("chain: (ii) w' partial", 18, 19),
-                      ("chain: conv taps", 19, 20)):
+                      ("chain: conv taps", 19, 20), ("chain: barrier (block 0)", 20, 21), ("chain: Adam pass (block 0)", 21, 22), ("chain: 2nd barrier (block 0)", 22, 23),
+                      ("chain: start -> last block enters conv sum", 16, 24), ("chain: last block conv sum + Adam", 24, 25), ("chain: start -> rider 0 start", 16, 26), ("chain: rider 0", 26, 27)):
         if v[i] and v[j]:
             print("  %-42s %8.2f" % (lab, (v[j] - v[i]) / 100.0))
