@@ -23,6 +23,7 @@
 
 typedef const __attribute__((address_space(4))) float* cptr;  // uniform loads => s_load + SGPR operands
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #ifdef SLODE_STAMPS  // diagnostic build only: phase boundaries of workgroup 0 in 10 ns ticks (s_memrealtime)
 __device__ unsigned long long g_stamps_ode[32];
@@ -90,7 +91,7 @@ __host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int
   m.A = o; o += pad4(T * S);
   m.x = o; o += pad4(T * S);
   m.lam = o; o += pad4(T * S);
-  int stn = ((2 * S + 3) & ~3) * T; if (Q * C * T > stn) stn = Q * C * T;
+  int stn = ((2 * S + 4) & ~3) * T; if (Q * C * T > stn) stn = Q * C * T;   // stage rows: [a (S) | d (S) | t | pad], see SP
   // the epilogue's scratch (chunk partials (nthreads/32) x (2S+1) x 32, then head-weight partials 4 x Q*C*S) aliases A | x | lam | st
   const int eps_n = (nthreads / 32) * (2 * S + 1) * 32 + 4 * Q * C * S, have = 3 * pad4(T * S) + pad4(stn);
   if (eps_n > have) stn += eps_n - have;
@@ -396,11 +397,12 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
   static_assert(H < 32, "lane H of each half-wave carries the head-bias gradients");
   float acc_head = 0.f;  // one (q,c,s) head-weight entry (head-grad role)
   // hidden-unit-major role: lane jj = hidden unit, chunk = half-wave index
-  constexpr int SP = (2 * S + 3) & ~3;  // stage-row stride: [a/ga (S) | d/gd (S) | pad], 16-B aligned rows
+  constexpr int SP = (2 * S + 4) & ~3;  // stage-row stride: [a/ga (S) | d/gd (S) | stage time | pad], 16-B aligned rows
   const int jj_e = tid & 31, chunk_e = tid >> 5, nchunk = NT >> 5;
-  float acc_wg[S], acc_wd[S], acc_wt = 0.f;
+  f32x2 accw[S];   // [dLoss/dW_g[:, jj] (S) | dLoss/dW_d[:, jj] (S)] as S register pairs, same order as a stage row
+  float acc_wt = 0.f;
 #pragma unroll
-  for (int s = 0; s < S; ++s) { acc_wg[s] = 0.f; acc_wd[s] = 0.f; }
+  for (int s = 0; s < S; ++s) accw[s] = f32x2{0.f, 0.f};
   const int hg_base = 64;  // head-grad role lives on waves >= 1 (the launcher guarantees NT >= 64 + roundup64(Q*C*S))
   const int n_headw = Q * C * S;
   int hsplit = (NT - hg_base) / n_headw;  // time range split over hsplit threads per head-weight entry
@@ -746,11 +748,11 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
       // ---- P6: weight-gradient contraction, hidden-unit-major; one round per stage index r ---------------
       float gu_acc = 0.f;
       const float wtj = s_wt[jj];
-      float wgj[S], wdj[S];  // this lane's column of the two dynamics heads
+      float wj[2 * S];  // this lane's column of the two dynamics heads, in stage-row order
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        wgj[s] = (jj < H) ? s_par[k.o_wg + s * H + jj] : 0.f;
-        wdj[s] = (jj < H) ? s_par[k.o_wd + s * H + jj] : 0.f;
+        wj[s] = (jj < H) ? s_par[k.o_wg + s * H + jj] : 0.f;
+        wj[S + s] = (jj < H) ? s_par[k.o_wd + s * H + jj] : 0.f;
       }
       const int nsamp0 = k.uses_next ? T : T - 1;
       for (int r = 0; r < R; ++r) {
@@ -766,6 +768,7 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
             s_st[n * SP + s] = ga;
             s_st[n * SP + S + s] = gd;
           }
+          s_st[n * SP + 2 * S] = s_ts[R * n + r];   // the sample's stage time rides in the row
         }
         __syncthreads();
         if (jj <= H) {  // lane H: constant-1 unit => accumulates the head-bias gradients
@@ -775,24 +778,21 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
           const float uj = s_u[jj];
 #pragma unroll 2
           for (int i = i0; i < i1; ++i) {
-            const float t = s_ts[R * i + r];
+            f32x4 rv[SP / 4];   // whole row: SP/4 ds_read_b128, register pairs line up with accw for v_pk_fma_f32
+            const f32x4* row = reinterpret_cast<const f32x4*>(s_st + i * SP);
+#pragma unroll
+            for (int q4 = 0; q4 < SP / 4; ++q4) rv[q4] = row[q4];
+            const float t = rv[(2 * S) / 4][(2 * S) % 4];
             const float pre = fmaf(wtj, t, uj);
             const float hj = (jj == H) ? 1.f : fmaxf(pre, 0.f);
+            const f32x2 hj2 = {hj, hj};
             float gh = 0.f;
-            float gv[SP];
-            const float4* row = reinterpret_cast<const float4*>(s_st + i * SP);
 #pragma unroll
-            for (int q4 = 0; q4 < SP / 4; ++q4) {
-              const float4 v4 = row[q4];
-              gv[4 * q4] = v4.x; gv[4 * q4 + 1] = v4.y; gv[4 * q4 + 2] = v4.z; gv[4 * q4 + 3] = v4.w;
-            }
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-              const float ga = gv[s], gd = gv[S + s];
-              gh = fmaf(wgj[s], ga, gh);
-              gh = fmaf(wdj[s], gd, gh);
-              acc_wg[s] = fmaf(ga, hj, acc_wg[s]);
-              acc_wd[s] = fmaf(gd, hj, acc_wd[s]);
+            for (int c2 = 0; c2 < S; ++c2) {
+              const f32x2 g2 = (c2 & 1) ? f32x2{rv[c2 / 2].z, rv[c2 / 2].w} : f32x2{rv[c2 / 2].x, rv[c2 / 2].y};
+              gh = fmaf(wj[2 * c2], g2.x, gh);
+              gh = fmaf(wj[2 * c2 + 1], g2.y, gh);
+              accw[c2] = __builtin_elementwise_fma(g2, hj2, accw[c2]);
             }
             const float gp = (pre > 0.f) ? gh : 0.f;
             acc_wt = fmaf(gp, t, acc_wt);
@@ -977,8 +977,8 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
   if (BWD) {
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      tmp[(chunk_e * (2 * S + 1) + s) * 32 + jj_e] = acc_wg[s];
-      tmp[(chunk_e * (2 * S + 1) + S + s) * 32 + jj_e] = acc_wd[s];
+      tmp[(chunk_e * (2 * S + 1) + s) * 32 + jj_e] = ((s & 1) ? accw[s / 2].y : accw[s / 2].x);
+      tmp[(chunk_e * (2 * S + 1) + S + s) * 32 + jj_e] = (((S + s) & 1) ? accw[(S + s) / 2].y : accw[(S + s) / 2].x);
     }
     tmp[(chunk_e * (2 * S + 1) + 2 * S) * 32 + jj_e] = acc_wt;
     if (k.with_ll) {
