@@ -20,6 +20,7 @@
 //     gradients are fused in; per-workgroup partial gradients are accumulated in LDS across the workgroup's
 //     trajectories and written once as a slab (fixed-order reduction in misc_kernels.hip => bitwise reproducible).
 #include "slode_common.h"
+#include <cstdlib>
 
 typedef const __attribute__((address_space(4))) float* cptr;  // uniform loads => s_load + SGPR operands
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -97,12 +98,7 @@ __host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int
   if (eps_n > have) stn += eps_n - have;
   m.st = o; o += pad4(stn);
   m.stn = pad4(stn);
-  m.acc = o; o += pad4(npar + 1);  // [loss | priors | init net | dynamics | heads]; constant_std goes straight to the slab
-  m.par = o; o += pad4(npar);
   m.uu = o; o += SLODE_MAX_NU;
-  m.auxh = o; o += naux * 32;   // label heads scored in the main loss only
-  m.auxd = o; o += naux * 32;
-  m.auxgo = o; o += pad4(naux * 12);
   m.z = o; o += pad4(L);
   m.gzl = o; o += pad4(L);
   m.gpl = o; o += pad4(2 * L);  // [d(-log p)/d prior loc | eps]
@@ -119,31 +115,55 @@ __host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int
   m.red = o; o += 64;
   m.pf = o; o += 3 * pad4(L);
   m.meta = o; o += pad4(L) * 8;   // per latent dim: prior-net offsets (ints), see setup
+  // everything above depends on (T, S, C, L, Q, method, nthreads) only: compile-time offsets in the shape-specialised instantiations
+  m.auxh = o; o += naux * 32;   // label heads scored in the main loss only
+  m.auxd = o; o += naux * 32;
+  m.auxgo = o; o += pad4(naux * 12);
+  m.acc = o; o += pad4(npar + 1);  // [loss | priors | init net | dynamics | heads]; constant_std goes straight to the slab
+  m.par = o; o += pad4(npar);
   m.total = o;
   return m;
 }
 
 // a(t), d(t): models/blackbox_ode.py:97-109 with the z-part of the hidden pre-activation (s_u) hoisted.
+// The 2*S*H head weights arrive as SGPR operands (s_load through the constant address space), ONE ROW AHEAD of the row being
+// accumulated: with all 2*S rows in flight at once the scheduler overflowed the ~100 SGPRs and spilled them through VGPR lanes
+// (v_writelane / v_readlane: +22 % vector instructions in this phase).
 template <int S, int H>
 __device__ __forceinline__ void eval_ad(float t, const float* __restrict__ s_wt, const float* __restrict__ s_u,
                                         cptr wg, cptr bg, cptr wd, cptr bd, float (&a)[S], float (&d)[S]) {
-  // keep the ~2*S*H weight s_loads local to this call: hoisting them across the trajectory loop costs >100 SGPRs
+  // keep the weight s_loads local to this call: hoisting them across the trajectory loop costs >100 SGPRs
   asm volatile("" : "+s"(wg), "+s"(wd), "+s"(bg), "+s"(bd));
   const float* wt = (const float*)__builtin_assume_aligned(s_wt, 16);
   const float* uu = (const float*)__builtin_assume_aligned(s_u, 16);
   float h[H];
 #pragma unroll
   for (int j = 0; j < H; ++j) h[j] = fmaxf(fmaf(wt[j], t, uu[j]), 0.f);
+  float bias[2 * S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) { bias[s] = bg[s]; bias[S + s] = bd[s]; }
+  float wr[2][H];
+#pragma unroll
+  for (int j = 0; j < H; ++j) wr[0][j] = wg[j];
+  float out[2 * S];
+#pragma unroll
+  for (int r = 0; r < 2 * S; ++r) {   // row r of [W_g; W_d]
+    if (r + 1 < 2 * S) {
+      cptr nxt = (r + 1 < S) ? wg + (r + 1) * H : wd + (r + 1 - S) * H;
+      asm volatile("" : "+s"(nxt));   // the row's loads cannot be issued before this point
+#pragma unroll
+      for (int j = 0; j < H; ++j) wr[(r + 1) & 1][j] = nxt[j];
+    }
+    float acc = bias[r];
+#pragma unroll
+    for (int j = 0; j < H; ++j) acc = fmaf(wr[r & 1][j], h[j], acc);
+    asm volatile("" : "+v"(acc));   // row r is finished before row r+2's pointer is laundered: at most two rows of SGPRs live
+    out[r] = acc;
+  }
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    float xa = bg[s], xd = bd[s];
-#pragma unroll
-    for (int j = 0; j < H; ++j) {
-      xa = fmaf(wg[s * H + j], h[j], xa);
-      xd = fmaf(wd[s * H + j], h[j], xd);
-    }
-    a[s] = sigmoidf_fast(xa);
-    d[s] = sigmoidf_fast(xd);
+    a[s] = sigmoidf_fast(out[s]);
+    d[s] = sigmoidf_fast(out[S + s]);
   }
 }
 
@@ -276,13 +296,26 @@ __device__ __forceinline__ void wave_affine_scan(const float* __restrict__ s_A, 
   }
 }
 
-// S = 8 carries 60% more live state per thread: its instantiations trade one wave/SIMD for a 168-VGPR budget (T <= 768)
-template <int S, int H, bool BWD>
+__host__ __device__ constexpr int ode_threads_for(int T, int Q, int C, int S) {
+  // waves >= 1 carry the head-gradient role (one (q,c,s) entry per thread) next to the adjoint scan on wave 0
+  const int nt = ((T + 63) / 64) * 64, need = 64 + ((Q * C * S + 63) / 64) * 64;
+  return nt < need ? need : nt;
+}
+
+// S = 8 carries 60% more live state per thread: its instantiations trade one wave/SIMD for a 168-VGPR budget (T <= 768).
+// T_, C_, L_, Q_, M_ (time points, channels, latent dim, decoder heads, solver): 0 / -1 = read from the launch struct; the
+// shape-specialised instantiations (launcher: the BASELINE metric shape) get compile-time LDS offsets, loop bounds and solver.
+template <int S, int H, bool BWD, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1>
 __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, NT = blockDim.x;
-  const int T = k.T, C = k.C, L = k.L, R = k.R, Q = k.Q;
-  const LdsMap m = lds_map(T, S, H, C, L, Q, k.nt, k.nseg, k.npar, NT, k.n_aux_lds);
+  const int tid = threadIdx.x;
+  const int T = T_ ? T_ : k.T, C = C_ ? C_ : k.C, L = L_ ? L_ : k.L, Q = Q_ ? Q_ : k.Q;
+  const int method = M_ >= 0 ? M_ : k.method;
+  const int R = M_ >= 0 ? (M_ == SLODE_EULER ? 1 : (M_ == SLODE_MIDPOINT ? 2 : 3)) : k.R;
+  const int n_stage_t = (M_ >= 0 && T_) ? R * (T - 1) + 1 : k.nt;
+  const int uses_next = M_ >= 0 ? (M_ == SLODE_RK4 ? 1 : 0) : k.uses_next, gauss = Q_ ? (Q_ == 1 ? 1 : 0) : k.gauss;
+  const int NT = T_ ? ode_threads_for(T_, Q_, C_, S) : (int)blockDim.x;
+  const LdsMap m = lds_map(T, S, H, C, L, Q, n_stage_t, k.nseg, k.npar, NT, k.n_aux_lds);
   float* s_ts = smem + m.ts;
   float* s_dt = smem + m.dt;
   float* s_sig = smem + m.sig;
@@ -327,7 +360,7 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
   // round trip for the common sizes instead of one per table); tables longer than DEPTH * NT elements take further rounds
   {
     constexpr int DEPTH = 8;
-    const int n_ts = k.nt, n_par = k.npar, n_sig = k.with_ll ? C * T : 0, n_dt = T - 1;
+    const int n_ts = n_stage_t, n_par = k.npar, n_sig = k.with_ll ? C * T : 0, n_dt = T - 1;
     int rounds = 0;
     {
       const int nmax = max(max(n_ts, n_par), max(n_sig, n_dt));
@@ -556,16 +589,18 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
     }
     const int n = tid;
     const bool own_step = n < T - 1;
-    const bool own_last = (n == T - 1) && k.uses_next;
-    if (own_step || own_last) {
+    const bool own_last = (n == T - 1) && uses_next;
+    // every lane evaluates (idle lanes on a clamped time): under a divergent branch the compiler hoisted all R x 2*S*H weight
+    // s_loads above the branch and spilled them through VGPR lanes
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        if (r < R && (own_step || r == 0)) {
-          eval_ad<S, H>(s_ts[R * n + r], s_wt, s_u, wg, bg, wd, bd, av[r], dv[r]);
-          __builtin_amdgcn_sched_barrier(0);  // do not interleave the R evaluations (3x the live registers)
-        }
+    for (int r = 0; r < 3; ++r) {
+      if (r < R) {   // wave-uniform
+        eval_ad<S, H>(s_ts[min(R * n + r, n_stage_t - 1)], s_wt, s_u, wg, bg, wd, bd, av[r], dv[r]);
+        __builtin_amdgcn_sched_barrier(0);  // do not interleave the R evaluations (3x the live registers)
       }
-      if (k.uses_next) {
+    }
+    if (own_step || own_last) {
+      if (uses_next) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
           s_st[n * SP + s] = av[0][s];
@@ -580,14 +615,14 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         float a3 = 0.f, d3 = 0.f;
-        if (k.uses_next) {
+        if (uses_next) {
           a3 = s_st[(n + 1) * SP + s];
           d3 = s_st[(n + 1) * SP + S + s];
         }
         const float a4[4] = {av[0][s], av[1][s], av[2][s], a3};
         const float d4[4] = {dv[0][s], dv[1][s], dv[2][s], d3};
         float A, bb;
-        step_fwd(k.method, h, a4, d4, A, bb);
+        step_fwd(method, h, a4, d4, A, bb);
         s_A[n * S + s] = A;
         s_x[(n + 1) * S + s] = bb;
       }
@@ -634,7 +669,7 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
             for (int s = 0; s < S; ++s) mu = fmaf(W[s], xs[s], mu);
             const float r = obv - mu;
             float gmu;
-            if (k.gauss) {
+            if (gauss) {
               ll += -logf(sig) - 0.91893853320467274178f - 0.5f * r * r * inv * inv;
               gmu = -r * inv * inv;
               gsig += inv - r * r * inv * inv * inv;
@@ -697,7 +732,7 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
       STAMP(7);
       // ---- P5: reverse mode of the step coefficients (thread n <-> step n) ------------------------------
       // (the stage buffer is free again: re-exchange the first-stage values instead of carrying a3/d3 in registers)
-      if (k.uses_next && (own_step || own_last)) {
+      if (uses_next && (own_step || own_last)) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
           s_st[n * SP + s] = av[0][s];
@@ -712,14 +747,14 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
           const float gb = s_lam[(n + 1) * S + s];
           const float gA = gb * s_x[n * S + s];
           float a3 = 0.f, d3 = 0.f;
-          if (k.uses_next) {  // slot n+1 is read here and rewritten below by this thread only
+          if (uses_next) {  // slot n+1 is read here and rewritten below by this thread only
             a3 = s_st[(n + 1) * SP + s];
             d3 = s_st[(n + 1) * SP + S + s];
           }
           const float a4[4] = {av[0][s], av[1][s], av[2][s], a3};
           const float d4[4] = {dv[0][s], dv[1][s], dv[2][s], d3};
           float ga[4], gd[4];
-          step_bwd(k.method, h, a4, d4, gA, gb, ga, gd);
+          step_bwd(method, h, a4, d4, gA, gb, ga, gd);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {  // through the sigmoids
             ga[r] *= a4[r] * (1.f - a4[r]);
@@ -727,7 +762,7 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
           }
           av[0][s] = ga[0]; av[1][s] = ga[1]; av[2][s] = ga[2];
           dv[0][s] = gd[0]; dv[1][s] = gd[1]; dv[2][s] = gd[2];
-          if (k.uses_next) {  // contribution to the NEXT step's first stage (shared evaluation a(t_{n+1}))
+          if (uses_next) {  // contribution to the NEXT step's first stage (shared evaluation a(t_{n+1}))
             s_st[(n + 1) * SP + s] = ga[3];
             s_st[(n + 1) * SP + S + s] = gd[3];
           }
@@ -737,7 +772,7 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
         for (int s = 0; s < S; ++s) { av[0][s] = 0.f; dv[0][s] = 0.f; }
       }
       __syncthreads();
-      if (k.uses_next && (own_step || own_last) && n >= 1) {
+      if (uses_next && (own_step || own_last) && n >= 1) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
           av[0][s] += s_st[n * SP + s];
@@ -748,13 +783,13 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
       // ---- P6: weight-gradient contraction, hidden-unit-major; one round per stage index r ---------------
       float gu_acc = 0.f;
       const float wtj = s_wt[jj];
-      float wj[2 * S];  // this lane's column of the two dynamics heads, in stage-row order
+      f32x2 wj[S];  // this lane's column of the two dynamics heads, in stage-row order (register pairs)
 #pragma unroll
-      for (int s = 0; s < S; ++s) {
-        wj[s] = (jj < H) ? s_par[k.o_wg + s * H + jj] : 0.f;
-        wj[S + s] = (jj < H) ? s_par[k.o_wd + s * H + jj] : 0.f;
+      for (int c = 0; c < 2 * S; ++c) {
+        const float w = (jj < H) ? s_par[(c < S ? k.o_wg + c * H : k.o_wd + (c - S) * H) + jj] : 0.f;
+        if (c & 1) wj[c / 2].y = w; else wj[c / 2].x = w;
       }
-      const int nsamp0 = k.uses_next ? T : T - 1;
+      const int nsamp0 = uses_next ? T : T - 1;
       for (int r = 0; r < R; ++r) {
         __syncthreads();
         const int ns = (r == 0) ? nsamp0 : T - 1;
@@ -786,14 +821,14 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
             const float pre = fmaf(wtj, t, uj);
             const float hj = (jj == H) ? 1.f : fmaxf(pre, 0.f);
             const f32x2 hj2 = {hj, hj};
-            float gh = 0.f;
+            f32x2 gh2 = {0.f, 0.f};
 #pragma unroll
             for (int c2 = 0; c2 < S; ++c2) {
               const f32x2 g2 = (c2 & 1) ? f32x2{rv[c2 / 2].z, rv[c2 / 2].w} : f32x2{rv[c2 / 2].x, rv[c2 / 2].y};
-              gh = fmaf(wj[2 * c2], g2.x, gh);
-              gh = fmaf(wj[2 * c2 + 1], g2.y, gh);
+              gh2 = __builtin_elementwise_fma(wj[c2], g2, gh2);
               accw[c2] = __builtin_elementwise_fma(g2, hj2, accw[c2]);
             }
+            const float gh = gh2.x + gh2.y;
             const float gp = (pre > 0.f) ? gh : 0.f;
             acc_wt = fmaf(gp, t, acc_wt);
             gu_acc += gp;
@@ -1030,14 +1065,14 @@ __global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK
   STAMP(11);
 }
 
-template <int S, int H>
+template <int S, int H, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1>
 hipError_t launch_sh(const OdeK& k, int grid, int nthreads, size_t lds, bool bwd, hipStream_t stream) {
   if (bwd) {
-    hipFuncSetAttribute((const void*)ode_elbo_kernel<S, H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((ode_elbo_kernel<S, H, true>), dim3(grid), dim3(nthreads), lds, stream, k);
+    (void)hipFuncSetAttribute((const void*)ode_elbo_kernel<S, H, true, T_, C_, L_, Q_, M_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ode_elbo_kernel<S, H, true, T_, C_, L_, Q_, M_>), dim3(grid), dim3(nthreads), lds, stream, k);
   } else {
-    hipFuncSetAttribute((const void*)ode_elbo_kernel<S, H, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((ode_elbo_kernel<S, H, false>), dim3(grid), dim3(nthreads), lds, stream, k);
+    (void)hipFuncSetAttribute((const void*)ode_elbo_kernel<S, H, false, T_, C_, L_, Q_, M_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ode_elbo_kernel<S, H, false, T_, C_, L_, Q_, M_>), dim3(grid), dim3(nthreads), lds, stream, k);
   }
   return hipGetLastError();
 }
@@ -1045,12 +1080,7 @@ hipError_t launch_sh(const OdeK& k, int grid, int nthreads, size_t lds, bool bwd
 }  // namespace
 
 int slode_ode_threads(const slode_shape& s) {
-  int nt = ((s.T + 63) / 64) * 64;
-  // waves >= 1 carry the head-gradient role (one (q,c,s) entry per thread) next to the adjoint scan on wave 0
-  const int Q = s.likelihood == SLODE_GAUSS ? 1 : 3;
-  const int need = 64 + ((Q * s.C * s.S + 63) / 64) * 64;
-  if (nt < need) nt = need;
-  return nt;
+  return ode_threads_for(s.T, s.likelihood == SLODE_GAUSS ? 1 : 3, s.C, s.S);
 }
 
 static int n_stage(const slode_shape& s) {
@@ -1130,6 +1160,9 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
     snprintf(err, errlen, "ode kernel: ode_state_dim %d supports at most 768 time points (got T=%d)", s.S, s.T);
     return hipErrorInvalidValue;
   }
+  // shape-specialised instantiation: BASELINE configs [1]/[3] (cvs, T = 200, C = 3, latent 3+3+2, ALD 3 heads, rk4)
+  if (s.H == 25 && s.S == 5 && s.T == 200 && s.C == 3 && s.L == 8 && k.Q == 3 && s.method == SLODE_RK4 && !getenv("SLODE_ODE_GENERIC"))
+    return launch_sh<5, 25, 200, 3, 8, 3, SLODE_RK4>(k, a.grid, nthreads, lds, bwd, stream);
   if (s.H == 25 && s.S == 5) return launch_sh<5, 25>(k, a.grid, nthreads, lds, bwd, stream);
   if (s.H == 25 && s.S == 8) return launch_sh<8, 25>(k, a.grid, nthreads, lds, bwd, stream);
   snprintf(err, errlen, "ode kernel is instantiated for (ode_state_dim, ode_hidden_dim) in {(5,25),(8,25)}; got (%d,%d)", s.S, s.H);
