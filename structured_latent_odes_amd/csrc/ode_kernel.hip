@@ -1160,9 +1160,18 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
     snprintf(err, errlen, "ode kernel: ode_state_dim %d supports at most 768 time points (got T=%d)", s.S, s.T);
     return hipErrorInvalidValue;
   }
-  // shape-specialised instantiation: BASELINE configs [1]/[3] (cvs, T = 200, C = 3, latent 3+3+2, ALD 3 heads, rk4)
-  if (s.H == 25 && s.S == 5 && s.T == 200 && s.C == 3 && s.L == 8 && k.Q == 3 && s.method == SLODE_RK4 && !getenv("SLODE_ODE_GENERIC"))
-    return launch_sh<5, 25, 200, 3, 8, 3, SLODE_RK4>(k, a.grid, nthreads, lds, bwd, stream);
+  // shape-specialised instantiations (compile-time LDS offsets, loop bounds, solver): the BASELINE.json shapes and the reference default
+  if (s.H == 25 && !getenv("SLODE_ODE_GENERIC")) {
+#define SLODE_STATIC(SS, TT, CC, LL, QQ, MM)                                                              \
+    if (s.S == SS && s.T == TT && s.C == CC && s.L == LL && k.Q == QQ && s.method == MM)                  \
+      return launch_sh<SS, 25, TT, CC, LL, QQ, MM>(k, a.grid, nthreads, lds, bwd, stream)
+    SLODE_STATIC(5, 200, 3, 8, 3, SLODE_RK4);        // configs [1] / [3]: cvs, latent 3+3+2, ALD
+    SLODE_STATIC(5, 100, 3, 4, 3, SLODE_RK4);        // config [0]: cvs, latent 1+1+2
+    SLODE_STATIC(8, 100, 4, 50, 3, SLODE_RK4);       // config [2] shapes: proc (fixed-grid stand-in for dopri5)
+    SLODE_STATIC(5, 300, 4, 15, 1, SLODE_RK4);       // config [4]: challenge, Gauss
+    SLODE_STATIC(5, 86, 3, 15, 3, SLODE_MIDPOINT);   // reference default: training_cvs.py, config_cvs.py
+#undef SLODE_STATIC
+  }
   if (s.H == 25 && s.S == 5) return launch_sh<5, 25>(k, a.grid, nthreads, lds, bwd, stream);
   if (s.H == 25 && s.S == 8) return launch_sh<8, 25>(k, a.grid, nthreads, lds, bwd, stream);
   snprintf(err, errlen, "ode kernel is instantiated for (ode_state_dim, ode_hidden_dim) in {(5,25),(8,25)}; got (%d,%d)", s.S, s.H);
