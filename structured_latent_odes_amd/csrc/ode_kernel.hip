@@ -305,8 +305,11 @@ __host__ __device__ constexpr int ode_threads_for(int T, int Q, int C, int S) {
 // S = 8 carries 60% more live state per thread: its instantiations trade one wave/SIMD for a 168-VGPR budget (T <= 768).
 // T_, C_, L_, Q_, M_ (time points, channels, latent dim, decoder heads, solver): 0 / -1 = read from the launch struct; the
 // shape-specialised instantiations (launcher: the BASELINE metric shape) get compile-time LDS offsets, loop bounds and solver.
+// T_ <= 128 (2-wave workgroups: 6 instead of 7 resident per CU) takes the 168-VGPR budget as well (fewer spills); the S = 8, T_ <= 128 shape
+// (proc: 69 KB of LDS, 2 x 3 waves per CU) can use 256.
 template <int S, int H, bool BWD, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1>
-__global__ void __launch_bounds__(S > 5 ? 768 : 1024) ode_elbo_kernel(const OdeK k) {
+__global__ void __launch_bounds__((S > 5 && T_ > 0 && T_ <= 128) ? 512 : ((S > 5 || (T_ > 0 && T_ <= 128)) ? 768 : 1024))
+ode_elbo_kernel(const OdeK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int T = T_ ? T_ : k.T, C = C_ ? C_ : k.C, L = L_ ? L_ : k.L, Q = Q_ ? Q_ : k.Q;
@@ -1168,7 +1171,8 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
     SLODE_STATIC(5, 200, 3, 8, 3, SLODE_RK4);        // configs [1] / [3]: cvs, latent 3+3+2, ALD
     SLODE_STATIC(5, 100, 3, 4, 3, SLODE_RK4);        // config [0]: cvs, latent 1+1+2
     SLODE_STATIC(8, 100, 4, 50, 3, SLODE_RK4);       // config [2] shapes: proc (fixed-grid stand-in for dopri5)
-    SLODE_STATIC(5, 300, 4, 15, 1, SLODE_RK4);       // config [4]: challenge, Gauss
+    // (config [4], challenge-Gauss T = 300: the generic instantiation is the faster one -- at the 128-VGPR budget the specialised code
+    //  spilled and produced wrong gradients in test_gpu_parity, at 168 VGPRs it was 10 % slower than generic)
     SLODE_STATIC(5, 86, 3, 15, 3, SLODE_MIDPOINT);   // reference default: training_cvs.py, config_cvs.py
 #undef SLODE_STATIC
   }
