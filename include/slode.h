@@ -210,7 +210,12 @@ int slode_adam_step(slode_handle h, int64_t n, float* params, const float* grads
  * events on `stream` around each of its kernels; slode_profile_read waits for the last one and returns the durations in
  * milliseconds of [fold (W_eff), encoder_fwd, ode_elbo (fused solve + ELBO fwd/bwd), encoder_bwd (heads),
  * gemm (MFMA g_pre^T X), chain (back to lin/conv weights), reduce].  With non-dense observation strides the layer-by-layer
- * encoder runs instead: slot 0 = 0, slot 3 = its backward, slot 4 = its MFMA lin.weight GEMM, slot 5 = 0. */
+ * encoder runs instead: slot 0 = 0, slot 3 = its backward, slot 4 = its MFMA lin.weight GEMM, slot 5 = 0.
+ * on = 1: events around every kernel (each bracket costs the kernels ~2-3 us); on = 2 + s: only slot s is bracketed (two events per
+ * step: the least perturbed duration of that kernel; the other slots read 0); on = 0: off; on = 16 + r: no events, but the
+ * (idempotent) ode_elbo kernel is launched 1 + r times per step -- the difference of two timed runs is its in-stream duration without
+ * any event on the stream (bench.py).  In the folded-encoder step slots 3
+ * (encoder heads backward, now inside ode_elbo) and 6 (reduction, now inside the chain launch) only measure event overhead. */
 #define SLODE_PROFILE_SLOTS 7
 int slode_profile_enable(slode_handle h, int on);
 int slode_profile_read(slode_handle h, float ms[SLODE_PROFILE_SLOTS]);

@@ -85,7 +85,7 @@ int slode_create(slode_handle* out, int device_id) {
   c->device = device_id;
   c->num_cu = prop.multiProcessorCount;
   c->err[0] = 0;
-  c->profile = 0; c->ev_ready = 0; c->ev_valid = 0;
+  c->profile = 0; c->ev_ready = 0; c->ev_valid = 0; c->repeat_ode = 0;
   c->no_fold = getenv("SLODE_NO_FOLD") != nullptr;   // diagnostics: force the layer-by-layer encoder kernels
   *out = c;
   return SLODE_OK;
@@ -366,7 +366,8 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
   hipStream_t st = (hipStream_t)stream;
   const bool bwd = grads != nullptr;
   const bool prof = h->profile && h->ev_ready && bwd;
-#define SLODE_MARK(i) do { if (prof) (void)hipEventRecord(h->ev[i], st); } while (0)
+  // profile == 1: events around every kernel; profile == 2 + s: only around slot s (two events: least perturbation of that kernel)
+#define SLODE_MARK(i) do { if (prof && (h->profile == 1 || (i) == h->profile - 2 || (i) == h->profile - 1)) (void)hipEventRecord(h->ev[i], st); } while (0)
   SLODE_MARK(0);
 
   // Folded encoder (encoder_fused.hip) when every trajectory's C*T observations are one dense block; else layer by layer.
@@ -407,9 +408,11 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     a.g_loc = w.g_loc; a.g_scale = w.g_scale; a.slabs = w.ode_slabs; a.slab_stride = w.ode_stride; a.grid = w.ode_grid;
     a.backward = bwd ? 1 : 0; a.with_ll = 1;
     if (bwd && folded) { a.enc_hid = w.hid; a.g_pre = w.g_pre; a.glat = w.glat; a.g_loc = nullptr; a.g_scale = nullptr; }
-    e = slode_launch_ode(a, st, h->err, sizeof(h->err));
-    if (e == hipErrorInvalidValue) return SLODE_EINVAL;
-    HIP_TRY(h, e);
+    for (int rep = 0; rep <= h->repeat_ode; ++rep) {   // repeat_ode > 0: measurement aid (the kernel is idempotent)
+      e = slode_launch_ode(a, st, h->err, sizeof(h->err));
+      if (e == hipErrorInvalidValue) return SLODE_EINVAL;
+      HIP_TRY(h, e);
+    }
   }
   SLODE_MARK(3);
 
@@ -517,7 +520,13 @@ int slode_profile_enable(slode_handle h, int on) {
     for (int i = 0; i <= SLODE_PROFILE_SLOTS; ++i) HIP_TRY(h, hipEventCreate(&h->ev[i]));
     h->ev_ready = 1;
   }
-  h->profile = on ? 1 : 0;
+  if (on >= 16 && on < 32) {   // 16 + r: no events; the ode_elbo kernel is launched 1 + r times per step
+    h->repeat_ode = on - 16; h->profile = 0; h->ev_valid = 0;
+    return SLODE_OK;
+  }
+  if (on < 0 || on > 1 + SLODE_PROFILE_SLOTS) return fail(h, SLODE_EINVAL, "profile mode %d outside [0, %d]", on, 1 + SLODE_PROFILE_SLOTS);
+  h->repeat_ode = 0;
+  h->profile = on;
   h->ev_valid = 0;
   return SLODE_OK;
 }
@@ -525,8 +534,12 @@ int slode_profile_enable(slode_handle h, int on) {
 int slode_profile_read(slode_handle h, float ms[SLODE_PROFILE_SLOTS]) {
   if (!h || !ms) return fail(h, SLODE_EINVAL, "handle / ms is NULL");
   if (!h->ev_valid) return fail(h, SLODE_EINVAL, "no profiled slode_elbo_step (with gradients) has been recorded");
-  HIP_TRY(h, hipEventSynchronize(h->ev[SLODE_PROFILE_SLOTS]));
-  for (int i = 0; i < SLODE_PROFILE_SLOTS; ++i) HIP_TRY(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+  if (h->profile == 0) return fail(h, SLODE_EINVAL, "profiling is off");
+  HIP_TRY(h, hipEventSynchronize(h->ev[h->profile == 1 ? SLODE_PROFILE_SLOTS : h->profile - 1]));
+  for (int i = 0; i < SLODE_PROFILE_SLOTS; ++i) {
+    ms[i] = 0.f;
+    if (h->profile == 1 || i == h->profile - 2) HIP_TRY(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+  }
   return SLODE_OK;
 }
 

@@ -25,6 +25,7 @@ struct slode_ctx {
   int ev_ready;           // events created
   int ev_valid;           // a profiled step has been recorded
   int no_fold;            // env SLODE_NO_FOLD: use the layer-by-layer encoder kernels inside slode_elbo_step
+  int repeat_ode;         // measurement aid: extra (idempotent) launches of the ode_elbo kernel per step (slode_profile_enable)
 };
 
 // ---- device helpers -------------------------------------------------------------------------------------

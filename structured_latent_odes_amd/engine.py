@@ -71,6 +71,9 @@ def _check(lib, handle, rc):
         raise L.SlodeError("libslode call failed (%d): %s" % (rc, msg.decode() if msg else "?"))
 
 
+PROFILE_SLOT_NAMES = ("fold", "enc_fwd", "ode_elbo", "enc_bwd", "gemm", "chain", "reduce")   # include/slode.h, slode_profile_read
+
+
 class Engine:
     def __init__(self, spec: ModelSpec, n_time: int, device: Optional[torch.device] = None):
         self.lib = L.load()
@@ -310,14 +313,20 @@ class Engine:
             float(lr), float(betas[0]), float(betas[1]), float(eps), int(step), self._stream()))
 
 
-    def profile_enable(self, on: bool):
-        _check(self.lib, self.handle, self.lib.slode_profile_enable(self.handle, 1 if on else 0))
+    def profile_enable(self, on, only: Optional[str] = None):
+        """on: record HIP events around every kernel of elbo_step; only=<slot name>: bracket just that kernel (least perturbation)."""
+        mode = 0 if not on else (1 if only is None else 2 + PROFILE_SLOT_NAMES.index(only))
+        _check(self.lib, self.handle, self.lib.slode_profile_enable(self.handle, mode))
+
+    def repeat_ode_kernel(self, extra: int):
+        """Measurement aid: launch the (idempotent) ode_elbo kernel 1 + extra times per elbo_step (0 restores normal operation)."""
+        _check(self.lib, self.handle, self.lib.slode_profile_enable(self.handle, 16 + int(extra) if extra else 0))
 
     def profile_read(self):
         """Durations (ms) of the kernels of the last profiled elbo_step (include/slode.h, slode_profile_read)."""
         ms = (C.c_float * 7)()
         _check(self.lib, self.handle, self.lib.slode_profile_read(self.handle, ms))
-        return dict(zip(("fold", "enc_fwd", "ode_elbo", "enc_bwd", "gemm", "chain", "reduce"), [float(v) for v in ms]))
+        return dict(zip(PROFILE_SLOT_NAMES, [float(v) for v in ms]))
 
 
 def cvs_spec(z_iext=5, z_rtpr=5, z_eps=5, gauss=False, solver="midpoint", quantile_diff=0.475) -> ModelSpec:
