@@ -44,6 +44,11 @@ typedef enum slode_method { SLODE_EULER = 0, SLODE_MIDPOINT = 1, SLODE_RK4 = 2, 
 
 /* Decoder (models/decoders.py:8-54, asymmetric-Laplace, 3 heads q50/q75/q25) or GaussianDecoder (:57-91, 1 head) */
 typedef enum slode_likelihood { SLODE_ALD = 0, SLODE_GAUSS = 1 } slode_likelihood;
+/* SLODE_GRAD_EXACT: exact gradient of the discrete scheme (== reference with adjoint_solver=False).
+ * SLODE_GRAD_REFERENCE_ADJOINT: what torchdiffeq.odeint_adjoint returns, the reference default (models/blackbox_ode.py:40-42,
+ * adjoint_solver = True in all three configs): the continuous adjoint stepped backwards with the same fixed-grid method, and NO
+ * gradient to z through the dynamics (OdeFunc.constants is not a parameter, :55).  Fixed-grid methods, ELBO / solve backward. */
+typedef enum slode_grad_mode { SLODE_GRAD_EXACT = 0, SLODE_GRAD_REFERENCE_ADJOINT = 1 } slode_grad_mode;
 
 /* One conditional prior net p(z_g | u_g): EncoderMLP([u_dim, [z_dim, z_dim]], [None, Exp]);
  * models/mechanistic_cvs.py:88-100, mechanistic_proc.py:107-114, mechanistic_challenge.py:88-95 */
@@ -88,6 +93,7 @@ typedef struct slode_shape {
   float aux_mult;      /* config.aux_loss_multiplier                                       */
   slode_aux aux[SLODE_MAX_AUX];
   int32_t aux_in_main; /* 1: the main model scores the label heads too (proc family)       */
+  int32_t grad_mode;   /* slode_grad_mode: which gradient the backward pass returns         */
 } slode_shape;
 
 /* Offsets (in floats) of each parameter tensor inside the flat parameter / gradient vector.

@@ -159,6 +159,62 @@ def odeint_fixed(f: Callable[[Tensor, Tensor], Tensor], y0: Tensor, times: Tenso
     return torch.stack(sol, dim=0)
 
 
+_DYN_KEYS = ("dynamics.dynamics_hidden.weight", "dynamics.dynamics_hidden.bias", "dynamics.dyanamics_growth.weight",
+             "dynamics.dyanamics_growth.bias", "dynamics.dyanmics_degradation.weight", "dynamics.dyanmics_degradation.bias")
+
+
+class _OdeintAdjoint(torch.autograd.Function):
+    """Restatement of ``torchdiffeq.odeint_adjoint`` (third-party, absent; version unpinned => parity unpinned) for the fixed-grid
+    solvers, as the reference calls it by default (models/blackbox_ode.py:40-42; ``adjoint_solver = True`` in all three
+    configs).  Forward: plain ``odeint`` under no_grad.  Backward: for i = T-1 .. 1 the augmented state (y, a_y, a_params) is
+    integrated from t[i] to t[i-1] with the SAME fixed-grid method (one step: the grid is ``times``), where
+        d a_y / dt = -a_y^T df/dy,   d a_params / dt = -a_y^T df/dparams,
+    then y is reset to the stored forward value y[i-1] and a_y += grad_y[i-1].  ``adjoint_params = tuple(func.parameters())``:
+    the dynamics net only -- ``OdeFunc.constants`` (= z) is a plain tensor (blackbox_ode.py:55), so NO gradient reaches z through
+    the dynamics in this mode (SURVEY hard part 2); z still gets gradient through y0."""
+
+    @staticmethod
+    def forward(ctx, fb, y0, times, method, *params):
+        ctx.fb, ctx.method = fb, method
+        with torch.no_grad():
+            y = odeint_fixed(fb(params), y0, times, method)
+        ctx.save_for_backward(times, y, *params)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        times, y, *params = ctx.saved_tensors
+        fb, step = ctx.fb, _FIXED_STEPS[ctx.method]
+
+        class Aug:  # tuple state with the arithmetic the step functions use
+            def __init__(self, parts): self.parts = tuple(parts)
+            def __add__(self, o): return Aug(a + b for a, b in zip(self.parts, o.parts))
+            def __sub__(self, o): return Aug(a - b for a, b in zip(self.parts, o.parts))
+            def __mul__(self, c): return Aug(a * c for a in self.parts)
+            __rmul__ = __mul__
+
+        def aug_dyn(t, st):
+            yy, a = st.parts[0], st.parts[1]
+            with torch.enable_grad():
+                yy_ = yy.detach().requires_grad_(True)
+                pr = [q.detach().requires_grad_(True) for q in params]
+                fe = fb(pr)(t, yy_)
+                vj = torch.autograd.grad(fe, [yy_] + pr, -a, allow_unused=True)
+            vj = [v if v is not None else torch.zeros_like(x) for v, x in zip(vj, [yy_] + pr)]
+            return Aug([fe.detach(), vj[0]] + vj[1:])
+
+        with torch.no_grad():
+            a_y = grad_y[-1].clone()
+            a_p = [torch.zeros_like(q) for q in params]
+            for i in range(times.shape[0] - 1, 0, -1):
+                t0, t1 = times[i], times[i - 1]
+                st = Aug([y[i], a_y] + a_p)
+                st = st + step(aug_dyn, t0, t1 - t0, t1, st)
+                a_y = st.parts[1] + grad_y[i - 1]
+                a_p = list(st.parts[2:])
+        return (None, a_y, None, None, *a_p)
+
+
 def stage_times(times: Tensor, method: str) -> Tensor:
     """The distinct times at which a fixed-grid method evaluates f, in evaluation order, computed with the
     same fp32 arithmetic as the step functions above (t0 + dt*c).  Layout: R entries per step
@@ -294,9 +350,20 @@ def _dopri5_interp(t0, t1, y0, ymid, y1, f0, f1, t):
     return e + x * (d + x * (c + x * (b + x * a)))
 
 
-def solve_ode(p: Params, z: Tensor, times: Tensor, method: str, prefix: str = _ODE, **kw) -> Tensor:
-    """models/blackbox_ode.py:36-47 (OdeModel.solve_ODE) -> [B, T, S]."""
+def solve_ode(p: Params, z: Tensor, times: Tensor, method: str, prefix: str = _ODE, grad_mode: str = "exact", **kw) -> Tensor:
+    """models/blackbox_ode.py:36-47 (OdeModel.solve_ODE) -> [B, T, S].  grad_mode "exact": autograd through the unrolled solver
+    (== adjoint_solver=False); "reference_adjoint": torchdiffeq.odeint_adjoint's backward (the reference default, :40-42)."""
     x0 = initialize_state(p, z, prefix)                                            # :37
+    if grad_mode == "reference_adjoint" and method != "dopri5":
+        zc = z.detach()
+
+        def fb(params):
+            q = dict(p)
+            for k, v in zip(_DYN_KEYS, params):
+                q[prefix + k] = v
+            return lambda t, x: dynamics(q, t, x, zc, prefix)
+        sol = _OdeintAdjoint.apply(fb, x0, times, method, *[p[prefix + k] for k in _DYN_KEYS])
+        return sol.permute(1, 0, 2)
     if method == "dopri5":
         def fr(t, x):
             if t.dim() == 0:
@@ -397,6 +464,7 @@ class Spec:
     aux_heads: List[Tuple[str, str, int, int, int, int]] = field(default_factory=list)
     labels_in_main: bool = False   # proc: main model also scores the labels (mechanistic_proc.py:145-146)
     solver_kw: dict = field(default_factory=dict)
+    grad_mode: str = "exact"       # "exact" (adjoint_solver=False) | "reference_adjoint" (torchdiffeq.odeint_adjoint, the default)
 
 
 def cvs_spec(z_iext=5, z_rtpr=5, z_eps=5, gauss=False, solver="midpoint", quantile_diff=0.475, pool_size=5) -> Spec:
@@ -463,9 +531,9 @@ def prior_loc_scale(p: Params, spec: Spec, u: Tensor) -> Tuple[Tensor, Tensor]:
 
 def decode_loglik(p: Params, spec: Spec, obs: Tensor, z: Tensor, times: Tensor):
     if spec.gauss:
-        sol, mean, std = decoder_gauss(p, z, times, spec.solver, **spec.solver_kw)
+        sol, mean, std = decoder_gauss(p, z, times, spec.solver, grad_mode=spec.grad_mode, **spec.solver_kw)
         return gauss_loglik(obs, mean, std), (sol, mean, std)
-    sol, mu75, mu50, mu25, std = decoder_ald(p, z, times, spec.solver, **spec.solver_kw)
+    sol, mu75, mu50, mu25, std = decoder_ald(p, z, times, spec.solver, grad_mode=spec.grad_mode, **spec.solver_kw)
     return ald_loglik_3q(obs, mu75, mu50, mu25, std, spec.quantile_diff), (sol, mu75, mu50, mu25, std)
 
 

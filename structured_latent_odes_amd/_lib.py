@@ -11,6 +11,7 @@ AUX_KINDS = {"sigmoid": 0, "softmax": 1, "expexp": 2}
 EULER, MIDPOINT, RK4, DOPRI5 = 0, 1, 2, 3
 ALD, GAUSS = 0, 1
 METHODS = {"euler": EULER, "midpoint": MIDPOINT, "rk4": RK4, "dopri5": DOPRI5}
+GRAD_MODES = {"exact": 0, "reference_adjoint": 1}   # slode_grad_mode
 
 
 class Group(C.Structure):
@@ -25,7 +26,7 @@ class Shape(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "T", "C", "L", "S", "H", "F", "K", "P", "Hc", "n_u", "n_groups")] + [
         ("groups", Group * MAX_GROUPS), ("method", C.c_int32), ("likelihood", C.c_int32),
         ("quantile_diff", C.c_float), ("rtol", C.c_float), ("atol", C.c_float), ("n_aux", C.c_int32), ("U", C.c_int32),
-        ("aux_mult", C.c_float), ("aux", Aux * MAX_AUX), ("aux_in_main", C.c_int32)]
+        ("aux_mult", C.c_float), ("aux", Aux * MAX_AUX), ("aux_in_main", C.c_int32), ("grad_mode", C.c_int32)]
 
 
 class Layout(C.Structure):

@@ -237,6 +237,48 @@ __device__ __forceinline__ void step_bwd(int method, float h, const float a[4], 
   }
 }
 
+// ---- grad_mode = reference_adjoint: torchdiffeq.odeint_adjoint's backward for the fixed-grid solvers (blackbox_ode.py:40-42, the
+// reference default; oracle: _OdeintAdjoint).  From node n+1 back to node n (hb = t_n - t_{n+1} < 0) the augmented state
+// (y, lam, g_theta) takes ONE step of the same method, y restarting from the stored forward value:
+//   dlam/dt = +d(t) lam  =>  lam_n = M lam_{n+1} (+ dLoss/dx_n),      dg_theta/dt = -lam (a' dxa/dtheta - y d' dxd/dtheta).
+// D[j] = d at the j-th BACKWARD stage: node n+1, then the forward stages of step n in reverse order (rk4: r = 2, 1, 0).
+__device__ __forceinline__ float radj_M(int method, float hb, const float D[4]) {
+  if (method == SLODE_EULER) return 1.f + hb * D[0];
+  if (method == SLODE_MIDPOINT) return 1.f + hb * D[1] * (1.f + 0.5f * hb * D[0]);
+  const float h3 = hb * (1.0f / 3.0f);
+  const float m2 = 1.f + h3 * D[0];
+  const float m3 = 1.f + hb * (D[1] * m2 - D[0] * (1.0f / 3.0f));
+  const float m4 = 1.f + hb * (D[0] - D[1] * m2 + D[2] * m3);
+  return 1.f + hb * 0.125f * (D[0] + 3.f * (D[1] * m2 + D[2] * m3) + D[3] * m4);
+}
+// Quadrature of the parameter adjoint over one backward step: per backward stage j the weights of dxa/dtheta and dxd/dtheta
+// BEFORE the sigmoid derivatives: gaq[j] = -w_j lam_j, gdq[j] = +w_j lam_j y_j  (w = hb * RK weights).
+__device__ __forceinline__ void radj_stage_grads(int method, float hb, const float A[4], const float D[4], float lam, float y,
+                                                 float gaq[4], float gdq[4]) {
+  gaq[0] = gaq[1] = gaq[2] = gaq[3] = 0.f;
+  gdq[0] = gdq[1] = gdq[2] = gdq[3] = 0.f;
+  if (method == SLODE_EULER) {
+    gaq[0] = -hb * lam;
+    gdq[0] = hb * lam * y;
+  } else if (method == SLODE_MIDPOINT) {
+    const float ym = y + 0.5f * hb * (A[0] - D[0] * y), lm = (1.f + 0.5f * hb * D[0]) * lam;
+    gaq[1] = -hb * lm;
+    gdq[1] = hb * lm * ym;
+  } else {
+    const float h3 = hb * (1.0f / 3.0f), w1 = hb * 0.125f, w3 = hb * 0.375f;
+    const float k1 = A[0] - D[0] * y, m2 = 1.f + h3 * D[0];
+    const float y2 = y + h3 * k1, k2 = A[1] - D[1] * y2;
+    const float m3 = 1.f + hb * (D[1] * m2 - D[0] * (1.0f / 3.0f));
+    const float y3 = y + hb * (k2 - k1 * (1.0f / 3.0f)), k3 = A[2] - D[2] * y3;
+    const float m4 = 1.f + hb * (D[0] - D[1] * m2 + D[2] * m3);
+    const float y4 = y + hb * (k1 - k2 + k3);
+    gaq[0] = -w1 * lam;            gdq[0] = w1 * lam * y;
+    gaq[1] = -w3 * m2 * lam;       gdq[1] = w3 * m2 * lam * y2;
+    gaq[2] = -w3 * m3 * lam;       gdq[2] = w3 * m3 * lam * y3;
+    gaq[3] = -w1 * m4 * lam;       gdq[3] = w1 * m4 * lam * y4;
+  }
+}
+
 // Affine recurrence y_{k+1} = A[i(k)] * y_k + v[j(k)], k = 0..T-2, results stored back over v, executed by ONE wave.
 //   forward (REV=false): i = k,       j = k+1, y_0 = v[0]      (x_{n+1} = A_n x_n + b_n, b_n pre-stored in v[n+1])
 //   reverse (REV=true):  i = T-2-k,   j = i,   y_0 = v[T-1]    (lambda_i = A_i lambda_{i+1} + g_i)
@@ -307,7 +349,7 @@ __host__ __device__ constexpr int ode_threads_for(int T, int Q, int C, int S) {
 // shape-specialised instantiations (launcher: the BASELINE metric shape) get compile-time LDS offsets, loop bounds and solver.
 // T_ <= 128 (2-wave workgroups: 6 instead of 7 resident per CU) takes the 168-VGPR budget as well (fewer spills); the S = 8, T_ <= 128 shape
 // (proc: 69 KB of LDS, 2 x 3 waves per CU) can use 256.
-template <int S, int H, bool BWD, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1>
+template <int S, int H, bool BWD, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1, bool RA = false>
 __global__ void __launch_bounds__((S > 5 && T_ > 0 && T_ <= 128) ? 512 : ((S > 5 || (T_ > 0 && T_ <= 128)) ? 768 : 1024))
 ode_elbo_kernel(const OdeK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -317,6 +359,8 @@ ode_elbo_kernel(const OdeK k) {
   const int R = M_ >= 0 ? (M_ == SLODE_EULER ? 1 : (M_ == SLODE_MIDPOINT ? 2 : 3)) : k.R;
   const int n_stage_t = (M_ >= 0 && T_) ? R * (T - 1) + 1 : k.nt;
   const int uses_next = M_ >= 0 ? (M_ == SLODE_RK4 ? 1 : 0) : k.uses_next, gauss = Q_ ? (Q_ == 1 ? 1 : 0) : k.gauss;
+  // RA (grad_mode = reference_adjoint): the backward pass also needs a, d at node n+1 for euler / midpoint
+  const int need_next = RA ? 1 : uses_next;
   const int NT = T_ ? ode_threads_for(T_, Q_, C_, S) : (int)blockDim.x;
   const LdsMap m = lds_map(T, S, H, C, L, Q, n_stage_t, k.nseg, k.npar, NT, k.n_aux_lds);
   float* s_ts = smem + m.ts;
@@ -592,7 +636,7 @@ ode_elbo_kernel(const OdeK k) {
     }
     const int n = tid;
     const bool own_step = n < T - 1;
-    const bool own_last = (n == T - 1) && uses_next;
+    const bool own_last = (n == T - 1) && (uses_next || (BWD && need_next));
     // every lane evaluates (idle lanes on a clamped time): under a divergent branch the compiler hoisted all R x 2*S*H weight
     // s_loads above the branch and spilled them through VGPR lanes
 #pragma unroll
@@ -708,6 +752,30 @@ ode_elbo_kernel(const OdeK k) {
     }
 
     if (BWD) {
+      if (RA) {
+        // reference_adjoint: the adjoint recurrence runs on the backward step maps M_n (see radj_M), exchanged / stored through s_A
+        // (the forward A is dead; the stage buffer still holds P3's dLoss/dmu for the head-gradient role)
+        __syncthreads();
+        if (own_step || own_last) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) s_A[n * S + s] = dv[0][s];
+        }
+        __syncthreads();
+        float Mn[S];
+        if (own_step) {
+          const float hb = -s_dt[n];
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            const float D[4] = {s_A[(n + 1) * S + s], method == SLODE_RK4 ? dv[2][s] : dv[1][s], dv[1][s], dv[0][s]};
+            Mn[s] = radj_M(method, hb, D);
+          }
+        }
+        __syncthreads();
+        if (own_step) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) s_A[n * S + s] = Mn[s];
+        }
+      }
       __syncthreads();
       STAMP(6);
       // ---- P4: adjoint scan (wave 0) || head-weight gradients (waves >= 1) ------------------------------
@@ -735,7 +803,7 @@ ode_elbo_kernel(const OdeK k) {
       STAMP(7);
       // ---- P5: reverse mode of the step coefficients (thread n <-> step n) ------------------------------
       // (the stage buffer is free again: re-exchange the first-stage values instead of carrying a3/d3 in registers)
-      if (uses_next && (own_step || own_last)) {
+      if (need_next && (own_step || own_last)) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
           s_st[n * SP + s] = av[0][s];
@@ -750,14 +818,27 @@ ode_elbo_kernel(const OdeK k) {
           const float gb = s_lam[(n + 1) * S + s];
           const float gA = gb * s_x[n * S + s];
           float a3 = 0.f, d3 = 0.f;
-          if (uses_next) {  // slot n+1 is read here and rewritten below by this thread only
+          if (need_next) {  // slot n+1 is read here and rewritten below by this thread only
             a3 = s_st[(n + 1) * SP + s];
             d3 = s_st[(n + 1) * SP + S + s];
           }
           const float a4[4] = {av[0][s], av[1][s], av[2][s], a3};
           const float d4[4] = {dv[0][s], dv[1][s], dv[2][s], d3};
           float ga[4], gd[4];
-          step_bwd(method, h, a4, d4, gA, gb, ga, gd);
+          if (RA) {
+            // backward stages: node n+1, then this step's forward stages in reverse; gb = lambda at node n+1 (after its jump)
+            const int r2 = method == SLODE_RK4 ? 2 : 1;
+            const float Ab[4] = {a3, a4[r2], a4[1], a4[0]}, Db[4] = {d3, d4[r2], d4[1], d4[0]};
+            float gaq[4], gdq[4];
+            radj_stage_grads(method, -h, Ab, Db, gb, s_x[(n + 1) * S + s], gaq, gdq);
+            // back to the forward slots (0..2 = this step's stages, 3 = node n+1)
+            ga[3] = gaq[0]; gd[3] = gdq[0];
+            ga[0] = ga[1] = ga[2] = 0.f; gd[0] = gd[1] = gd[2] = 0.f;
+            if (method == SLODE_RK4) { ga[2] = gaq[1]; gd[2] = gdq[1]; ga[1] = gaq[2]; gd[1] = gdq[2]; ga[0] = gaq[3]; gd[0] = gdq[3]; }
+            else if (method == SLODE_MIDPOINT) { ga[1] = gaq[1]; gd[1] = gdq[1]; }
+          } else {
+            step_bwd(method, h, a4, d4, gA, gb, ga, gd);
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {  // through the sigmoids
             ga[r] *= a4[r] * (1.f - a4[r]);
@@ -765,7 +846,7 @@ ode_elbo_kernel(const OdeK k) {
           }
           av[0][s] = ga[0]; av[1][s] = ga[1]; av[2][s] = ga[2];
           dv[0][s] = gd[0]; dv[1][s] = gd[1]; dv[2][s] = gd[2];
-          if (uses_next) {  // contribution to the NEXT step's first stage (shared evaluation a(t_{n+1}))
+          if (need_next) {  // contribution to the NEXT step's first stage (shared evaluation a(t_{n+1}))
             s_st[(n + 1) * SP + s] = ga[3];
             s_st[(n + 1) * SP + S + s] = gd[3];
           }
@@ -775,7 +856,7 @@ ode_elbo_kernel(const OdeK k) {
         for (int s = 0; s < S; ++s) { av[0][s] = 0.f; dv[0][s] = 0.f; }
       }
       __syncthreads();
-      if (uses_next && (own_step || own_last) && n >= 1) {
+      if (need_next && (own_step || own_last) && n >= 1) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
           av[0][s] += s_st[n * SP + s];
@@ -792,7 +873,7 @@ ode_elbo_kernel(const OdeK k) {
         const float w = (jj < H) ? s_par[(c < S ? k.o_wg + c * H : k.o_wd + (c - S) * H) + jj] : 0.f;
         if (c & 1) wj[c / 2].y = w; else wj[c / 2].x = w;
       }
-      const int nsamp0 = uses_next ? T : T - 1;
+      const int nsamp0 = need_next ? T : T - 1;
       for (int r = 0; r < R; ++r) {
         __syncthreads();
         const int ns = (r == 0) ? nsamp0 : T - 1;
@@ -879,7 +960,7 @@ ode_elbo_kernel(const OdeK k) {
         const int l = tid & (Lp - 1), part = tid / Lp, lc = min(l, L - 1);
         float gz = 0.f;
         for (int j = part; j < H; j += parts) {
-          gz = fmaf(s_par[k.o_wh + j * (1 + L) + 1 + lc], s_gu[j], gz);
+          if (!RA) gz = fmaf(s_par[k.o_wh + j * (1 + L) + 1 + lc], s_gu[j], gz);   // reference_adjoint: z is not an adjoint parameter
           gz = fmaf(s_par[k.o_w1 + j * L + lc], s_gp0[j], gz);
         }
         for (int off = Lp; off < 64; off <<= 1) gz += __shfl_xor(gz, off, 64);
@@ -1069,8 +1150,15 @@ ode_elbo_kernel(const OdeK k) {
 }
 
 template <int S, int H, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1>
-hipError_t launch_sh(const OdeK& k, int grid, int nthreads, size_t lds, bool bwd, hipStream_t stream) {
-  if (bwd) {
+hipError_t launch_sh(const OdeK& k, int grid, int nthreads, size_t lds, bool bwd, hipStream_t stream, bool ra = false) {
+  if (bwd && ra) {
+    if constexpr (T_ == 0) {   // reference_adjoint backward: generic instantiation only
+      (void)hipFuncSetAttribute((const void*)ode_elbo_kernel<S, H, true, 0, 0, 0, 0, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((ode_elbo_kernel<S, H, true, 0, 0, 0, 0, -1, true>), dim3(grid), dim3(nthreads), lds, stream, k);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  } else if (bwd) {
     (void)hipFuncSetAttribute((const void*)ode_elbo_kernel<S, H, true, T_, C_, L_, Q_, M_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((ode_elbo_kernel<S, H, true, T_, C_, L_, Q_, M_>), dim3(grid), dim3(nthreads), lds, stream, k);
   } else {
@@ -1164,7 +1252,8 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
     return hipErrorInvalidValue;
   }
   // shape-specialised instantiations (compile-time LDS offsets, loop bounds, solver): the BASELINE.json shapes and the reference default
-  if (s.H == 25 && !getenv("SLODE_ODE_GENERIC")) {
+  const bool ra = bwd && s.grad_mode == SLODE_GRAD_REFERENCE_ADJOINT;
+  if (s.H == 25 && !ra && !getenv("SLODE_ODE_GENERIC")) {
 #define SLODE_STATIC(SS, TT, CC, LL, QQ, MM)                                                              \
     if (s.S == SS && s.T == TT && s.C == CC && s.L == LL && k.Q == QQ && s.method == MM)                  \
       return launch_sh<SS, 25, TT, CC, LL, QQ, MM>(k, a.grid, nthreads, lds, bwd, stream)
@@ -1176,8 +1265,8 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
     SLODE_STATIC(5, 86, 3, 15, 3, SLODE_MIDPOINT);   // reference default: training_cvs.py, config_cvs.py
 #undef SLODE_STATIC
   }
-  if (s.H == 25 && s.S == 5) return launch_sh<5, 25>(k, a.grid, nthreads, lds, bwd, stream);
-  if (s.H == 25 && s.S == 8) return launch_sh<8, 25>(k, a.grid, nthreads, lds, bwd, stream);
+  if (s.H == 25 && s.S == 5) return launch_sh<5, 25>(k, a.grid, nthreads, lds, bwd, stream, ra);
+  if (s.H == 25 && s.S == 8) return launch_sh<8, 25>(k, a.grid, nthreads, lds, bwd, stream, ra);
   snprintf(err, errlen, "ode kernel is instantiated for (ode_state_dim, ode_hidden_dim) in {(5,25),(8,25)}; got (%d,%d)", s.S, s.H);
   return hipErrorInvalidValue;
 }

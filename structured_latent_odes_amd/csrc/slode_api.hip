@@ -59,6 +59,7 @@ static const char* check_shape(const slode_shape* s) {
     if (x.z_off < 0 || x.z_dim < 1 || x.z_off + x.z_dim > s->L) return "aux head latent range outside [0, L)";
     if (x.u_off < 0 || x.u_dim < 1 || x.u_dim > 8 || x.u_off + x.u_dim > s->n_u) return "aux head label range outside [0, n_u) or wider than 8";
   }
+  if (s->grad_mode != SLODE_GRAD_EXACT && s->grad_mode != SLODE_GRAD_REFERENCE_ADJOINT) return "grad_mode must be SLODE_GRAD_EXACT or SLODE_GRAD_REFERENCE_ADJOINT";
   return nullptr;
 }
 

@@ -59,6 +59,9 @@ class ModelSpec:
     aux_mult: float = 46.0
     rtol: float = 1e-7      # dopri5 only (torchdiffeq defaults)
     atol: float = 1e-9
+    # "exact": gradient of the discrete scheme (== adjoint_solver=False); "reference_adjoint": torchdiffeq.odeint_adjoint's backward,
+    # the reference default (config.adjoint_solver = True; models/blackbox_ode.py:40-42) -- no gradient to z through the dynamics
+    grad_mode: str = "exact"
 
     @property
     def head_names(self) -> List[str]:
@@ -111,7 +114,8 @@ class Engine:
                         F=sp.n_filters, K=sp.filter_size, P=sp.pool_size, Hc=sp.cnn_hidden_dim, n_u=sp.n_u,
                         n_groups=len(sp.prior_groups), method=L.METHODS[sp.solver],
                         likelihood=L.GAUSS if sp.gauss else L.ALD, quantile_diff=sp.quantile_diff, rtol=sp.rtol, atol=sp.atol,
-                        n_aux=len(sp.aux_heads), U=sp.u_hidden_dim, aux_mult=sp.aux_mult, aux_in_main=int(sp.labels_in_main))
+                        n_aux=len(sp.aux_heads), U=sp.u_hidden_dim, aux_mult=sp.aux_mult, aux_in_main=int(sp.labels_in_main),
+                        grad_mode=L.GRAD_MODES[sp.grad_mode])
             for i, a in enumerate(sp.aux_heads):
                 s.aux[i] = L.Aux(L.AUX_KINDS[a.kind], a.z_off, a.z_dim, a.u_off, a.u_dim)
             for i, g in enumerate(sp.prior_groups):

@@ -101,7 +101,10 @@ class MechanisticBase(nn.Module):
                          aux_heads=aux, labels_in_main=self.LABELS_IN_MAIN, u_hidden_dim=self.u_hidden_dim, aux_mult=self.aux_loss_multiplier,
                          ode_state_dim=cfg.ode_state_dim, ode_hidden_dim=cfg.ode_hidden_dim, n_filters=cfg.n_filters,
                          filter_size=cfg.filter_size, pool_size=cfg.pool_size, cnn_hidden_dim=cfg.cnn_hidden_dim,
-                         solver=cfg.solver, quantile_diff=cfg.quantile_diff)
+                         solver=cfg.solver, quantile_diff=cfg.quantile_diff,
+                         # config.adjoint_solver (True in all three reference configs) selects torchdiffeq.odeint_adjoint
+                         # (models/blackbox_ode.py:40-42): its gradients are reproduced by grad_mode "reference_adjoint"
+                         grad_mode="reference_adjoint" if (getattr(cfg, "adjoint_solver", False) and cfg.solver != "dopri5") else "exact")
 
     def _bind(self):
         """Create the engine and move every parameter into the flat vector (first hot-path use; needs a HIP device)."""

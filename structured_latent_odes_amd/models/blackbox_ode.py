@@ -1,8 +1,9 @@
 """models/blackbox_ode.py of the reference (OdeModel, OdeFunc, Dynamics) on the HIP engine.
 
-``OdeModel.solve_ODE`` = ``slode_ode_solve_fwd`` (+ ``slode_ode_solve_bwd`` under autograd): no torchdiffeq.  Gradients are the
-exact discrete ones (the reference's ``adjoint_solver=False`` path); ``adjoint_solver`` is accepted and ignored (SURVEY
-hard part 2, row N2)."""
+``OdeModel.solve_ODE`` = ``slode_ode_solve_fwd`` (+ ``slode_ode_solve_bwd`` under autograd): no torchdiffeq.
+``adjoint_solver=False``: exact gradients of the discrete scheme (autograd through ``torchdiffeq.odeint``);
+``adjoint_solver=True`` (the reference default, :40-42): the gradients ``torchdiffeq.odeint_adjoint`` returns -- continuous
+adjoint stepped backwards with the same fixed-grid method, no gradient to z through the dynamics (SURVEY hard part 2, row N2)."""
 from __future__ import annotations
 
 import torch
@@ -103,7 +104,8 @@ class OdeModel(nn.Module):
             dev = self.latent_to_ode_net[0].weight.device
             T = int(self.times.numel())
             spec = ModelSpec("ode_only", True, 3, self.latent_dim, self.latent_dim, 0, [], ode_state_dim=self.ode_state_dim,
-                             ode_hidden_dim=self.ode_hidden_dim, solver=self.solver)
+                             ode_hidden_dim=self.ode_hidden_dim, solver=self.solver,
+                             grad_mode="reference_adjoint" if (self.adjoint_solver and self.solver != "dopri5") else "exact")
             if T < 14:
                 spec.filter_size, spec.pool_size = 1, 1   # the (unused) encoder segment must still be a valid shape
             named = self._named_for_binding()

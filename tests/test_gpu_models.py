@@ -37,7 +37,9 @@ def _cvs(gauss=False, solver="midpoint", T=86, B=24):
                 p.add_(0.3 * torch.randn_like(p))
     obs, labels, _ = synthetic_batch("cvs", B, T, 3, seed=7)
     batch = {"observations": obs.to(dev), "iext": labels["iext"].to(dev), "rtpr": labels["rtpr"].to(dev)}
-    ospec = O.cvs_spec(gauss=gauss, solver=solver)
+    import dataclasses
+    ospec = dataclasses.replace(O.cvs_spec(gauss=gauss, solver=solver), grad_mode=m.model_spec().grad_mode)   # config: adjoint_solver=True
+    assert ospec.grad_mode == "reference_adjoint"
     return m, cfg, batch, ospec, dev
 
 
@@ -143,22 +145,23 @@ def test_module_level_autograd_matches_oracle():
     assert _rel(enc.conv.weight.grad, p["encoder.conv.weight"].grad) < 3e-4
     assert _rel(enc.z_scale[0].bias.grad, p["encoder.z_scale.0.bias"].grad) < 3e-4
 
-    om = OdeModel()
-    times = torch.arange(0.0, 40.0, device=dev) * 0.5
-    om.init_with_params(times=times, ode_state_dim=5, latent_dim=8, ode_hidden_dim=25, adjoint_solver=True, solver="midpoint", device=dev)
-    om.to(dev)
-    z = torch.randn(7, 8, device=dev, requires_grad=True)
-    sol = om.solve_ODE(z)
-    w = torch.randn(7, 40, 5, device=dev)
-    (sol * w).sum().backward()
-    q = {"decoder.ode_model." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in om.state_dict().items() if ".prod." not in k and ".degr." not in k}
-    zz = z.detach().cpu().clone().requires_grad_(True)
-    want = O.solve_ode(q, zz, times.cpu(), "midpoint")
-    (want * w.cpu()).sum().backward()
-    assert _close(sol.detach(), want.detach())
-    assert _rel(z.grad, zz.grad) < 5e-4
-    assert _rel(om.dynamics.dynamics_hidden.weight.grad, q["decoder.ode_model.dynamics.dynamics_hidden.weight"].grad) < 5e-4
-    assert _rel(om.latent_to_ode_net[2].weight.grad, q["decoder.ode_model.latent_to_ode_net.2.weight"].grad) < 5e-4
+    for adjoint in (True, False):   # torchdiffeq.odeint_adjoint (reference default) / odeint
+        om = OdeModel()
+        times = torch.arange(0.0, 40.0, device=dev) * 0.5
+        om.init_with_params(times=times, ode_state_dim=5, latent_dim=8, ode_hidden_dim=25, adjoint_solver=adjoint, solver="midpoint", device=dev)
+        om.to(dev)
+        z = torch.randn(7, 8, device=dev, requires_grad=True)
+        sol = om.solve_ODE(z)
+        w = torch.randn(7, 40, 5, device=dev)
+        (sol * w).sum().backward()
+        q = {"decoder.ode_model." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in om.state_dict().items() if ".prod." not in k and ".degr." not in k}
+        zz = z.detach().cpu().clone().requires_grad_(True)
+        want = O.solve_ode(q, zz, times.cpu(), "midpoint", grad_mode="reference_adjoint" if adjoint else "exact")
+        (want * w.cpu()).sum().backward()
+        assert _close(sol.detach(), want.detach())
+        assert _rel(z.grad, zz.grad) < 5e-4
+        assert _rel(om.dynamics.dynamics_hidden.weight.grad, q["decoder.ode_model.dynamics.dynamics_hidden.weight"].grad) < 5e-4
+        assert _rel(om.latent_to_ode_net[2].weight.grad, q["decoder.ode_model.latent_to_ode_net.2.weight"].grad) < 5e-4
     # OdeFunc.forward(t, state) and initialize_state
     f = om.gen_dynamics(z.detach())
     st = torch.rand(7, 5, device=dev)

@@ -418,3 +418,49 @@ def test_abi_error_paths():
     assert lib.slode_elbo_step(*a) == -1 and b"forward-only" in lib.slode_last_error(h)
     assert lib.slode_adam_step(h, 10, p(flat), p(grads), p(flat), p(flat), 1e-3, 0.9, 0.999, 1e-8, 0, None) == -1   # step < 1
     assert lib.slode_elbo_step(*args()) == 0 and torch.isfinite(loss).all()      # the handle stays usable after errors
+
+
+# ---- grad_mode = "reference_adjoint": torchdiffeq.odeint_adjoint's gradients, the reference default ------------
+RA_CASES = {
+    "cvs_rk4": ("cvs", dict(z_iext=3, z_rtpr=3, z_eps=2, solver="rk4"), 9, 120),
+    "cvs_ref_default_midpoint": ("cvs", dict(), 7, 86),            # training_cvs.py defaults: midpoint, adjoint_solver=True
+    "cvs_euler_gauss": ("cvs", dict(gauss=True, solver="euler"), 5, 64),
+    "challenge_gauss_rk4": ("challenge", dict(gauss=True, solver="rk4"), 6, 150),
+    "proc_rk4": ("proc", dict(z_g=3, z_eps=2, solver="rk4"), 6, 100),
+}
+
+
+@pytest.mark.parametrize("case", list(RA_CASES))
+def test_reference_adjoint_gradients(case):
+    """The HIP backward in reference_adjoint mode == the oracle's restatement of odeint_adjoint (fp64): continuous adjoint stepped
+    backwards with the same fixed-grid method, no z -> dynamics gradient; the loss value is the same as in exact mode."""
+    import dataclasses
+    from structured_latent_odes_amd import engine as E
+    fam, kw, B, T = RA_CASES[case]
+    ospec = {"cvs": O.cvs_spec, "challenge": O.challenge_spec, "proc": O.proc_spec}[fam](**kw)
+    ospec = dataclasses.replace(ospec, grad_mode="reference_adjoint")
+    espec = dataclasses.replace({"cvs": E.cvs_spec, "challenge": E.challenge_spec, "proc": E.proc_spec}[fam](**kw), grad_mode="reference_adjoint")
+    S = 8 if fam == "proc" else 5
+    p = O.init_params(ospec, T=T, S=S)
+    g = torch.Generator().manual_seed(5)
+    p = {k: v + 0.05 * torch.randn(v.shape, generator=g) for k, v in p.items()}
+    obs, u, eps, times = O.synthetic_batch(ospec, B, T)
+    dev = torch.device("cuda:0")
+    eng = E.Engine(espec, T, dev)
+    eng.set_times(times)
+    flat = eng.pack(p)
+    obs_d = obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)
+    loss = torch.zeros(1, device=dev)
+    grads = torch.full((eng.n_params,), float("nan"), device=dev)
+    eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss, grads=grads)
+    p64 = {k: v.double() for k, v in p.items()}
+    want_loss, want = O.loss_and_grads(p64, ospec, obs.double(), u.double(), eps.double(), times.double())
+    assert abs(loss.item() - want_loss.item()) / abs(want_loss.item()) < 1e-5
+    assert torch.isfinite(grads).all()
+    got = eng.unpack(grads)
+    bad = {k: _rel(v, want[k]) for k, v in got.items() if _rel(v, want[k]) > 5e-4}
+    assert not bad, bad
+    # and it is NOT the exact-mode gradient: the encoder sees no z -> dynamics term
+    exact_spec = dataclasses.replace(ospec, grad_mode="exact")
+    _, exact = O.loss_and_grads(p64, exact_spec, obs.double(), u.double(), eps.double(), times.double())
+    assert _rel(got["encoder.z_loc.weight"], exact["encoder.z_loc.weight"]) > 1e-3
