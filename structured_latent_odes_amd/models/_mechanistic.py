@@ -219,3 +219,47 @@ class MechanisticBase(nn.Module):
             solution_xt, mu_75, mu_50, mu_25, std = self.decoder.forward(z=z)
             return {"l1": self.l1_func(mu_50, observations), "solution_xt": solution_xt, "mu_75": mu_75, "mu_50": mu_50,
                     "mu_25": mu_25, "std": std, "z": z}
+
+    def recon_samples(self, observations, is_post, num_samples: int, eps=None, **labels):
+        """``multiple_samples`` of the reference (training_proc.py:205-223, training_cvs.py / training_challenge.py alike): it calls
+        ``recon`` ``num_samples`` times (config.num_samples = 200) and concatenates the quantile curves along a new last axis.
+        Here the ``num_samples`` latent draws of the whole batch go through ONE ODE solve + ONE head launch
+        (``num_samples * B`` trajectories).  Returns a dict of tensors shaped ``[B, C, T, num_samples]`` (``mu_25/mu_50/mu_75``, or
+        ``mean`` for the Gaussian family) plus ``z`` ``[num_samples, B, L]``.  ``eps`` (``[num_samples, B, L]`` standard normal
+        draws, optional) makes the result reproducible."""
+        self._bind()
+        with torch.no_grad():
+            B, ns = observations.shape[0], int(num_samples)
+            if is_post:
+                loc, scale = self.encoder.forward(observations)
+            else:
+                ploc, pscale = self._prior_loc_scale(labels)
+                zeros = torch.zeros(B, self.z_epsilon_dim, device=ploc.device)
+                loc, scale = torch.cat((ploc, zeros), 1), torch.cat((pscale, torch.ones_like(zeros)), 1)
+            if eps is None:
+                eps = torch.randn(ns, B, loc.shape[1], device=loc.device)
+            z = loc.unsqueeze(0) + scale.unsqueeze(0) * eps.to(loc.device)               # [ns, B, L]
+            out = self.decoder.forward(z=z.reshape(ns * B, -1).contiguous())
+            names = ("solution_xt", "mean", "std") if self.GAUSS else ("solution_xt", "mu_75", "mu_50", "mu_25", "std")
+            res = {"z": z}
+            for name, val in zip(names, out):
+                if name in ("solution_xt", "std"):
+                    continue
+                res[name] = val.reshape(ns, B, val.shape[1], val.shape[2]).permute(1, 2, 3, 0).contiguous()   # [B, C, T, ns]
+            return res
+
+    def save_recon_samples(self, results_dir: str, observations, is_post, num_samples: int, **labels):
+        """Writes the arrays ``multiple_samples`` saves, under the reference's file names (``mu_50_post_sample.npy`` ...)."""
+        import os
+        import numpy as np
+        res = self.recon_samples(observations, is_post, num_samples, **labels)
+        os.makedirs(results_dir, exist_ok=True)
+        tag = "post_sample" if is_post else "prior_sample"
+        written = []
+        for name in ("mu_50", "mu_75", "mu_25", "mean"):
+            if name in res:
+                path = os.path.join(results_dir, "%s_%s.npy" % (name, tag))
+                np.save(path, res[name].cpu().numpy())
+                written.append(path)
+        return written
+

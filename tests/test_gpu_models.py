@@ -202,3 +202,27 @@ def test_training_entry_points_run(family):
     assert 0 <= best_epoch <= 2
     assert all(torch.isfinite(p).all() for p in var_model.parameters())
     assert all(torch.isfinite(p).all() for p in best_model.parameters())
+
+
+def test_recon_samples_is_one_batched_launch_of_recon(tmp_path):
+    """`multiple_samples` (num_samples Monte-Carlo reconstructions) as one batched solve; same numbers as looping
+    over `recon`-style single draws, reference file naming for the .npy dump."""
+    import numpy as np
+    m, cfg, batch, ospec, dev = _cvs(solver="rk4")
+    ns, B = 5, batch["observations"].shape[0]
+    eps = torch.randn(ns, B, m.latent_dim, generator=torch.Generator().manual_seed(2)).to(dev)
+    res = m.recon_samples(batch["observations"], True, ns, eps=eps, iext=batch["iext"], rtpr=batch["rtpr"])
+    assert res["mu_50"].shape == (B, 3, cfg.seq_len, ns) and res["z"].shape == (ns, B, m.latent_dim)
+    p = _oracle_params(m)
+    with torch.no_grad():
+        loc, scale = O.encoder_conv(p, batch["observations"].cpu(), ospec.pool_size)
+        for i in range(ns):
+            z = loc + scale * eps[i].cpu()
+            sol, mu75, mu50, mu25, std = O.decoder_ald(p, z, m.times.cpu(), "rk4")
+            assert _close(res["mu_50"][..., i], mu50, 2e-5) and _close(res["mu_75"][..., i], mu75, 2e-5) and _close(res["mu_25"][..., i], mu25, 2e-5)
+    # prior samples: conditional prior for the label groups, N(0, 1) for z_epsilon
+    resp = m.recon_samples(batch["observations"], False, 3, iext=batch["iext"], rtpr=batch["rtpr"])
+    assert resp["mu_50"].shape == (B, 3, cfg.seq_len, 3) and torch.isfinite(resp["mu_50"]).all()
+    files = m.save_recon_samples(str(tmp_path / "results_Mechanistic"), batch["observations"], True, 4, iext=batch["iext"], rtpr=batch["rtpr"])
+    assert sorted(os.path.basename(f) for f in files) == ["mu_25_post_sample.npy", "mu_50_post_sample.npy", "mu_75_post_sample.npy"]
+    assert np.load(files[0]).shape == (B, 3, cfg.seq_len, 4)
