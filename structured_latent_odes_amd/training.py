@@ -1,11 +1,13 @@
 """Shared body of the three entry points (training_cvs.py / training_proc.py / training_challenge.py of the reference):
 ``train(config)`` with the reference's structure -- two SVI objects sharing one Adam (training_cvs.py:226-249), an epoch loop of
 ``run_batch`` (:147-157, :256-266), validation with ``evaluate_loss`` + ``recon`` + label prediction (:43-144), best-model copy
-(:325-331) and the per-epoch summary line (:336-352).  The reference's CSV / pickle loaders are out of scope:
-batches come from ``synthetic.synthetic_batch`` unless the caller passes its own list of batch dicts."""
+(:325-331) and the per-epoch summary line (:336-352).  Batches come from ``synthetic.synthetic_batch`` unless ``--data-dir`` points at
+the reference's data files (cvs: ``processed_data.pkl`` ...; challenge: ``data.pkl``), which are then read by ``data.py`` (SURVEY row
+N3) and fed through pinned host buffers, or the caller passes its own list of batch dicts."""
 from __future__ import annotations
 
 import logging
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -91,14 +93,15 @@ def train(config, family: str, model_cls, model_cls_gauss, batches_per_epoch: in
     elbo = Trace_ELBO(num_particles=config.num_particles)
     losses = [SVI(var_model.model, var_model.guide, optimizer, loss=elbo),
               SVI(var_model.model_meta, var_model.guide_meta, optimizer, loss=elbo)]
-    train_b = list(train_batches) if train_batches is not None else make_batches(config, family, batches_per_epoch, seed=1000)
-    val_b = list(val_batches) if val_batches is not None else make_batches(config, family, 1, seed=5000)
+    # batch sources may be lists or re-iterable feeders (data.BatchFeeder: a fresh pass, reshuffled, every epoch)
+    train_b = train_batches if train_batches is not None else make_batches(config, family, batches_per_epoch, seed=1000)
+    val_b = val_batches if val_batches is not None else make_batches(config, family, 1, seed=5000)
     best_val_loss, best_epoch = np.inf, 0
     names = FAMILY_LABELS[family][:2]
     for epoch in range(config.num_epochs + 1):
         epoch_loss = [run_batch(batch_to_device(b, device, family), losses) for b in train_b]
         val = input_pred_stats(val_b, var_model, losses, True, device, family)
-        trn = input_pred_stats(train_b[:1], var_model, losses, True, device, family)
+        trn = input_pred_stats([next(iter(train_b))], var_model, losses, True, device, family)
         val_elbo = torch.sum(val["elbo"]) * len(val["elbo"])
         improved = ""
         if best_val_loss >= val_elbo:
@@ -112,15 +115,51 @@ def train(config, family: str, model_cls, model_cls_gauss, batches_per_epoch: in
     return var_model, best_model, best_epoch
 
 
+def real_batches(config, family: str, data_dir: str):
+    """(train_batches, val_batches) read from the reference's data files with the reference's transforms and splits
+    (training_cvs.py:168-190, training_challenge.py:226-246); each an iterable of host batch dicts re-read every epoch."""
+    from . import data as D
+    dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    if family == "cvs":
+        tf = D.create_transforms(config.norm, D._torch_load(os.path.join(data_dir, "data_norm_params.pkl")))
+        tr = D.CVSDataset(data_dir, "train", config.seq_len, False, tf)
+        va = D.CVSDataset(data_dir, "val", config.seq_len, False, tf)
+    elif family == "challenge":
+        pair = D.build_challenge_datasets(os.path.join(data_dir, "data.pkl"), config.seed, config.folds, config.split)
+        tf = D.create_transforms(config.norm, pair.data_norm_params)
+        tr, va = D.ChallengeDataset(pair.train, transforms=tf), D.ChallengeDataset(pair.test, transforms=tf)
+    else:
+        raise ValueError("--data-dir is wired for the cvs and challenge families (proc: data.load_proc_csv / ProcDataset)")
+    class _AsBCT:
+        """The datasets yield [B, T, C]; the models take the [B, C, T] permuted VIEW of it (training_cvs.py:25: no copy)."""
+
+        def __init__(self, feeder):
+            self.feeder = feeder
+
+        def __len__(self):
+            return len(self.feeder)
+
+        def __iter__(self):
+            for b in self.feeder:
+                b["observations"] = b["observations"].permute(0, 2, 1)
+                yield b
+
+    return (_AsBCT(D.BatchFeeder(tr, config.mini_batch_size, dev, shuffle=True, seed=config.seed)),
+            _AsBCT(D.BatchFeeder(va, config.mini_batch_size, dev)))
+
+
 def main(family: str, load_config, model_cls, model_cls_gauss):
     import argparse
-    import os
     ap = argparse.ArgumentParser()
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--batches-per-epoch", type=int, default=7)
+    ap.add_argument("--data-dir", default=None, help="directory with the reference's data files (default: synthetic batches)")
     a = ap.parse_args()
     config = load_config()
     config.num_epochs = a.epochs
     os.makedirs("results_%s" % config.model, exist_ok=True)
     logging.basicConfig(filename="results_%s/model.log" % config.model, filemode="w", level=logging.DEBUG)
-    train(config, family, model_cls, model_cls_gauss, a.batches_per_epoch)
+    kw = {}
+    if a.data_dir:
+        kw["train_batches"], kw["val_batches"] = real_batches(config, family, a.data_dir)
+    train(config, family, model_cls, model_cls_gauss, a.batches_per_epoch, **kw)

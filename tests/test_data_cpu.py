@@ -1,0 +1,128 @@
+"""Real-data front end: readers, transforms, splits and the pinned-buffer feeder, on files written by the test in the
+reference's on-disk formats; when the reference tree is present (this container, not the GPU box) the readers are also run on its
+shipped data files (shapes and label conventions only -- nothing from those files is copied)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from structured_latent_odes_amd import data as D
+
+REF = "/root/reference/data"
+
+
+def _write_cvs(tmp, n_train=40, n_test=7, T=30, C=3, seed=0):
+    rng = np.random.default_rng(seed)
+    obs = {"train": rng.normal(size=(n_train, T, C)) * 3 + 50, "test": rng.normal(size=(n_test, T, C)) * 3 + 50}
+    par = lambda n: {"i_ext": rng.choice([0.0, -0.2], size=n), "r_tpr_mod": rng.choice([0.0, 0.5], size=n)}
+    trp, tep = par(n_train), par(n_test)
+    torch.save(obs, os.path.join(tmp, "processed_data.pkl"))
+    torch.save(trp, os.path.join(tmp, "train_params_data.pkl"))
+    torch.save(tep, os.path.join(tmp, "test_params_data.pkl"))
+    return obs, trp, tep
+
+
+def test_cvs_dataset_split_labels_and_transform(tmp_path):
+    obs, trp, tep = _write_cvs(str(tmp_path))
+    params = D.find_norm_params(obs["train"])
+    assert np.allclose(params["std"], obs["train"].reshape(-1, 3).std(0)) and np.allclose(params["max"], obs["train"].max((0, 1)))
+    tf = D.create_transforms("zero_to_one", params)
+    tr = D.CVSDataset(str(tmp_path) + "/", "train", 20, False, tf)
+    va = D.CVSDataset(str(tmp_path) + "/", "val", 20, False, tf)
+    te = D.CVSDataset(str(tmp_path) + "/", "test", 20, False, tf)
+    assert (len(tr), len(va), len(te)) == (36, 4, 7)                      # first 90 % / rest / test
+    s = va[1]
+    want = (obs["train"][37, :20] - params["min"]) / (params["max"] - params["min"])
+    assert s["observations"].shape == (20, 3) and np.allclose(s["observations"].numpy(), want, atol=1e-6)
+    assert s["iext"].item() == float(trp["i_ext"][37] >= 0) and s["rtpr"].item() == float(trp["r_tpr_mod"][37] > 0)
+    back = tf["normalize"].denormalize(s["observations"][None])
+    assert np.allclose(back[0].numpy(), obs["train"][37, :20], rtol=1e-5, atol=1e-3)
+    z = D.create_transforms("zscore", params)["normalize"]
+    assert np.allclose(z(torch.as_tensor(obs["train"][0])).numpy(), (obs["train"][0] - params["mean"]) / params["std"], atol=1e-5)
+    with pytest.raises(ValueError):
+        D.create_transforms("nope", params)
+    # random window start stays inside the series
+    rs = D.CVSDataset(str(tmp_path) + "/", "train", 20, True, tf)
+    assert all(rs[i]["observations"].shape == (20, 3) for i in range(10))
+
+
+def test_kfold_and_holdout_splits():
+    tr, va = D.kfold_ids(35, 5, 5, 12)
+    assert len(va) == 7 and len(tr) == 28 and not set(tr) & set(va) and sorted(set(tr) | set(va)) == list(range(35))
+    assert np.array_equal(va, np.sort(va)) and np.array_equal(D.kfold_ids(35, 5, 5, 12)[1], va)          # seeded
+    folds = [D.kfold_ids(35, 5, k, 12)[1] for k in range(1, 6)]
+    assert sorted(np.concatenate(folds).tolist()) == list(range(35))                                      # folds partition the data
+    np.random.seed(12)
+    assert np.array_equal(va, np.sort(np.array_split(np.random.permutation(35), 5)[4]))                 # the reference's recipe
+    tr, va = D.holdout_ids(np.array([0, 1, 2, 1, 0, 2, 2]), 2)
+    assert va.tolist() == [2, 5, 6] and tr.tolist() == [0, 1, 3, 4]
+
+
+def test_challenge_pair_and_feeder(tmp_path):
+    rng = np.random.default_rng(1)
+    data = {"observations": rng.random((35, 142, 4)), "shedding": rng.integers(0, 2, (35, 1)).astype(float),
+            "symptoms": rng.integers(0, 2, (35, 1)).astype(float), "n_time": 142}
+    path = str(tmp_path / "data.pkl")
+    with open(path, "wb") as fh:
+        pickle.dump(data, fh)
+    pair = D.build_challenge_datasets(path, seed=12, folds=5, split=5)
+    assert pair.n_train == 28 and pair.n_test == 7 and pair.max_time == 142
+    assert np.allclose(pair.data_norm_params["min"], pair.train["observations"].min((0, 1)))
+    ds = D.ChallengeDataset(pair.train, transforms=D.create_transforms("zero_to_one", pair.data_norm_params))
+    feeder = D.BatchFeeder(ds, batch_size=10, device=torch.device("cpu"))
+    batches = list(feeder)
+    assert len(feeder) == 3 and [b["observations"].shape[0] for b in batches] == [10, 10, 8]
+    assert batches[0]["observations"].shape == (10, 142, 4) and batches[0]["observations"].is_contiguous()      # [B, T, C]
+    assert torch.equal(batches[2]["observations"][3], ds[23]["observations"]) and torch.equal(batches[1]["shedding"][0], ds[10]["shedding"])
+    assert float(batches[0]["observations"].min()) >= 0.0 and float(batches[0]["observations"].max()) <= 1.0
+    sh = D.BatchFeeder(ds, batch_size=10, device=torch.device("cpu"), shuffle=True, seed=3, drop_last=True)
+    got = torch.cat([b["shedding"] for b in sh])
+    assert got.shape[0] == 20 and len(sh) == 2
+
+
+def test_proc_csv_reader(tmp_path):
+    # two tiny plate-reader files in the reference's column layout
+    def write(name, devs, conds, T, t_scale):
+        sigs = ["EYFP", "ECFP", "mRFP1", "OD"]
+        cols = ["Content", "Colony", "Well Col", "Well Row", "Content"] + ["Raw Data (%s) %d - x" % (s, k + 1) for s in sigs for k in range(T)]
+        times = ["", "", "", "", ""] + [t_scale * k for _ in sigs for k in range(T)]
+        rows = [times]
+        for i, (d, c) in enumerate(zip(devs, conds)):
+            rows.append([d, "", str(i + 1), "A", c] + [float(10 * si + i + 0.01 * k) for si in range(4) for k in range(T)])
+        import csv
+        with open(os.path.join(str(tmp_path), name), "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(cols)
+            w.writerows(rows)
+    write("a.csv", ["R33S32_Y81C76", "Pcat_Y81C76", "XXX"], ["C6=25000", "C12=1.5", "C6=1"], 6, 0.2)
+    write("b.csv", ["R33S32_Y81C76", "R33S32_Y81C76"], ["C6=0", "EtOH=2"], 8, 0.15)
+    devices = ["Pcat_Y81C76", "R33S32_Y81C76"]
+    dmap = {d: float(i) for i, d in enumerate(devices)}
+    sig = ["OD", "mRFP1", "EYFP", "ECFP"]
+    pa = D.load_proc_csv(str(tmp_path / "a.csv"), devices, dmap, ["C6", "C12"], sig)
+    pb = D.load_proc_csv(str(tmp_path / "b.csv"), devices, dmap, ["C6", "C12"], sig)
+    dev, tr, times, obs = pa
+    assert dev.tolist() == [1, 0] and tr.tolist() == [[25000.0, 0.0], [0.0, 1.5]] and obs.shape == (2, 4, 6)
+    assert np.allclose(times, 0.2 * np.arange(6)) and np.allclose(obs[0, 0], 30 + 0 + 0.01 * np.arange(6))     # signal order: OD first
+    assert pb[0].tolist() == [1] and pb[3].shape == (1, 4, 8)                                                # EtOH row dropped
+    assert D.load_proc_csv(str(tmp_path / "a.csv"), ["nope"], {"nope": 0.0}, ["C6"], sig) is None
+    ds = D.ProcDataset([pa, pb], subtract_background=True, dev_1hot_fn=lambda d: np.eye(2, dtype=np.float32)[d])
+    assert len(ds) == 3 and ds.observations.shape == (3, 4, 8)                                              # grid of the file with fewest series
+    assert np.allclose(ds.inputs[0].numpy(), np.log(1.0 + np.array([25000.0, 0.0])))
+    assert float(ds.observations.min()) == 0.0 and float(ds.observations.max()) <= 1.0
+    assert ds[2]["dev_1hot"].tolist() == [0.0, 1.0]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference data tree not present (GPU box)")
+def test_readers_on_the_shipped_reference_files():
+    tr = D.CVSDataset(REF + "/cvs/", "train", 86, False, D.create_transforms("zero_to_one", D._torch_load(REF + "/cvs/data_norm_params.pkl")))
+    assert len(tr) == 810 and tr[0]["observations"].shape == (86, 3) and set(float(tr[i]["iext"]) for i in range(50)) <= {0.0, 1.0}
+    assert len(D.CVSDataset(REF + "/cvs/", "val", 86, False)) == 90 and len(D.CVSDataset(REF + "/cvs/", "test", 86, False)) == 100
+    pair = D.build_challenge_datasets(REF + "/challenge/data.pkl", seed=12, folds=5, split=5)
+    assert (pair.n_train, pair.n_test, pair.max_time) == (28, 7, 142) and pair.train["observations"].shape == (28, 142, 4)
+    devices = ["Pcat_Y81C76", "RS100S32_Y81C76", "RS100S34_Y81C76", "R33S32_Y81C76", "R33S34_Y81C76", "R33S175_Y81C76"]
+    dmap = {d: float(i) for i, d in enumerate(devices)}
+    parsed = D.load_proc_csv(REF + "/proc/proc140916.csv", devices, dmap, ["C6", "C12"], ["OD", "mRFP1", "EYFP", "ECFP"])
+    assert parsed is not None and parsed[3].shape[1:] == (4, 100) and parsed[1].shape[1] == 2 and len(parsed[2]) == 100

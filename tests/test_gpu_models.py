@@ -226,3 +226,37 @@ def test_recon_samples_is_one_batched_launch_of_recon(tmp_path):
     files = m.save_recon_samples(str(tmp_path / "results_Mechanistic"), batch["observations"], True, 4, iext=batch["iext"], rtpr=batch["rtpr"])
     assert sorted(os.path.basename(f) for f in files) == ["mu_25_post_sample.npy", "mu_50_post_sample.npy", "mu_75_post_sample.npy"]
     assert np.load(files[0]).shape == (B, 3, cfg.seq_len, 4)
+
+
+def test_training_on_reference_format_files(tmp_path):
+    """SURVEY row N3 end to end: cvs / challenge files in the reference's on-disk formats -> data.py readers, transforms, splits ->
+    pinned-buffer feeder -> the epoch loop (two SVI objects, one Adam)."""
+    import pickle
+    import training_cvs, training_challenge
+    from structured_latent_odes_amd import training as TR
+    rng = np.random.default_rng(0)
+    d = str(tmp_path) + "/"
+    obs = {"train": rng.random((70, 86, 3)) * 40 + 60, "test": rng.random((9, 86, 3)) * 40 + 60}
+    torch.save(obs, d + "processed_data.pkl")
+    for name, n in (("train", 70), ("test", 9)):
+        torch.save({"i_ext": rng.choice([0.0, -0.2], size=n), "r_tpr_mod": rng.choice([0.0, 0.5], size=n)}, d + name + "_params_data.pkl")
+    from structured_latent_odes_amd.data import find_norm_params
+    torch.save(find_norm_params(obs["train"]), d + "data_norm_params.pkl")
+    cfg = training_cvs.load_config()
+    cfg.num_epochs, cfg.mini_batch_size = 1, 24
+    trb, vab = TR.real_batches(cfg, "cvs", d)
+    assert len(trb) == 3 and len(vab) == 1                       # 63 train / 7 val series
+    b0 = next(iter(trb))
+    assert b0["observations"].is_cuda and b0["observations"].shape == (24, 3, 86) and b0["observations"].stride() == (258, 1, 3)   # [B,C,T] view of [B,T,C]
+    assert 0.0 <= float(b0["observations"].min()) and float(b0["observations"].max()) <= 1.0
+    vm, bm, be = training_cvs.train(cfg, train_batches=trb, val_batches=vab)
+    assert all(torch.isfinite(p).all() for p in vm.parameters())
+    with open(d + "data.pkl", "wb") as fh:
+        pickle.dump({"observations": rng.random((35, 142, 4)), "shedding": rng.integers(0, 2, (35, 1)).astype(float),
+                     "symptoms": rng.integers(0, 2, (35, 1)).astype(float), "n_time": 142}, fh)
+    cfg = training_challenge.load_config()
+    cfg.num_epochs, cfg.mini_batch_size = 1, 16
+    trb, vab = TR.real_batches(cfg, "challenge", d)
+    assert len(trb) == 2 and len(vab) == 1                       # 28 / 7 by the seeded 5-fold split
+    vm, bm, be = training_challenge.train(cfg, train_batches=trb, val_batches=vab)
+    assert all(torch.isfinite(p).all() for p in vm.parameters())
