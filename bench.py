@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)   # ~0.25 s timed: dilutes a sporadic 40 ms host/box stall
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grad-mode", choices=["exact", "reference_adjoint"], default="exact",
+                    help="exact: gradient of the discrete scheme (adjoint_solver=False); reference_adjoint: torchdiffeq.odeint_adjoint's")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,7 +74,8 @@ def main():
     from structured_latent_odes_amd.utils.utils import set_seed
 
     cfg = load_config_cvs()
-    cfg.update(seq_len=T, z_iext_dim=Z_SPLIT[0], z_rtpr_dim=Z_SPLIT[1], z_epsilon_dim=Z_SPLIT[2], solver="rk4", mini_batch_size=B_PER_GPU)
+    cfg.update(seq_len=T, z_iext_dim=Z_SPLIT[0], z_rtpr_dim=Z_SPLIT[1], z_epsilon_dim=Z_SPLIT[2], solver="rk4", mini_batch_size=B_PER_GPU,
+               adjoint_solver=(args.grad_mode == "reference_adjoint"))
     set_seed(cfg.seed)                                              # identical weights on every rank (config_cvs.py:28)
     times = torch.arange(0.0, T * cfg.delta_t, cfg.delta_t, device=dev)
     model = MechanisticModel(cfg, dev, times)                       # reference initialisers, random init
@@ -178,7 +181,7 @@ def main():
         "config": {"workload": "BASELINE config[1]: synthetic CVS, B=1024/GPU, T=200, C=3, latent_dim=8 (3,3,2), S=5, "
                                "rk4(3/8) fixed grid dt=1, ALD 3-quantile likelihood; step = ELBO fwd+bwd (all 96,462 parameters) "
                                "+ grad all-reduce (N>1) + Adam",
-                   "global_batch": world * B_PER_GPU, "T": T, "parallelism": "dp%d" % world},
+                   "global_batch": world * B_PER_GPU, "T": T, "parallelism": "dp%d" % world, "grad_mode": args.grad_mode},
         "final_loss_per_traj": final_loss / (world * B_PER_GPU),
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32, "traffic": traffic,

@@ -1151,13 +1151,9 @@ ode_elbo_kernel(const OdeK k) {
 
 template <int S, int H, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1>
 hipError_t launch_sh(const OdeK& k, int grid, int nthreads, size_t lds, bool bwd, hipStream_t stream, bool ra = false) {
-  if (bwd && ra) {
-    if constexpr (T_ == 0) {   // reference_adjoint backward: generic instantiation only
-      (void)hipFuncSetAttribute((const void*)ode_elbo_kernel<S, H, true, 0, 0, 0, 0, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((ode_elbo_kernel<S, H, true, 0, 0, 0, 0, -1, true>), dim3(grid), dim3(nthreads), lds, stream, k);
-    } else {
-      return hipErrorInvalidValue;
-    }
+  if (bwd && ra) {   // reference_adjoint backward
+    (void)hipFuncSetAttribute((const void*)ode_elbo_kernel<S, H, true, T_, C_, L_, Q_, M_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ode_elbo_kernel<S, H, true, T_, C_, L_, Q_, M_, true>), dim3(grid), dim3(nthreads), lds, stream, k);
   } else if (bwd) {
     (void)hipFuncSetAttribute((const void*)ode_elbo_kernel<S, H, true, T_, C_, L_, Q_, M_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((ode_elbo_kernel<S, H, true, T_, C_, L_, Q_, M_>), dim3(grid), dim3(nthreads), lds, stream, k);
@@ -1253,10 +1249,10 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   }
   // shape-specialised instantiations (compile-time LDS offsets, loop bounds, solver): the BASELINE.json shapes and the reference default
   const bool ra = bwd && s.grad_mode == SLODE_GRAD_REFERENCE_ADJOINT;
-  if (s.H == 25 && !ra && !getenv("SLODE_ODE_GENERIC")) {
+  if (s.H == 25 && !getenv("SLODE_ODE_GENERIC")) {
 #define SLODE_STATIC(SS, TT, CC, LL, QQ, MM)                                                              \
     if (s.S == SS && s.T == TT && s.C == CC && s.L == LL && k.Q == QQ && s.method == MM)                  \
-      return launch_sh<SS, 25, TT, CC, LL, QQ, MM>(k, a.grid, nthreads, lds, bwd, stream)
+      return launch_sh<SS, 25, TT, CC, LL, QQ, MM>(k, a.grid, nthreads, lds, bwd, stream, ra)
     SLODE_STATIC(5, 200, 3, 8, 3, SLODE_RK4);        // configs [1] / [3]: cvs, latent 3+3+2, ALD
     SLODE_STATIC(5, 100, 3, 4, 3, SLODE_RK4);        // config [0]: cvs, latent 1+1+2
     SLODE_STATIC(8, 100, 4, 50, 3, SLODE_RK4);       // config [2] shapes: proc (fixed-grid stand-in for dopri5)

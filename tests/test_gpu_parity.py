@@ -423,6 +423,8 @@ def test_abi_error_paths():
 # ---- grad_mode = "reference_adjoint": torchdiffeq.odeint_adjoint's gradients, the reference default ------------
 RA_CASES = {
     "cvs_rk4": ("cvs", dict(z_iext=3, z_rtpr=3, z_eps=2, solver="rk4"), 9, 120),
+    "cvs_c1_rk4_metric_shape": ("cvs", dict(z_iext=3, z_rtpr=3, z_eps=2, solver="rk4"), 6, 200),   # shape-specialised instantiation
+    "cvs_c0_rk4": ("cvs", dict(z_iext=1, z_rtpr=1, z_eps=2, solver="rk4"), 5, 100),                # shape-specialised instantiation
     "cvs_ref_default_midpoint": ("cvs", dict(), 7, 86),            # training_cvs.py defaults: midpoint, adjoint_solver=True
     "cvs_euler_gauss": ("cvs", dict(gauss=True, solver="euler"), 5, 64),
     "challenge_gauss_rk4": ("challenge", dict(gauss=True, solver="rk4"), 6, 150),
