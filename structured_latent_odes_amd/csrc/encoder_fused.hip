@@ -53,20 +53,43 @@ struct FoldK {
 __device__ __forceinline__ int kappa_of(const FoldK& k, int c, int t) { return k.t_major ? t * k.C + c : c * k.T + t; }
 
 // ---- fold: W_eff, rowsum, b_eff, w' ---------------------------------------------------------------------------------
+constexpr int WPB = 128;   // W_eff outputs per 256-thread block of weff_kernel
 template <int JM>  // compile-time bound on J = K + P - 1 (14 for every reference config)
-__global__ void __launch_bounds__(256) weff_kernel(const FoldK k) {
+__global__ void __launch_bounds__(256) weff_kernel(const FoldK k, const int stage_rows) {
   __shared__ float s_wp[SLODE_MAX_F * SLODE_MAX_C * JM];
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [F*C*K conv taps][stage_rows ? 2 lin.weight rows : 0]
   const int tid = threadIdx.x, J = k.J, C = k.C, K = k.K;
   const float fP = (float)k.P;
   if (blockIdx.x == 0 && tid == 0 && k.counter) *k.counter = 0u;   // arrival counter of this step's chain blocks
   STAMP(0);
+  const int n_w = k.Hc * k.CT;
+  const int nb_w = (n_w + WPB - 1) / WPB;
+  float* s_cw = smem;
+  float* s_lw = smem + ((k.F * C * K + 3) & ~3);
+  // Everything this block reads from global memory is fetched in ONE batch: the conv taps, and (W_eff blocks) the lin.weight rows
+  // of the <= 2 hidden units its 256 outputs belong to -- coalesced, instead of F*JM = 140 strided loads per thread.
+  const int e_first = (int)blockIdx.x * WPB, m0 = min(e_first, n_w - 1) / k.CT, m1 = min(e_first + WPB - 1, n_w - 1) / k.CT;
+  for (int i = tid; i < k.F * C * K; i += 256) s_cw[i] = k.conv_w[i];
+  if (stage_rows && (int)blockIdx.x < nb_w) {
+    const int n_st = (m1 - m0 + 1) * k.FQ;
+    const float* src = k.lin_w + (long long)m0 * k.FQ;
+    for (int i0 = tid; i0 < n_st; i0 += 16 * 256) {
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = src[min(i0 + q * 256, n_st - 1)];
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (i0 + q * 256 < n_st) s_lw[i0 + q * 256] = v[q];
+    }
+  }
+  __syncthreads();
   // w'[f][c][j] = (1/P) * sum_{k + p = j} w[f][c][k]   (rows padded to JM, zero beyond J)
   for (int e = tid; e < k.F * C * JM; e += 256) {
     const int j = e % JM, fc = e / JM;
     float s = 0.f;
     for (int p = 0; p < k.P; ++p) {
       const int kk = j - p;
-      if (j < J && kk >= 0 && kk < K) s += k.conv_w[fc * K + kk];
+      if (j < J && kk >= 0 && kk < K) s += s_cw[fc * K + kk];
     }
     s = s / fP;
     s_wp[e] = s;
@@ -74,17 +97,17 @@ __global__ void __launch_bounds__(256) weff_kernel(const FoldK k) {
   }
   __syncthreads();
   STAMP(1);
-  const int n_w = k.Hc * k.CT;
-  const int nb_w = (n_w + 255) / 256;
   if ((int)blockIdx.x < nb_w) {
-    const int e = min((int)blockIdx.x * 256 + tid, n_w - 1);
+    // WPB = 128 outputs per block, two threads per output (each half of the filters): ~250 blocks fill the 256 CUs
+    const int el = tid & (WPB - 1), fh = tid / WPB, fper = (k.F + 1) / 2;
+    const int e = min((int)blockIdx.x * WPB + el, n_w - 1);
     const int m = e / k.CT, kap = e - m * k.CT;
     int c, t;
     if (k.t_major) { t = kap / C; c = kap - t * C; } else { c = kap / k.T; t = kap - c * k.T; }
     float acc0 = 0.f, acc1 = 0.f;
-    const float* wlm = k.lin_w + (long long)m * k.FQ;
+    const float* wlm = stage_rows ? s_lw + (m - m0) * k.FQ : k.lin_w + (long long)m * k.FQ;
 #pragma unroll 2
-    for (int f = 0; f < k.F; ++f) {
+    for (int f = fh * fper; f < min(k.F, (fh + 1) * fper); ++f) {
       const float* wl = wlm + f * k.n_pool;
       const float* wp = s_wp + (f * C + c) * JM;
       float v[JM];
@@ -96,7 +119,10 @@ __global__ void __launch_bounds__(256) weff_kernel(const FoldK k) {
         if (j + 1 < JM) acc1 = fmaf((t - j - 1 >= 0 && t - j - 1 < k.n_pool) ? v[j + 1] : 0.f, wp[j + 1], acc1);
       }
     }
-    if ((int)blockIdx.x * 256 + tid < n_w) k.weff[e] = acc0 + acc1;
+    __shared__ float s_half[WPB];
+    if (fh == 1) s_half[el] = acc0 + acc1;
+    __syncthreads();
+    if (fh == 0 && (int)blockIdx.x * WPB + el < n_w) k.weff[e] = (acc0 + acc1) + s_half[el];
     STAMP(2);
   } else {
     // one wave per hidden unit m: rowsum[m][f] for every f, then b_eff[m]
@@ -513,9 +539,18 @@ int slode_fold_small_count(const slode_shape& s) { return s.Hc + 2 * (s.L * s.Hc
 
 hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream, hipEvent_t mid) {
   FoldK k = make_foldk(a);
-  const int nb_w = (k.Hc * k.CT + 255) / 256, nb_r = (k.Hc + 3) / 4;
-  if (k.J <= 14) hipLaunchKernelGGL((weff_kernel<14>), dim3(nb_w + nb_r), dim3(256), 0, stream, k);
-  else hipLaunchKernelGGL((weff_kernel<SLODE_MAX_K + SLODE_MAX_P>), dim3(nb_w + nb_r), dim3(256), 0, stream, k);
+  const int nb_w = (k.Hc * k.CT + WPB - 1) / WPB, nb_r = (k.Hc + 3) / 4;
+  // dynamic LDS: conv taps + (when they fit) the two lin.weight rows a block can touch
+  const size_t cw = ((size_t)k.F * k.C * k.K + 3) & ~(size_t)3;
+  const int stage_rows = (cw + 2 * (size_t)k.FQ) * sizeof(float) <= 96 * 1024 ? 1 : 0;
+  const size_t wlds = sizeof(float) * (cw + (stage_rows ? 2 * (size_t)k.FQ : 0));
+  if (k.J <= 14) {
+    if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)weff_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
+    hipLaunchKernelGGL((weff_kernel<14>), dim3(nb_w + nb_r), dim3(256), wlds, stream, k, stage_rows);
+  } else {
+    if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)weff_kernel<SLODE_MAX_K + SLODE_MAX_P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
+    hipLaunchKernelGGL((weff_kernel<SLODE_MAX_K + SLODE_MAX_P>), dim3(nb_w + nb_r), dim3(256), wlds, stream, k, stage_rows);
+  }
   if (mid) (void)hipEventRecord(mid, stream);
   const size_t lds = sizeof(float) * ((size_t)TBE * k.CT + TBE * 64 + 2 * (size_t)k.L * k.Hc + 64);
   (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
