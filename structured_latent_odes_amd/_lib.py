@@ -60,6 +60,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise SlodeError("libslode.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
                          "there is no CPU/PyTorch fallback for the hot path" % LIB_PATH)
+    # One HIP runtime per process: torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Import torch BEFORE dlopen so
+    # libslode binds to the runtime torch already loaded; loaded the other way round, two runtimes coexist and slode_create reports
+    # "no ROCm-capable device" (seen with `python __graft_entry__.py smoke`, where build() loaded the library first).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     P, VP, I64P = C.POINTER, C.c_void_p, C.POINTER(C.c_int64)
     lib.slode_version.restype = C.c_int

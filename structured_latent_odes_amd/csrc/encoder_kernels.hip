@@ -588,10 +588,10 @@ hipError_t slode_launch_enc_fwd(const EncLaunch& a, hipStream_t stream) {
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int grid = (a.s.B + TBE - 1) / TBE;
   if (a.s.C == 3 && a.s.K == 10) {
-    hipFuncSetAttribute((const void*)enc_fwd_kernel<3, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)enc_fwd_kernel<3, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((enc_fwd_kernel<3, 10>), dim3(grid), dim3(ENC_NT), lds, stream, k);
   } else if (a.s.C == 4 && a.s.K == 10) {
-    hipFuncSetAttribute((const void*)enc_fwd_kernel<4, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)enc_fwd_kernel<4, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((enc_fwd_kernel<4, 10>), dim3(grid), dim3(ENC_NT), lds, stream, k);
   } else {
     return hipErrorInvalidValue;
@@ -607,10 +607,10 @@ hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream, hipEv
   const size_t lds = enc_bwd_lds(k);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (a.s.C == 3 && a.s.K == 10) {
-    hipFuncSetAttribute((const void*)enc_bwd_kernel<3, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)enc_bwd_kernel<3, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((enc_bwd_kernel<3, 10>), dim3(a.grid_small), dim3(ENC_NT_BWD), lds, stream, k);
   } else if (a.s.C == 4 && a.s.K == 10) {
-    hipFuncSetAttribute((const void*)enc_bwd_kernel<4, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)enc_bwd_kernel<4, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((enc_bwd_kernel<4, 10>), dim3(a.grid_small), dim3(ENC_NT_BWD), lds, stream, k);
   } else {
     return hipErrorInvalidValue;
