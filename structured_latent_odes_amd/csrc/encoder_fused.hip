@@ -57,7 +57,7 @@ constexpr int WPB = 128;   // W_eff outputs per 256-thread block of weff_kernel
 template <int JM>  // compile-time bound on J = K + P - 1 (14 for every reference config)
 __global__ void __launch_bounds__(256) weff_kernel(const FoldK k, const int stage_rows) {
   __shared__ float s_wp[SLODE_MAX_F * SLODE_MAX_C * JM];
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [F*C*K conv taps][stage_rows ? 2 lin.weight rows : 0]
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [F*C*K conv taps][stage_rows ? the block's lin.weight rows : 0]
   const int tid = threadIdx.x, J = k.J, C = k.C, K = k.K;
   const float fP = (float)k.P;
   if (blockIdx.x == 0 && tid == 0 && k.counter) *k.counter = 0u;   // arrival counter of this step's chain blocks
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) weff_kernel(const FoldK k, const int stag
   float* s_cw = smem;
   float* s_lw = smem + ((k.F * C * K + 3) & ~3);
   // Everything this block reads from global memory is fetched in ONE batch: the conv taps, and (W_eff blocks) the lin.weight rows
-  // of the <= 2 hidden units its 256 outputs belong to -- coalesced, instead of F*JM = 140 strided loads per thread.
+  // of the hidden units its WPB outputs belong to (2 for C*T >= WPB) -- coalesced, instead of F*JM = 140 strided loads per thread.
   const int e_first = (int)blockIdx.x * WPB, m0 = min(e_first, n_w - 1) / k.CT, m1 = min(e_first + WPB - 1, n_w - 1) / k.CT;
   for (int i = tid; i < k.F * C * K; i += 256) s_cw[i] = k.conv_w[i];
   if (stage_rows && (int)blockIdx.x < nb_w) {
@@ -540,10 +540,11 @@ int slode_fold_small_count(const slode_shape& s) { return s.Hc + 2 * (s.L * s.Hc
 hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream, hipEvent_t mid) {
   FoldK k = make_foldk(a);
   const int nb_w = (k.Hc * k.CT + WPB - 1) / WPB, nb_r = (k.Hc + 3) / 4;
-  // dynamic LDS: conv taps + (when they fit) the two lin.weight rows a block can touch
+  // dynamic LDS: conv taps + (when they fit) the lin.weight rows a block's WPB consecutive outputs can touch
   const size_t cw = ((size_t)k.F * k.C * k.K + 3) & ~(size_t)3;
-  const int stage_rows = (cw + 2 * (size_t)k.FQ) * sizeof(float) <= 96 * 1024 ? 1 : 0;
-  const size_t wlds = sizeof(float) * (cw + (stage_rows ? 2 * (size_t)k.FQ : 0));
+  const size_t max_rows = (size_t)(WPB - 1) / k.CT + 2;   // WPB outputs starting anywhere inside a row of CT
+  const int stage_rows = (cw + max_rows * (size_t)k.FQ) * sizeof(float) <= 96 * 1024 ? 1 : 0;
+  const size_t wlds = sizeof(float) * (cw + (stage_rows ? max_rows * (size_t)k.FQ : 0));
   if (k.J <= 14) {
     if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)weff_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
     hipLaunchKernelGGL((weff_kernel<14>), dim3(nb_w + nb_r), dim3(256), wlds, stream, k, stage_rows);
