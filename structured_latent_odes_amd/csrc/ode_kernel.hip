@@ -349,7 +349,9 @@ __host__ __device__ constexpr int ode_threads_for(int T, int Q, int C, int S) {
 // shape-specialised instantiations (launcher: the BASELINE metric shape) get compile-time LDS offsets, loop bounds and solver.
 // T_ <= 128 (2-wave workgroups: 6 instead of 7 resident per CU) takes the 168-VGPR budget as well (fewer spills); the S = 8, T_ <= 128 shape
 // (proc: 69 KB of LDS, 2 x 3 waves per CU) can use 256.
-template <int S, int H, bool BWD, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1, bool RA = false>
+// ONE: the grid has one workgroup per trajectory (B <= CUs x occupancy, e.g. the metric config): no persistent loop, so nothing is
+// hoisted out of it and the accumulators only live from P6 to the epilogue.
+template <int S, int H, bool BWD, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1, bool RA = false, bool ONE = false>
 __global__ void __launch_bounds__((S > 5 && T_ > 0 && T_ <= 128) ? 512 : ((S > 5 || (T_ > 0 && T_ <= 128)) ? 768 : 1024))
 ode_elbo_kernel(const OdeK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1070,7 +1072,7 @@ ode_elbo_kernel(const OdeK k) {
       }
       k.g_pre[(long long)b * 64 + mm] = (g0 + g1) * (1.f - hv * hv);
     }
-    if (b + (int)gridDim.x < k.B && tid >= 64 && tid < 128) {   // next trajectory's latent inputs (wave 1; wave 0 may still read s_pf? no: P0a is long past)
+    if (!ONE && b + (int)gridDim.x < k.B && tid >= 64 && tid < 128) {   // next trajectory's latent inputs (wave 1; wave 0 may still read s_pf? no: P0a is long past)
       const int bn = b + gridDim.x, t1 = tid - 64;
       if (t1 < L) {
         if (k.loc != nullptr) {
@@ -1083,6 +1085,7 @@ ode_elbo_kernel(const OdeK k) {
       if (k.u != nullptr && t1 < k.nu) s_uu[t1] = k.u[(long long)bn * k.nu + t1];
     }
     STAMP(10);
+    if (ONE) break;
   }  // trajectories
 
   // ---- workgroup epilogue: fold register accumulators into the LDS segment, write the slab ---------------
@@ -1151,6 +1154,18 @@ ode_elbo_kernel(const OdeK k) {
 
 template <int S, int H, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1>
 hipError_t launch_sh(const OdeK& k, int grid, int nthreads, size_t lds, bool bwd, hipStream_t stream, bool ra = false) {
+  if constexpr (T_ == 200) {   // metric shape: loop-free instantiation when every trajectory has its own workgroup
+    if (bwd && grid == k.B && !getenv("SLODE_ODE_LOOP")) {
+      if (ra) {
+        (void)hipFuncSetAttribute((const void*)ode_elbo_kernel<S, H, true, T_, C_, L_, Q_, M_, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ode_elbo_kernel<S, H, true, T_, C_, L_, Q_, M_, true, true>), dim3(grid), dim3(nthreads), lds, stream, k);
+      } else {
+        (void)hipFuncSetAttribute((const void*)ode_elbo_kernel<S, H, true, T_, C_, L_, Q_, M_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ode_elbo_kernel<S, H, true, T_, C_, L_, Q_, M_, false, true>), dim3(grid), dim3(nthreads), lds, stream, k);
+      }
+      return hipGetLastError();
+    }
+  }
   if (bwd && ra) {   // reference_adjoint backward
     (void)hipFuncSetAttribute((const void*)ode_elbo_kernel<S, H, true, T_, C_, L_, Q_, M_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((ode_elbo_kernel<S, H, true, T_, C_, L_, Q_, M_, true>), dim3(grid), dim3(nthreads), lds, stream, k);
