@@ -1154,7 +1154,7 @@ ode_elbo_kernel(const OdeK k) {
 
 template <int S, int H, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1>
 hipError_t launch_sh(const OdeK& k, int grid, int nthreads, size_t lds, bool bwd, hipStream_t stream, bool ra = false) {
-  if constexpr (T_ == 200) {   // metric shape: loop-free instantiation when every trajectory has its own workgroup
+  {   // loop-free instantiation when every trajectory has its own workgroup (B <= CUs x occupancy)
     if (bwd && grid == k.B && !getenv("SLODE_ODE_LOOP")) {
       if (ra) {
         (void)hipFuncSetAttribute((const void*)ode_elbo_kernel<S, H, true, T_, C_, L_, Q_, M_, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -183,6 +183,10 @@ static int ode_grid_for(slode_handle h, const slode_shape& s) {
   if (occ < 1) occ = 1;
   const int cus = h ? h->num_cu : 256;
   long long g = (long long)cus * occ;
+  // One workgroup per trajectory up to 65,536 trajectories: the loop-free instantiation (no register spills) with the hardware
+  // queueing the workgroups beats the persistent loop by ~10 % (tools/batch_sweep.py) at the price of one 9 KB slab per trajectory;
+  // beyond that (and under SLODE_ODE_LOOP, which the persistent-loop test sets) a resident grid loops over the trajectories.
+  if (s.B <= 65536 && !getenv("SLODE_ODE_LOOP")) g = s.B;
   if (g > s.B) g = s.B;
   return (int)g;
 }

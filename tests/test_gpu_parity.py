@@ -326,11 +326,15 @@ def test_elbo_other_observation_layouts(layout):
     assert not bad, bad
 
 
-def test_more_trajectories_than_workgroups():
-    """B > grid (= CUs x occupancy): every workgroup integrates several trajectories in its persistent loop, carrying the register
-    accumulators and the input prefetch across them.  Loss/gradient must equal the sum over chunks that each fit one pass, and a
-    slice must match the oracle."""
+@pytest.mark.parametrize("policy", ["one_workgroup_per_trajectory", "persistent_loop"])
+def test_more_trajectories_than_workgroups(policy, monkeypatch):
+    """B > CUs x occupancy.  Default policy (B <= 65,536): one workgroup per trajectory, loop-free kernel, the hardware queues the
+    workgroups.  Persistent-loop policy (B > 65,536; forced here with SLODE_ODE_LOOP): a resident grid where every workgroup
+    integrates several trajectories, carrying the register accumulators and the input prefetch across them.  Either way loss/gradient
+    must equal the sum over chunks that each fit one pass, and a slice must match the oracle."""
     from structured_latent_odes_amd import engine as E
+    if policy == "persistent_loop":
+        monkeypatch.setenv("SLODE_ODE_LOOP", "1")
     dev = torch.device("cuda:0")
     ospec = O.cvs_spec(3, 3, 2, solver="rk4")
     B, T = 2500, 86                      # 2500 trajectories over <= 1024..2048 workgroups, ragged
