@@ -167,7 +167,7 @@ def main():
     step_flops = sum(KERNEL_FLOPS.values()) * B_PER_GPU
 
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
