@@ -463,7 +463,9 @@ ode_elbo_kernel(const OdeK k) {
         const int i = i0 + q * NT;
         if (i < n_ts) s_ts[i] = v_ts[q];
         if (i < n_par) s_par[i] = v_par[q];
-        if (i < n_sig) s_sig[i] = softplusf(v_sig[q]);
+        if (r * DEPTH * NT + q * NT < n_sig) {   // wave-uniform: slots past the table skip the (long) softplus altogether
+          if (i < n_sig) s_sig[i] = softplusf(v_sig[q]);
+        }
         if (i < n_dt) s_dt[i] = v_t1[q] - v_t0[q];
       }
     }
