@@ -50,6 +50,24 @@ def run_case(rng, case: int, dev):
         if not (e <= worst):
             worst, wk = e, k
     ok = lrel < 1e-5 and worst < 5e-4 and bool(torch.isfinite(grads).all())
-    desc = "%-3d %-9s T=%-3d B=%-2d L=%-2d %-8s %-5s %-17s loss rel %.1e  worst grad %.1e (%s)" % (
-        case, fam, T, B, espec.latent_dim, solver, "gauss" if gauss else "ald", mode, lrel, worst, wk)
+    # the auxiliary step (second SVI object) on the same model and batch
+    aloss = torch.zeros(1, device=dev)
+    agrads = torch.full((eng.n_params,), float("nan"), device=dev)
+    eng.aux_step(flat, obs_d, u.to(dev), eps.to(dev), aloss, agrads)
+    q = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    awant = O.aux_loss(q, ospec, obs.double(), u.double(), eps.double())
+    awant.backward()
+    alrel = abs(aloss.item() - awant.item()) / abs(awant.item())
+    aworst = 0.0
+    for k, v in eng.unpack(agrads).items():
+        w = q[k].grad if q[k].grad is not None else torch.zeros_like(q[k])
+        if float(w.abs().max()) == 0.0:
+            e = float(v.abs().max())
+        else:
+            e = ((v.double().cpu() - w).norm() / w.norm()).item()
+        if not (e <= aworst):
+            aworst = e
+    ok = ok and alrel < 1e-5 and aworst < 5e-4 and bool(torch.isfinite(agrads).all())
+    desc = "%-3d %-9s T=%-3d B=%-2d L=%-2d %-8s %-5s %-17s loss rel %.1e  worst grad %.1e (%s)  aux: loss rel %.1e worst grad %.1e" % (
+        case, fam, T, B, espec.latent_dim, solver, "gauss" if gauss else "ald", mode, lrel, worst, wk, alrel, aworst)
     return ok, desc
