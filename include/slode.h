@@ -212,6 +212,14 @@ int slode_aux_step(slode_handle h, const slode_shape* s, const slode_layout* lay
 int slode_adam_step(slode_handle h, int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                     float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
 
+/* Per-parameter step counts of pyro.optim.Adam (one torch.optim.Adam per parameter, state created at the first non-None gradient):
+ * the two SVI objects of the reference share one optimizer (training_cvs.py:226-249) and alternate main, aux, main, ...; every
+ * parameter is registered by both (pyro.module(..., self)), so all are stepped twice per minibatch -- except that the label heads of the
+ * cvs / challenge families have no gradient yet in the very first main step and are skipped there.  Elements [lo, hi) of the flat
+ * vector therefore use step + step_delta (skipped while that is < 1) in every Adam this handle applies (slode_adam_step,
+ * slode_elbo_adam_step, slode_aux_step).  Default: empty region. */
+int slode_adam_region(slode_handle h, int64_t lo, int64_t hi, int64_t step_delta);
+
 /* Measurement aid for bench.py's roofline block (no reference counterpart): when enabled, slode_elbo_step records HIP
  * events on `stream` around each of its kernels; slode_profile_read waits for the last one and returns the durations in
  * milliseconds of [fold (W_eff), encoder_fwd, ode_elbo (fused solve + ELBO fwd/bwd), encoder_bwd (heads),

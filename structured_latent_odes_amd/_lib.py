@@ -43,7 +43,7 @@ class Layout(C.Structure):
 EXPORTS = ["slode_version", "slode_create", "slode_destroy", "slode_last_error", "slode_layout_init",
            "slode_num_stage_times", "slode_workspace_bytes", "slode_stage_times", "slode_encoder_conv_fwd",
            "slode_encoder_conv_bwd", "slode_ode_solve_fwd", "slode_ode_solve_bwd", "slode_decode_heads",
-           "slode_elbo_step", "slode_adam_step", "slode_profile_enable", "slode_profile_read", "slode_dynamics_eval", "slode_elbo_adam_step", "slode_aux_step"]
+           "slode_elbo_step", "slode_adam_step", "slode_profile_enable", "slode_profile_read", "slode_dynamics_eval", "slode_elbo_adam_step", "slode_aux_step", "slode_adam_region"]
 
 _lib = None
 
@@ -67,6 +67,7 @@ def load():
     lib = C.CDLL(LIB_PATH)
     P, VP, I64P = C.POINTER, C.c_void_p, C.POINTER(C.c_int64)
     lib.slode_version.restype = C.c_int
+    lib.slode_adam_region.argtypes = [VP, C.c_int64, C.c_int64, C.c_int64]
     lib.slode_create.argtypes = [P(VP), C.c_int]
     lib.slode_destroy.argtypes = [VP]
     lib.slode_last_error.argtypes = [VP]

@@ -27,8 +27,7 @@ struct ReduceK {
   float* grads; float* loss_out;
   int n_params, zero_rest;
   // optional fused Adam (single-process training): applied to element i right after its gradient is final
-  float *adam_p, *adam_m, *adam_v;
-  float step_size, one_minus_b1, b2, one_minus_b2, sqrt_bc2, eps;
+  AdamK ad;     // ad.p == nullptr: no fused Adam
   int n_total;  // >= n_params: parameters appended by the caller (zero main-loss gradient) are stepped too
 };
 
@@ -48,7 +47,7 @@ __global__ void reduce_kernel(const ReduceK k) {
     k.loss_out[0] = (float)acc;
   }
   if (k.grads == nullptr) return;
-  const int n_all = k.adam_p ? k.n_total : k.n_params;
+  const int n_all = k.ad.p ? k.n_total : k.n_params;
   if (i >= n_all) return;
   float g = 0.f;
   bool write = false;
@@ -75,15 +74,7 @@ __global__ void reduce_kernel(const ReduceK k) {
     }
     if (write) k.grads[i] = g;
   }
-  if (k.adam_p) {  // torch.optim.Adam single-tensor formulas (see adam_kernel)
-    float mi = k.adam_m[i], vi = k.adam_v[i];
-    mi = mi + k.one_minus_b1 * (g - mi);
-    vi = vi * k.b2 + k.one_minus_b2 * g * g;
-    const float denom = sqrtf(vi) / k.sqrt_bc2 + k.eps;
-    k.adam_p[i] = k.adam_p[i] - k.step_size * (mi / denom);
-    k.adam_m[i] = mi;
-    k.adam_v[i] = vi;
-  }
+  if (k.ad.p) adam_apply(k.ad, i, g);
 }
 
 // Decoder heads on a given trajectory tensor: models/decoders.py:45-47 (ALD: q50, q75, q25) / :86 (Gauss: mean),
@@ -132,19 +123,10 @@ __global__ void dynamics_eval_kernel(const float* __restrict__ params, int wh, i
 // torch.optim.Adam single-tensor update (amsgrad=False, weight_decay=0, maximize=False) as applied per parameter by
 // pyro.optim.Adam (training_cvs.py:226-227): exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v + (1-b2) g*g;
 // denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m/denom.
-__global__ void adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, float step_size, float one_minus_b1, float b2, float one_minus_b2,
-                            float sqrt_bc2, float eps) {
+__global__ void adam_kernel(long long n, const float* __restrict__ g, const AdamK a) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float gi = g[i];
-  float mi = m[i], vi = v[i];
-  mi = mi + one_minus_b1 * (gi - mi);
-  vi = vi * b2 + one_minus_b2 * gi * gi;
-  const float denom = sqrtf(vi) / sqrt_bc2 + eps;
-  p[i] = p[i] - step_size * (mi / denom);
-  m[i] = mi;
-  v[i] = vi;
+  adam_apply(a, (int)i, g[i]);
 }
 
 }  // namespace
@@ -187,10 +169,9 @@ hipError_t slode_launch_reduce(const ReduceLaunch& a_in, hipStream_t stream) {
   k.grads = a.grads; k.loss_out = a.loss_out; k.n_params = a.lay.n_params; k.zero_rest = a.zero_rest;
   int n = a.grads ? a.lay.n_params : 1;
   if (a.adam_p && a.grads) {
-    const double bc1 = 1.0 - pow((double)a.adam_b1, (double)a.adam_step), bc2 = 1.0 - pow((double)a.adam_b2, (double)a.adam_step);
-    k.adam_p = a.adam_p; k.adam_m = a.adam_m; k.adam_v = a.adam_v;
-    k.step_size = (float)((double)a.adam_lr / bc1); k.one_minus_b1 = 1.0f - a.adam_b1; k.b2 = a.adam_b2;
-    k.one_minus_b2 = 1.0f - a.adam_b2; k.sqrt_bc2 = (float)sqrt(bc2); k.eps = a.adam_eps;
+    AdamHost ah{a.adam_p, a.adam_m, a.adam_v, a.adam_lr, a.adam_b1, a.adam_b2, a.adam_eps, a.adam_step, a.adam_n};
+    ah.lo2 = a.adam_lo2; ah.hi2 = a.adam_hi2; ah.delta2 = a.adam_delta2;
+    k.ad = make_adamk(&ah);
     k.n_total = a.adam_n > a.lay.n_params ? (int)a.adam_n : a.lay.n_params;
     n = k.n_total;
   }
@@ -215,13 +196,13 @@ hipError_t slode_launch_dynamics_eval(const slode_shape& s, const slode_layout& 
   return hipGetLastError();
 }
 
+hipError_t slode_launch_adam_k(int64_t n, const float* g, const AdamHost& a, hipStream_t stream) {
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (long long)n, g, make_adamk(&a));
+  return hipGetLastError();
+}
+
 hipError_t slode_launch_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2, float eps,
                              int64_t step, hipStream_t stream) {
-  const double bc1 = 1.0 - pow((double)b1, (double)step);
-  const double bc2 = 1.0 - pow((double)b2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
-  const float sqrt_bc2 = (float)sqrt(bc2);
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (long long)n, p, g, m, v, step_size,
-                     1.0f - b1, b2, 1.0f - b2, sqrt_bc2, eps);
-  return hipGetLastError();
+  const AdamHost a{p, m, v, lr, b1, b2, eps, step, n};
+  return slode_launch_adam_k(n, g, a, stream);
 }

@@ -87,6 +87,7 @@ int slode_create(slode_handle* out, int device_id) {
   c->num_cu = prop.multiProcessorCount;
   c->err[0] = 0;
   c->profile = 0; c->ev_ready = 0; c->ev_valid = 0; c->repeat_ode = 0;
+  c->adam_lo2 = c->adam_hi2 = 0; c->adam_delta2 = 0;
   c->no_fold = getenv("SLODE_NO_FOLD") != nullptr;   // diagnostics: force the layer-by-layer encoder kernels
   *out = c;
   return SLODE_OK;
@@ -425,7 +426,10 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     // Fused tail.  The ODE kernel has already run the encoder heads + tanh backward (g_pre, glat): three launches remain --
     // split-K MFMA GEMMs (+ rider blocks: stage 1 of the ODE-slab reduction), chain rule, one final reduction (+ Adam).
     AdamHost ah{};
-    if (adam) ah = AdamHost{adam->p, adam->m, adam->v, adam->lr, adam->b1, adam->b2, adam->eps, adam->step, adam->n};
+    if (adam) {
+      ah = AdamHost{adam->p, adam->m, adam->v, adam->lr, adam->b1, adam->b2, adam->eps, adam->step, adam->n};
+      ah.lo2 = h->adam_lo2; ah.hi2 = h->adam_hi2; ah.delta2 = h->adam_delta2;
+    }
     const float* ode_part = nullptr;
     int ode_pn = 0;
     SLODE_MARK(4);
@@ -455,7 +459,8 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, n_slabs, w.small_slabs, w.small_stride, w.small_grid,
                    w.conv_slabs, s->Hc, grads, loss_out, 0, w.ode_part, w.small_part, 1};
     if (adam) { r.adam_p = adam->p; r.adam_m = adam->m; r.adam_v = adam->v; r.adam_lr = adam->lr; r.adam_b1 = adam->b1;
-                r.adam_b2 = adam->b2; r.adam_eps = adam->eps; r.adam_step = adam->step; r.adam_n = adam->n; }
+                r.adam_b2 = adam->b2; r.adam_eps = adam->eps; r.adam_step = adam->step; r.adam_n = adam->n;
+                r.adam_lo2 = h->adam_lo2; r.adam_hi2 = h->adam_hi2; r.adam_delta2 = h->adam_delta2; }
     HIP_TRY(h, slode_launch_reduce(r, st));
     SLODE_MARK(7);
     if (prof) h->ev_valid = 1;
@@ -468,7 +473,8 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, n_slabs, w.small_slabs, w.small_stride, w.small_grid,
                    w.lin_slabs, w.lin_splitk, grads, loss_out, 1, w.ode_part, w.small_part, 0};
     if (adam) { r.adam_p = adam->p; r.adam_m = adam->m; r.adam_v = adam->v; r.adam_lr = adam->lr; r.adam_b1 = adam->b1;
-                r.adam_b2 = adam->b2; r.adam_eps = adam->eps; r.adam_step = adam->step; r.adam_n = adam->n; }
+                r.adam_b2 = adam->b2; r.adam_eps = adam->eps; r.adam_step = adam->step; r.adam_n = adam->n;
+                r.adam_lo2 = h->adam_lo2; r.adam_hi2 = h->adam_hi2; r.adam_delta2 = h->adam_delta2; }
     HIP_TRY(h, slode_launch_reduce(r, st));
     SLODE_MARK(7);
     if (prof) h->ev_valid = 1;
@@ -519,6 +525,13 @@ int slode_dynamics_eval(slode_handle h, const slode_shape* s, const slode_layout
   return SLODE_OK;
 }
 
+int slode_adam_region(slode_handle h, int64_t lo, int64_t hi, int64_t step_delta) {
+  if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
+  if (lo < 0 || hi < lo || hi > 0x7fffffff) return fail(h, SLODE_EINVAL, "bad Adam region [%lld, %lld)", (long long)lo, (long long)hi);
+  h->adam_lo2 = (int)lo; h->adam_hi2 = (int)hi; h->adam_delta2 = step_delta;
+  return SLODE_OK;
+}
+
 int slode_profile_enable(slode_handle h, int on) {
   if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
   if (on && !h->ev_ready) {
@@ -553,7 +566,9 @@ int slode_adam_step(slode_handle h, int64_t n, float* params, const float* grads
   if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
   if (n < 0 || step < 1 || !params || !grads || !exp_avg || !exp_avg_sq) return fail(h, SLODE_EINVAL, "bad Adam arguments");
   if (n == 0) return SLODE_OK;
-  HIP_TRY(h, slode_launch_adam(n, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, (hipStream_t)stream));
+  AdamHost a{params, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, n};
+  a.lo2 = h->adam_lo2; a.hi2 = h->adam_hi2; a.delta2 = h->adam_delta2;
+  HIP_TRY(h, slode_launch_adam_k(n, grads, a, (hipStream_t)stream));
   return SLODE_OK;
 }
 

@@ -25,6 +25,8 @@ struct slode_ctx {
   int ev_ready;           // events created
   int ev_valid;           // a profiled step has been recorded
   int no_fold;            // env SLODE_NO_FOLD: use the layer-by-layer encoder kernels inside slode_elbo_step
+  int adam_lo2, adam_hi2; // slode_adam_region: elements with their own Adam step count = step + adam_delta2
+  int64_t adam_delta2;
   int repeat_ode;         // measurement aid: extra (idempotent) launches of the ode_elbo kernel per step (slode_profile_enable)
 };
 
@@ -84,18 +86,23 @@ __device__ __forceinline__ float strided_sum(const float* p, int stride, int n) 
 }
 
 // ---- fused tail of the folded-encoder ELBO step (runs inside the chain-rule launch, encoder_fused.hip) -------------------------
-struct AdamK { float *p, *m, *v; float step_size, one_minus_b1, b2, one_minus_b2, sqrt_bc2, eps; };
+// Elements of [lo2, hi2) carry their OWN step count (pyro.optim keeps one torch.optim.Adam per parameter: the label heads of the
+// cvs / challenge families see their first non-None gradient one SVI step later than everything else, training_cvs.py:236-249):
+// step_size2 / sqrt_bc2_2 are their bias corrections, skip2 != 0 leaves them untouched (their step count is still 0).
+struct AdamK { float *p, *m, *v; float step_size, one_minus_b1, b2, one_minus_b2, sqrt_bc2, eps; int lo2, hi2, skip2; float step_size2, sqrt_bc2_2; };
 // torch.optim.Adam single-tensor formulas (see adam_kernel, misc_kernels.hip)
 __device__ __forceinline__ void adam_apply(const AdamK& a, int i, float g) {
+  const bool r2 = i >= a.lo2 && i < a.hi2;
+  if (r2 && a.skip2) return;
   float mi = a.m[i], vi = a.v[i];
   mi = mi + a.one_minus_b1 * (g - mi);
   vi = vi * a.b2 + a.one_minus_b2 * g * g;
-  const float denom = sqrtf(vi) / a.sqrt_bc2 + a.eps;
-  a.p[i] = a.p[i] - a.step_size * (mi / denom);
+  const float denom = sqrtf(vi) / (r2 ? a.sqrt_bc2_2 : a.sqrt_bc2) + a.eps;
+  a.p[i] = a.p[i] - (r2 ? a.step_size2 : a.step_size) * (mi / denom);
   a.m[i] = mi;
   a.v[i] = vi;
 }
-struct AdamHost { float *p, *m, *v; float lr, b1, b2, eps; int64_t step, n; };
+struct AdamHost { float *p, *m, *v; float lr, b1, b2, eps; int64_t step, n; int lo2 = 0, hi2 = 0; int64_t delta2 = 0; };
 inline AdamK make_adamk(const AdamHost* a) {
   AdamK k{};
   if (a && a->p) {
@@ -103,6 +110,15 @@ inline AdamK make_adamk(const AdamHost* a) {
     k.p = a->p; k.m = a->m; k.v = a->v;
     k.step_size = (float)((double)a->lr / bc1); k.one_minus_b1 = 1.0f - a->b1; k.b2 = a->b2;
     k.one_minus_b2 = 1.0f - a->b2; k.sqrt_bc2 = (float)sqrt(bc2); k.eps = a->eps;
+    k.lo2 = a->lo2; k.hi2 = a->hi2; k.step_size2 = k.step_size; k.sqrt_bc2_2 = k.sqrt_bc2;
+    if (a->hi2 > a->lo2) {
+      const int64_t s2 = a->step + a->delta2;
+      k.skip2 = s2 < 1 ? 1 : 0;
+      if (s2 >= 1) {
+        k.step_size2 = (float)((double)a->lr / (1.0 - pow((double)a->b1, (double)s2)));
+        k.sqrt_bc2_2 = (float)sqrt(1.0 - pow((double)a->b2, (double)s2));
+      }
+    }
   }
   return k;
 }
@@ -317,6 +333,7 @@ struct ReduceLaunch {
   float *adam_p = nullptr, *adam_m = nullptr, *adam_v = nullptr;  // optional fused Adam (after the positional members)
   float adam_lr = 0.f, adam_b1 = 0.f, adam_b2 = 0.f, adam_eps = 0.f;
   int64_t adam_step = 0, adam_n = 0;
+  int adam_lo2 = 0, adam_hi2 = 0; int64_t adam_delta2 = 0;
 };
 hipError_t slode_launch_reduce(const ReduceLaunch& a, hipStream_t stream);
 
@@ -328,5 +345,6 @@ hipError_t slode_launch_dynamics_eval(const slode_shape& s, const slode_layout& 
                                       const float* state, const float* z, float* out, hipStream_t stream);
 hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const float* z,
                                float* x, hipStream_t stream);
+hipError_t slode_launch_adam_k(int64_t n, const float* g, const AdamHost& a, hipStream_t stream);
 hipError_t slode_launch_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2,
                              float eps, int64_t step, hipStream_t stream);

@@ -317,6 +317,17 @@ class Engine:
             float(lr), float(betas[0]), float(betas[1]), float(eps), int(step), self._stream()))
 
 
+    def adam_region(self, lo: int, hi: int, step_delta: int):
+        """Flat-vector elements [lo, hi) use Adam step count `step + step_delta` (skipped while < 1): include/slode.h, slode_adam_region."""
+        _check(self.lib, self.handle, self.lib.slode_adam_region(self.handle, int(lo), int(hi), int(step_delta)))
+
+    def aux_only_region(self):
+        """[lo, hi) of the label-head parameters when only the auxiliary loss uses them (cvs / challenge), else (0, 0)."""
+        lay, sp = self.layout, self.spec
+        if not sp.aux_heads or sp.labels_in_main:
+            return 0, 0
+        return int(lay.aux_w1[0]), int(lay.cstd)
+
     def profile_enable(self, on, only: Optional[str] = None):
         """on: record HIP events around every kernel of elbo_step; only=<slot name>: bracket just that kernel (least perturbation)."""
         mode = 0 if not on else (1 if only is None else 2 + PROFILE_SLOT_NAMES.index(only))

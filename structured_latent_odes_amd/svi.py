@@ -99,6 +99,12 @@ class Adam:
             a = self.optim_args
             self._flat = FlatAdam(binding.engine, binding.flat, lr=a.get("lr", 1e-3), betas=tuple(a.get("betas", (0.9, 0.999))),
                                   eps=a.get("eps", 1e-8))
+            # pyro.optim.Adam keeps one torch.optim.Adam per parameter.  Both SVI objects register every parameter, so each is
+            # stepped twice per minibatch (with a zero gradient by the loss that does not use it) -- except that the label heads of
+            # the cvs / challenge families have no gradient at all in the very first main step and are skipped there: their step
+            # count runs one behind (training_cvs.py:147-157, 236-249).
+            lo, hi = binding.engine.aux_only_region()
+            binding.engine.adam_region(lo, hi, -1)
         return self._flat
 
 

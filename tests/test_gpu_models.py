@@ -260,3 +260,52 @@ def test_training_on_reference_format_files(tmp_path):
     assert len(trb) == 2 and len(vab) == 1                       # 28 / 7 by the seeded 5-fold split
     vm, bm, be = training_challenge.train(cfg, train_batches=trb, val_batches=vab)
     assert all(torch.isfinite(p).all() for p in vm.parameters())
+
+
+def test_two_svi_objects_share_adam_with_per_parameter_step_counts():
+    """the reference alternates SVI(model, guide).step and SVI(model_meta, guide_meta).step on ONE pyro.optim.Adam
+    (training_cvs.py:147-157, 226-249).  pyro.optim keeps a torch.optim.Adam per parameter; both objects register every parameter
+    (pyro.module(..., self)), so each parameter is stepped in both, with a zero gradient by the loss that does not use it -- except
+    that a parameter whose .grad is still None is skipped: the label heads in the very first main step.  Emulated here on the CPU
+    with the oracle's gradients; the HIP path must end up with the same parameters after main, aux, main, aux."""
+    from structured_latent_odes_amd.svi import SVI, Adam, Trace_ELBO
+    m, cfg, batch, ospec, dev = _cvs(solver="rk4")
+    lr, b1, b2, aeps = 1e-3, 0.9, 0.999, 1e-8
+    opt = Adam({"lr": lr, "betas": (b1, b2)})
+    main = SVI(m.model, m.guide, opt, loss=Trace_ELBO(num_particles=1))
+    aux = SVI(m.model_meta, m.guide_meta, opt, loss=Trace_ELBO(num_particles=1))
+    p = {k: v.double() for k, v in _oracle_params(m).items() if ".prod." not in k and ".degr." not in k}
+    st = {k: dict(m=torch.zeros_like(v), v=torch.zeros_like(v), n=0, seen=False) for k, v in p.items()}
+    obs, u = batch["observations"].cpu().double(), torch.cat([batch["iext"], batch["rtpr"]], 1).cpu().double()
+    times = m.times.cpu().double()
+    g = torch.Generator().manual_seed(9)
+    for it in range(4):
+        eps = torch.randn(24, m.latent_dim, generator=g)
+        if it % 2 == 0:
+            main.step(eps=eps.to(dev), **batch)
+            _, grads = O.loss_and_grads(p, ospec, obs, u, eps.double(), times)
+            used = lambda k: not k.startswith("q_")
+        else:
+            aux.step(eps=eps.to(dev), **batch)
+            q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+            O.aux_loss(q, ospec, obs, u, eps.double()).backward()
+            grads = {k: (q[k].grad if q[k].grad is not None else torch.zeros_like(q[k])) for k in q}
+            used = lambda k: k.startswith("q_") or k.startswith("encoder.")
+        for k in p:                                   # one torch.optim.Adam per parameter
+            s = st[k]
+            if used(k):
+                s["seen"] = True
+            if not s["seen"]:
+                continue                              # .grad is None: torch.optim.Adam skips it
+            gk = grads[k] if used(k) else torch.zeros_like(p[k])
+            s["n"] += 1
+            s["m"] = s["m"] + (1 - b1) * (gk - s["m"])
+            s["v"] = b2 * s["v"] + (1 - b2) * gk * gk
+            denom = s["v"].sqrt() / (1 - b2 ** s["n"]) ** 0.5 + aeps
+            p[k] = p[k] - (lr / (1 - b1 ** s["n"])) * s["m"] / denom
+    assert st["q_iext.sequential_mlp.0.0.module.weight" if "q_iext.sequential_mlp.0.0.module.weight" in st else next(k for k in st if k.startswith("q_"))]["n"] == 3
+    assert st["encoder.conv.weight"]["n"] == 4
+    got = _oracle_params(m)
+    for k, v in p.items():
+        err = (got[k].double() - v).abs().max().item()
+        assert err < 3e-6, (k, err)
