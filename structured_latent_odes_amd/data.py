@@ -268,6 +268,60 @@ class ProcDataset(torch.utils.data.Dataset):
         return out
 
 
+PROC_DEVICES = ["Pcat_Y81C76", "RS100S32_Y81C76", "RS100S34_Y81C76", "R33S32_Y81C76", "R33S34_Y81C76", "R33S175_Y81C76"]
+PROC_GROUPS = OrderedDict([("aR", [0, 1, 1, 2, 2, 2]), ("aS", [0, 1, 2, 1, 2, 3])])   # LuxR / LasR RBS group of every device
+PROC_FILES = ["proc140916.csv", "proc140930.csv", "proc141006.csv", "proc141021.csv", "proc141023.csv", "proc141028.csv"]
+PROC_SIGNALS = ["OD", "mRFP1", "EYFP", "ECFP"]
+PROC_CONDITIONS = ["C6", "C12"]
+
+
+def proc_cassettes(device_ids: np.ndarray, groups=PROC_GROUPS) -> np.ndarray:
+    """Multi-hot device description (data/proc/config_proc.py:70-110, utils/proc_dataset.py:49-73): for every component group the
+    one-hot of the device's group index, stacked -- aR (3) then aS (4) for the shipped device list."""
+    rows = []
+    for d in np.asarray(device_ids).astype(int):
+        parts = []
+        for g in groups.values():
+            v = np.zeros(len(set(g)), dtype=np.float32)
+            v[g[d]] = 1.0
+            parts.append(v)
+        rows.append(np.hstack(parts))
+    return np.array(rows, dtype=np.float32)
+
+
+class ProcTrainingView(torch.utils.data.Dataset):
+    """A subset of a ProcDataset in the form ``training_proc.py:23-32`` consumes: ``aR = dev_1hot[:, :3]``, ``aS = dev_1hot[:, 3:]``,
+    ``C12 = inputs[:, 0]``, ``C6 = inputs[:, 1]`` (the reference's column assignment, kept as is), observations ``[C, T]``."""
+
+    def __init__(self, ds: ProcDataset, ids):
+        self.ds, self.ids = ds, np.asarray(ids)
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, i):
+        j = int(self.ids[i])
+        one = self.ds.dev_1hot[j].float()
+        inp = self.ds.inputs[j].float()
+        return {"observations": self.ds.observations[j].float(), "aR": one[:3], "aS": one[3:], "C12": inp[0:1], "C6": inp[1:2]}
+
+
+def build_proc_datasets(data_dir: str, seed: int, folds: int, split: int, heldout: Optional[str] = None, files=None):
+    """(train view, validation view, times): utils/proc_dataset.py:164-204 on the plate-reader CSVs found in ``data_dir``."""
+    files = [f for f in (files or PROC_FILES) if os.path.exists(os.path.join(data_dir, f))]
+    if not files:
+        raise FileNotFoundError("no plate-reader CSV (%s ...) in %s" % (PROC_FILES[0], data_dir))
+    dmap = {d: float(i) for i, d in enumerate(PROC_DEVICES)}
+    parsed = [load_proc_csv(os.path.join(data_dir, f), PROC_DEVICES, dmap, PROC_CONDITIONS, PROC_SIGNALS) for f in files]
+    ds = ProcDataset(parsed, normalize=None, subtract_background=True, dev_1hot_fn=proc_cassettes)
+    np.random.seed(seed)
+    if heldout:
+        tr, va = holdout_ids(ds.devices, int(dmap[heldout]))
+    else:
+        tr, va = kfold_ids(len(ds), folds, split, seed)
+    return ProcTrainingView(ds, tr), ProcTrainingView(ds, va), ds.times.float()
+
+
 # ---- host -> device feeding ------------------------------------------------------------------------------------------------------
 class BatchFeeder:
     """Iterates ``dataset`` in minibatches of ``batch_size``: samples are collated straight into one of two PINNED host buffers per

@@ -2,7 +2,7 @@
 ``train(config)`` with the reference's structure -- two SVI objects sharing one Adam (training_cvs.py:226-249), an epoch loop of
 ``run_batch`` (:147-157, :256-266), validation with ``evaluate_loss`` + ``recon`` + label prediction (:43-144), best-model copy
 (:325-331) and the per-epoch summary line (:336-352).  Batches come from ``synthetic.synthetic_batch`` unless ``--data-dir`` points at
-the reference's data files (cvs: ``processed_data.pkl`` ...; challenge: ``data.pkl``), which are then read by ``data.py`` (SURVEY row
+the reference's data files (cvs: ``processed_data.pkl`` ...; challenge: ``data.pkl``; proc: the plate-reader CSVs), which are then read by ``data.py`` (SURVEY row
 N3) and fed through pinned host buffers, or the caller passes its own list of batch dicts."""
 from __future__ import annotations
 
@@ -70,10 +70,12 @@ def make_batches(config, family: str, n_batches: int, seed: int):
 
 
 def train(config, family: str, model_cls, model_cls_gauss, batches_per_epoch: int = 7,
-          train_batches: Optional[Sequence[dict]] = None, val_batches: Optional[Sequence[dict]] = None):
+          train_batches: Optional[Sequence[dict]] = None, val_batches: Optional[Sequence[dict]] = None, times: Optional[torch.Tensor] = None):
     set_seed(config.seed)
     device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-    if family == "proc":
+    if times is not None:
+        times = times.to(device)
+    elif family == "proc":
         _, _, times = synthetic_batch("proc", 1, config.seq_len, config.obs_dim, seed=0)     # non-uniform grid like the CSV times
         times = times.to(device)
     else:
@@ -116,7 +118,7 @@ def train(config, family: str, model_cls, model_cls_gauss, batches_per_epoch: in
 
 
 def real_batches(config, family: str, data_dir: str):
-    """(train_batches, val_batches) read from the reference's data files with the reference's transforms and splits
+    """(train_batches, val_batches, times or None) read from the reference's data files with the reference's transforms and splits
     (training_cvs.py:168-190, training_challenge.py:226-246); each an iterable of host batch dicts re-read every epoch."""
     from . import data as D
     dev = torch.device("cuda" if torch.cuda.is_available() else "cpu")
@@ -128,8 +130,11 @@ def real_batches(config, family: str, data_dir: str):
         pair = D.build_challenge_datasets(os.path.join(data_dir, "data.pkl"), config.seed, config.folds, config.split)
         tf = D.create_transforms(config.norm, pair.data_norm_params)
         tr, va = D.ChallengeDataset(pair.train, transforms=tf), D.ChallengeDataset(pair.test, transforms=tf)
-    else:
-        raise ValueError("--data-dir is wired for the cvs and challenge families (proc: data.load_proc_csv / ProcDataset)")
+    else:   # proc: observations are already [C, T]; the (non-uniform) time grid comes with the data
+        tr, va, times = D.build_proc_datasets(data_dir, config.seed, config.folds, config.split, getattr(config, "heldout", None))
+        config.seq_len = int(times.numel())
+        return (D.BatchFeeder(tr, config.mini_batch_size, dev, shuffle=True, seed=config.seed),
+                D.BatchFeeder(va, config.mini_batch_size, dev), times)
     class _AsBCT:
         """The datasets yield [B, T, C]; the models take the [B, C, T] permuted VIEW of it (training_cvs.py:25: no copy)."""
 
@@ -145,7 +150,7 @@ def real_batches(config, family: str, data_dir: str):
                 yield b
 
     return (_AsBCT(D.BatchFeeder(tr, config.mini_batch_size, dev, shuffle=True, seed=config.seed)),
-            _AsBCT(D.BatchFeeder(va, config.mini_batch_size, dev)))
+            _AsBCT(D.BatchFeeder(va, config.mini_batch_size, dev)), None)
 
 
 def main(family: str, load_config, model_cls, model_cls_gauss):
@@ -161,5 +166,5 @@ def main(family: str, load_config, model_cls, model_cls_gauss):
     logging.basicConfig(filename="results_%s/model.log" % config.model, filemode="w", level=logging.DEBUG)
     kw = {}
     if a.data_dir:
-        kw["train_batches"], kw["val_batches"] = real_batches(config, family, a.data_dir)
+        kw["train_batches"], kw["val_batches"], kw["times"] = real_batches(config, family, a.data_dir)
     train(config, family, model_cls, model_cls_gauss, a.batches_per_epoch, **kw)

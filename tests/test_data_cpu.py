@@ -113,6 +113,15 @@ def test_proc_csv_reader(tmp_path):
     assert np.allclose(ds.inputs[0].numpy(), np.log(1.0 + np.array([25000.0, 0.0])))
     assert float(ds.observations.min()) == 0.0 and float(ds.observations.max()) <= 1.0
     assert ds[2]["dev_1hot"].tolist() == [0.0, 1.0]
+    # the training view of training_proc.py:23-32: aR | aS cassettes, C12 := inputs[:, 0], C6 := inputs[:, 1], observations [C, T]
+    tr, va, times = D.build_proc_datasets(str(tmp_path), seed=12, folds=3, split=1, files=["a.csv", "b.csv"])
+    assert len(tr) + len(va) == 3 and len(va) == 1 and times.shape == (8,)
+    item = tr[0]
+    assert item["observations"].shape == (4, 8) and item["aR"].shape == (3,) and item["aS"].shape == (4,)
+    assert float(item["aR"].sum()) == 1.0 and float(item["aS"].sum()) == 1.0 and item["C12"].shape == (1,) and item["C6"].shape == (1,)
+    assert D.proc_cassettes(np.array([0, 3, 5])).tolist() == [[1, 0, 0, 1, 0, 0, 0], [0, 0, 1, 0, 1, 0, 0], [0, 0, 1, 0, 0, 0, 1]]
+    tr_h, va_h, _ = D.build_proc_datasets(str(tmp_path), seed=12, folds=3, split=1, heldout="Pcat_Y81C76", files=["a.csv", "b.csv"])
+    assert len(va_h) == 1 and float(va_h[0]["aR"][0]) == 1.0 and len(tr_h) == 2
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference data tree not present (GPU box)")
@@ -126,3 +135,6 @@ def test_readers_on_the_shipped_reference_files():
     dmap = {d: float(i) for i, d in enumerate(devices)}
     parsed = D.load_proc_csv(REF + "/proc/proc140916.csv", devices, dmap, ["C6", "C12"], ["OD", "mRFP1", "EYFP", "ECFP"])
     assert parsed is not None and parsed[3].shape[1:] == (4, 100) and parsed[1].shape[1] == 2 and len(parsed[2]) == 100
+    tr, va, times = D.build_proc_datasets(REF + "/proc", seed=12, folds=4, split=1)
+    assert len(tr) == 234 and len(va) == 78 and times.shape == (100,) and tr[0]["observations"].shape == (4, 100)
+    assert 0.0 <= float(tr.ds.observations.min()) and float(tr.ds.observations.max()) <= 1.0
