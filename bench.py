@@ -61,11 +61,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    # SLODE_BENCH_REHEARSE=1: control-flow rehearsal of the N>1 path on a one-GPU box (every rank on cuda:0, gloo); never a measurement
+    rehearse = world > 1 and os.environ.get("SLODE_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)
 
     from structured_latent_odes_amd.configs import load_config_cvs
     from structured_latent_odes_amd.models.mechanistic_cvs import MechanisticModel
@@ -178,6 +185,7 @@ def main():
         "metric": "trajectories/sec ELBO step (CVS, batch=1024, T=200)", "value": value, "unit": "trajectories/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        **({"rehearsal": "all ranks on cuda:0 over gloo: NOT a measurement"} if rehearse else {}),
         "config": {"workload": "BASELINE config[1]: synthetic CVS, B=1024/GPU, T=200, C=3, latent_dim=8 (3,3,2), S=5, "
                                "rk4(3/8) fixed grid dt=1, ALD 3-quantile likelihood; step = ELBO fwd+bwd (all 96,462 parameters) "
                                "+ grad all-reduce (N>1) + Adam",

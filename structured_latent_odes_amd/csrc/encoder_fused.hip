@@ -359,11 +359,13 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const Tai
   STAMP(17);
   const float gb = s_G[CT];
   const int sC = k.t_major ? 1 : T, sT = k.t_major ? C : 1;   // kappa(c, t) = c*sC + t*sT
+  // The two contractions are independent: the lower half of the workgroup runs (i) while the upper half runs (ii).
+  const int NT1 = NT / 2, NT2 = NT - NT1;
   // (i) dLoss/d lin.weight[m][f*n_pool + q] = g_beff[m]*conv_b[f] + sum_{c,j} G[kappa(c, q+j)] * w'[f][c][j]; thread (fh, q)
-  {
-    const int nfh = (NT / n_pool) < 1 ? 1 : ((NT / n_pool) > F ? F : (NT / n_pool));   // filter groups handled in parallel
+  if (tid < NT1) {
+    const int nfh = (NT1 / n_pool) < 1 ? 1 : ((NT1 / n_pool) > F ? F : (NT1 / n_pool));   // filter groups handled in parallel
     const int fper = (F + nfh - 1) / nfh;
-    for (int e = tid; e < nfh * n_pool; e += NT) {
+    for (int e = tid; e < nfh * n_pool; e += NT1) {
       const int fh = e / n_pool, q = e - fh * n_pool;
       float Gw[C][JM];
 #pragma unroll
@@ -384,9 +386,9 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const Tai
   STAMP(18);
   // (ii) partial dLoss/dw'[f][c][j] (this m) = sum_q G[kappa(c, q+j)] * lin.weight[m][f*n_pool + q]; thread (qchunk, f, c) keeps all
   // JM taps in registers and slides a JM-wide window of G along q (2 LDS reads per JM FMAs)
-  {
+  if (tid >= NT1) {
     const int per = (n_pool + QCH - 1) / QCH;
-    for (int e = tid; e < QCH * F * C; e += NT) {
+    for (int e = tid - NT1; e < QCH * F * C; e += NT2) {
       const int fc = e % (F * C), ch = e / (F * C), f = fc / C, c = fc - f * C;
       const int q0 = ch * per, q1 = min(n_pool, q0 + per);
       const float* wl = s_wl + f * n_pool;
