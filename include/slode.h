@@ -180,7 +180,12 @@ int slode_decode_heads(slode_handle h, const slode_shape* s, const slode_layout*
  *   over the batch) -> exact gradient wrt every parameter of the layout.
  * Outputs: loss_out[0] = -ELBO (float, device); grads[0 .. lay->n_params) overwritten.
  * With grads == NULL only the loss is computed (SVI.evaluate_loss, training_cvs.py:81).
- * Optional outputs (NULL to skip): x_out[B,T,S] latent trajectories, z_out[B,L]. */
+ * Optional outputs (NULL to skip): x_out[B,T,S] latent trajectories, z_out[B,L].
+ * method == SLODE_DOPRI5 (solver="dopri5", models/blackbox_ode.py:41-45): adaptive solve with one controller per trajectory
+ * (rtol / atol of the shape); the gradient is the reverse mode of the accepted steps and of the dense output, step sizes held fixed
+ * (grad_mode SLODE_GRAD_REFERENCE_ADJOINT: without the z -> dynamics path, as odeint_adjoint).  stage_t is ignored.  At most 65,536
+ * trajectories per call; a trajectory whose accepted steps exceed the record capacity (256 MB / (B*(S+2)) floats, clamped to
+ * [64, 2048] steps) or that exhausts 20,000 attempted steps turns the loss into NaN.  slode_workspace_bytes accounts for the records. */
 int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params,
                     const float* times, const float* stage_t, const float* obs, const int64_t obs_strides[3],
                     const float* u, const float* eps, float* loss_out, float* grads, float* x_out, float* z_out,

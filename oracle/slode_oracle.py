@@ -282,7 +282,9 @@ def odeint_dopri5(f, y0: Tensor, times: Tensor, rtol: float = 1e-7, atol: float 
     d2 = norm((f1 - f0) / scale) / h0
     h1 = torch.where((d1 <= 1e-15) & (d2 <= 1e-15), torch.maximum(torch.full_like(h0, 1e-6), h0 * 1e-3),
                      (0.01 / torch.maximum(d1, d2)) ** (1.0 / 5.0))
-    dt = torch.minimum(100 * h0, h1)
+    # the controller is not differentiated: step sizes are data of the discrete solve (differentiating ratio ** -0.2 through
+    # rejected / floor-limited steps is meaningless and overflows); gradients are those of the accepted steps + dense output
+    dt = torch.minimum(100 * h0, h1).detach()
 
     n_ctl = dt.shape[0]
     t = t0.expand(n_ctl).clone()
@@ -325,7 +327,7 @@ def odeint_dopri5(f, y0: Tensor, times: Tensor, rtol: float = 1e-7, atol: float 
                                0.9 * ratio.clamp_min(1e-300) ** (-1.0 / 5.0))
             factor = torch.where(ratio < 1, safe.clamp(1.0, 10.0), safe.clamp(0.2, 10.0))   # dfactor = 1 iff ratio < 1 (torchdiffeq)
             factor = torch.where(ratio == 0, torch.full_like(ratio, 10.0), factor)
-            dt = torch.where(active, dt * factor, dt)
+            dt = torch.where(active, dt * factor, dt).detach()
         # dense output at tj through the last accepted step of each controller
         out.append(_dopri5_interp(bc(t_prev), bc(t), y_prev, y_mid, y, f_prev, fy, tj))
     return torch.stack(out, dim=0)
@@ -365,10 +367,15 @@ def solve_ode(p: Params, z: Tensor, times: Tensor, method: str, prefix: str = _O
         sol = _OdeintAdjoint.apply(fb, x0, times, method, *[p[prefix + k] for k in _DYN_KEYS])
         return sol.permute(1, 0, 2)
     if method == "dopri5":
+        # reference_adjoint with the adaptive solver: odeint_adjoint's adjoint_params are the dynamics weights only (z is a plain
+        # tensor, hard part 2), and its continuous adjoint -- itself solved by dopri5 -- equals the gradient of the discrete solve to
+        # solver tolerance.  Restated at solution level: autograd through the solve with the latent detached inside the dynamics.
+        zd = z.detach() if grad_mode == "reference_adjoint" else z
+
         def fr(t, x):
             if t.dim() == 0:
-                return dynamics(p, t, x, z, prefix)
-            return _dynamics_rowtime(p, t, x, z, prefix)
+                return dynamics(p, t, x, zd, prefix)
+            return _dynamics_rowtime(p, t, x, zd, prefix)
         sol = odeint_dopri5(fr, x0, times, **kw)
     else:
         sol = odeint_fixed(lambda t, x: dynamics(p, t, x, z, prefix), x0, times, method)  # :41-45

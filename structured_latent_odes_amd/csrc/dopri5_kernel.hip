@@ -7,6 +7,13 @@
 // ratio = rms(err / (atol + rtol*max(|y0|,|y1|))), factor clamp [0.2, 10] with safety 0.9, quartic dense output through
 // (y0, y_mid, y1, f0, f1)) -- validated at solution level against the oracle's per-trajectory restatement and scipy RK45.
 // The dynamics weights arrive as SGPR operands (uniform), the per-trajectory hidden offsets u = W_z z + b live in LDS.
+//
+// Training with dopri5 (BASELINE config[2]): the forward kernel also records every accepted step (t, dt, y) and
+// `dopri5_bwd_kernel` walks a trajectory's record backwards -- the exact reverse mode of the accepted Dormand-Prince steps and of
+// the dense-output polynomial, step sizes held fixed (the controller is not differentiated), lane = trajectory.  The right-hand
+// side is linear in the state with coefficients that depend on time only, so a step's seven stages are re-evaluated from its
+// recorded (t, dt, y) instead of being stored.  Dynamics-weight gradients accumulate in per-lane LDS columns and leave the
+// workgroup as one slab row in the layout of the fixed-grid kernel's slabs (summed by the same deterministic tail).
 #include "slode_common.h"
 
 typedef const __attribute__((address_space(4))) float* cptr;
@@ -16,7 +23,12 @@ namespace {
 struct DpK {
   int B, T, L;
   const float *times, *z, *w1, *b1, *w2, *b2, *wh, *bh, *wg, *bg, *wd, *bd;
+  const float *loc, *scale, *eps;   // z == nullptr: z = loc + scale * eps (the guide's sample), written to z_out
   float* x;
+  float* z_out;
+  float* rec;    // [kmax][B][S + 2] accepted steps (t, dt, y) or nullptr
+  int* nrec;     // [B] accepted steps per trajectory (> kmax: record overflow; -1: max_steps exhausted)
+  int kmax;
   float rtol, atol;
   int max_steps;
 };
@@ -60,7 +72,15 @@ __global__ void __launch_bounds__(DPW) dopri5_kernel(const DpK k) {
   const bool live = b < k.B;
   const cptr wg = (cptr)k.wg, bg = (cptr)k.bg, wd = (cptr)k.wd, bd = (cptr)k.bd;
   if (lane < 32) s_wt[lane] = lane < H ? k.wh[lane * (1 + L)] : 0.f;
-  for (int l = 0; l < L; ++l) s_z[l * DPW + lane] = live ? k.z[(long long)(live ? b : 0) * L + l] : 0.f;
+  for (int l = 0; l < L; ++l) {
+    const long long i = (long long)(live ? b : 0) * L + l;
+    float zl = 0.f;
+    if (live) {
+      zl = k.z ? k.z[i] : fmaf(k.scale[i], k.eps[i], k.loc[i]);
+      if (k.z_out) k.z_out[i] = zl;
+    }
+    s_z[l * DPW + lane] = zl;
+  }
   __syncthreads();
   // u = W_z z + b_h ; x0 = sigmoid(W2 relu(W1 z + b1) + b2)   (blackbox_ode.py:19-22, 97-101)
   float y[S];
@@ -113,7 +133,7 @@ __global__ void __launch_bounds__(DPW) dopri5_kernel(const DpK k) {
     dt = fminf(100.f * h0, h1);
   }
   int j = 1;
-  int steps = 0;
+  int steps = 0, nacc = 0;
   // every lane leaves the loop: either all outputs written or max_steps reached (outputs then hold the last state)
   while (__any(live && j < T && steps < k.max_steps)) {
     const bool act = live && j < T && steps < k.max_steps;
@@ -153,6 +173,13 @@ __global__ void __launch_bounds__(DPW) dopri5_kernel(const DpK k) {
     const bool accept = act && (ratio <= 1.f || dt <= 16.f * 1.1920929e-7f * fmaxf(fabsf(t), 1.f));
     if (accept) {
       const float t1 = t + dt;
+      if (k.rec && nacc < k.kmax) {
+        float* r = k.rec + ((long long)nacc * k.B + b) * (S + 2);
+        r[0] = t; r[1] = dt;
+#pragma unroll
+        for (int s = 0; s < S; ++s) r[2 + s] = y[s];
+      }
+      ++nacc;
       if (j < T && k.times[j] <= t1) {
         float ymid[S];
 #pragma unroll
@@ -187,18 +214,362 @@ __global__ void __launch_bounds__(DPW) dopri5_kernel(const DpK k) {
       dt *= factor;
     }
   }
-  if (live)  // max_steps exhausted: fill the remaining outputs with the last state (finite, and flagged by the host via steps)
+  if (live) {
+    if (k.nrec) k.nrec[b] = (j < T) ? -1 : nacc;
+    // max_steps exhausted: fill the remaining outputs with the last state (finite; the training path turns nrec < 0 into a NaN loss)
     for (; j < T; ++j)
 #pragma unroll
       for (int s = 0; s < S; ++s) xo[j * S + s] = y[s];
+  }
+}
+
+// ---- reverse mode over the recorded steps --------------------------------------------------------------------------------
+struct DpBK {
+  int B, T, L, kmax, drop_z;   // drop_z: reference_adjoint semantics -- z is not an adjoint parameter of the dynamics
+  const float *times, *z, *gx, *rec;
+  const int* nrec;
+  const float *w1, *b1, *w2, *b2, *wh, *bh, *wg, *bg, *wd, *bd;
+  float *gz, *slabs;           // gz [B][L]; slabs: one row per workgroup, slot 0 = loss (0, or NaN on a failed solve), then the ode segment
+  int slab_stride, nseg;
+  int o_w1, o_b1, o_w2, o_b2, o_wh, o_bh, o_wg, o_bg, o_wd, o_bd;
+};
+
+// growth / degradation coefficients at time t: a = sigmoid(Wg h + bg), d = sigmoid(Wd h + bd), h = relu(wt t + u)
+template <int S, int H>
+__device__ __forceinline__ void coef(float t, const float* __restrict__ s_wt, const float* __restrict__ s_ul, cptr wg, cptr bg, cptr wd,
+                                     cptr bd, float (&a)[S], float (&d)[S]) {
+  asm volatile("" : "+s"(wg), "+s"(wd), "+s"(bg), "+s"(bd));
+  float xa[S], xd[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) { xa[s] = bg[s]; xd[s] = bd[s]; }
+  // hidden-unit-major with a short unroll: the fully unrolled form keeps all 2*S*H weights in SGPRs at once and spills hundreds
+#pragma unroll 5
+  for (int j = 0; j < H; ++j) {
+    const float h = fmaxf(fmaf(s_wt[j], t, s_ul[j * DPW]), 0.f);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      xa[s] = fmaf(wg[s * H + j], h, xa[s]);
+      xd[s] = fmaf(wd[s * H + j], h, xd[s]);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) { a[s] = sigmoidf_fast(xa[s]); d[s] = sigmoidf_fast(xd[s]); }
+}
+
+// Weight gradients of one accepted step: its six evaluation times at once, so that every accumulator column entry is touched once
+// per step (plain read-modify-write: the column is lane-private) and the weights are fetched once per hidden unit.
+// gxa / gxd: dL/d(pre-sigmoid growth / degradation) per evaluation time.  acc columns (stride DPW): [wg S*H | wd S*H | bg S | bd S | u H | wt H]
+template <int S, int H>
+__device__ __forceinline__ void accum_step(const float (&te)[6], const float* __restrict__ s_wt, const float* __restrict__ s_ul, cptr wg, cptr wd,
+                                           const float (&gxa)[6][S], const float (&gxd)[6][S], float* __restrict__ acc) {
+  asm volatile("" : "+s"(wg), "+s"(wd));   // keep the weight loads inside the step
+#pragma unroll 1
+  for (int j = 0; j < H; ++j) {
+    const float wt = s_wt[j], uj = s_ul[j * DPW];
+    float wgj[S], wdj[S], ta[S], td[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) { wgj[s] = wg[s * H + j]; wdj[s] = wd[s * H + j]; ta[s] = 0.f; td[s] = 0.f; }
+    float gu = 0.f, gwt = 0.f;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const float pre = fmaf(wt, te[e], uj);
+      const float h = fmaxf(pre, 0.f);
+      float gh = 0.f;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        gh = fmaf(gxa[e][s], wgj[s], gh);
+        gh = fmaf(gxd[e][s], wdj[s], gh);
+        ta[s] = fmaf(gxa[e][s], h, ta[s]);
+        td[s] = fmaf(gxd[e][s], h, td[s]);
+      }
+      gh = pre > 0.f ? gh : 0.f;
+      gu += gh;
+      gwt = fmaf(gh, te[e], gwt);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      acc[(s * H + j) * DPW] += ta[s];
+      acc[(S * H + s * H + j) * DPW] += td[s];
+    }
+    acc[(2 * S * H + 2 * S + j) * DPW] += gu;
+    acc[(2 * S * H + 2 * S + H + j) * DPW] += gwt;
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    float a = 0.f, d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) { a += gxa[e][s]; d += gxd[e][s]; }
+    acc[(2 * S * H + s) * DPW] += a;
+    acc[(2 * S * H + S + s) * DPW] += d;
+  }
+}
+
+template <int S, int H>
+__global__ void __launch_bounds__(DPW) dopri5_bwd_kernel(const DpBK k) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NACC = 2 * S * H + 2 * S + 2 * H;
+  float* s_wt = smem;                 // [32]
+  float* s_u = s_wt + 32;             // [H][DPW] hidden offsets; after the step loop: dL/d(init-net pre-activation)
+  float* s_z = s_u + H * DPW;         // [L][DPW]
+  float* s_acc = s_z + k.L * DPW;     // [NACC][DPW]
+  const int lane = threadIdx.x, b = blockIdx.x * DPW + lane, L = k.L, T = k.T;
+  const bool live = b < k.B;
+  const cptr wg = (cptr)k.wg, bg = (cptr)k.bg, wd = (cptr)k.wd, bd = (cptr)k.bd;
+  const cptr wh = (cptr)k.wh, bh = (cptr)k.bh, w1 = (cptr)k.w1, b1 = (cptr)k.b1, w2 = (cptr)k.w2, b2 = (cptr)k.b2;
+  if (lane < 32) s_wt[lane] = lane < H ? k.wh[lane * (1 + L)] : 0.f;
+  for (int l = 0; l < L; ++l) s_z[l * DPW + lane] = live ? k.z[(long long)b * L + l] : 0.f;
+  for (int i = 0; i < NACC; ++i) s_acc[i * DPW + lane] = 0.f;
+  __syncthreads();
+  for (int j = 0; j < H; ++j) {
+    float uj = bh[j];
+    for (int l = 0; l < L; ++l) uj = fmaf(wh[j * (1 + L) + 1 + l], s_z[l * DPW + lane], uj);
+    s_u[j * DPW + lane] = uj;
+  }
+  const float* s_ul = s_u + lane;
+  float* acc = s_acc + lane;
+  const int nr = live ? k.nrec[b] : 0;
+  const bool bad = nr < 0 || nr > k.kmax;
+  const int K = bad ? 0 : nr;
+  const float* gxb = k.gx + (long long)(live ? b : 0) * T * S;
+  float lam[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) lam[s] = 0.f;
+  int j = T - 1;
+  // every lane leaves the loop after max(K) <= kmax iterations
+  for (int it = 0; __any(it < K); ++it) {
+    const bool act = it < K;
+    const int kk = act ? K - 1 - it : 0;
+    float t = 0.f, dt = 0.f, y[S];
+    {
+      const float* r = k.rec + ((long long)kk * k.B + (live ? b : 0)) * (S + 2);
+      if (act) { t = r[0]; dt = r[1]; }
+#pragma unroll
+      for (int s = 0; s < S; ++s) y[s] = act ? r[2 + s] : 0.f;
+    }
+    // stage coefficients at the six distinct stage times (stages 6 and 7 share t + dt) and the stage slopes
+    float A[6][S], D[6][S];
+    coef<S, H>(t, s_wt, s_ul, wg, bg, wd, bd, A[0], D[0]);
+    coef<S, H>(t + dt * (1.f / 5), s_wt, s_ul, wg, bg, wd, bd, A[1], D[1]);
+    coef<S, H>(t + dt * (3.f / 10), s_wt, s_ul, wg, bg, wd, bd, A[2], D[2]);
+    coef<S, H>(t + dt * (4.f / 5), s_wt, s_ul, wg, bg, wd, bd, A[3], D[3]);
+    coef<S, H>(t + dt * (8.f / 9), s_wt, s_ul, wg, bg, wd, bd, A[4], D[4]);
+    coef<S, H>(t + dt, s_wt, s_ul, wg, bg, wd, bd, A[5], D[5]);
+    float k1[S], k2[S], k3[S], k4[S], k5[S], k6[S], y2[S], y3[S], y4[S], y5[S], y6[S], y1[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      k1[s] = A[0][s] - D[0][s] * y[s];
+      y2[s] = fmaf(dt, (1.f / 5) * k1[s], y[s]);
+      k2[s] = A[1][s] - D[1][s] * y2[s];
+      y3[s] = fmaf(dt, (3.f / 40) * k1[s] + (9.f / 40) * k2[s], y[s]);
+      k3[s] = A[2][s] - D[2][s] * y3[s];
+      y4[s] = fmaf(dt, (44.f / 45) * k1[s] + (-56.f / 15) * k2[s] + (32.f / 9) * k3[s], y[s]);
+      k4[s] = A[3][s] - D[3][s] * y4[s];
+      y5[s] = fmaf(dt, (19372.f / 6561) * k1[s] + (-25360.f / 2187) * k2[s] + (64448.f / 6561) * k3[s] + (-212.f / 729) * k4[s], y[s]);
+      k5[s] = A[4][s] - D[4][s] * y5[s];
+      y6[s] = fmaf(dt, (9017.f / 3168) * k1[s] + (-355.f / 33) * k2[s] + (46732.f / 5247) * k3[s] + (49.f / 176) * k4[s] + (-5103.f / 18656) * k5[s], y[s]);
+      k6[s] = A[5][s] - D[5][s] * y6[s];
+      y1[s] = fmaf(dt, (35.f / 384) * k1[s] + (500.f / 1113) * k3[s] + (125.f / 192) * k4[s] + (-2187.f / 6784) * k5[s] + (11.f / 84) * k6[s], y[s]);
+    }
+    // dense outputs inside (t, t + dt]: x_j = y + q cd + q^2 cc + q^3 cb + q^4 ca with q = (times[j] - t) / dt
+    float Ga[S], Gb[S], Gc[S], Gd[S], gy[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) Ga[s] = Gb[s] = Gc[s] = Gd[s] = gy[s] = 0.f;
+    while (act && j >= 1 && k.times[j] > t) {
+      const float q = (k.times[j] - t) / dt, q2 = q * q, q3 = q2 * q, q4 = q2 * q2;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const float g = gxb[j * S + s];
+        gy[s] += g;
+        Gd[s] = fmaf(q, g, Gd[s]); Gc[s] = fmaf(q2, g, Gc[s]); Gb[s] = fmaf(q3, g, Gb[s]); Ga[s] = fmaf(q4, g, Ga[s]);
+      }
+      --j;
+    }
+    float g1[S], g2[S], g3[S], g4[S], g5[S], g6[S], gxa[6][S], gxd[6][S], gy1[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const float gf0 = dt * (-2.f * Ga[s] + 5.f * Gb[s] - 4.f * Gc[s] + Gd[s]);
+      const float gf1 = dt * (2.f * Ga[s] - 3.f * Gb[s] + Gc[s]);
+      const float gm = 16.f * Ga[s] - 32.f * Gb[s] + 16.f * Gc[s];          // dL/dy_mid
+      gy[s] += -8.f * Ga[s] + 18.f * Gb[s] - 11.f * Gc[s] + gm;
+      gy1[s] = lam[s] - 8.f * Ga[s] + 14.f * Gb[s] - 5.f * Gc[s];
+      const float dgm = dt * gm;
+      g1[s] = fmaf(dgm, 6025192743.f / 30085553152.f / 2, gf0);
+      g2[s] = 0.f;
+      g3[s] = dgm * (51252292925.f / 65400821598.f / 2);
+      g4[s] = dgm * (-2691868925.f / 45128329728.f / 2);
+      g5[s] = dgm * (187940372067.f / 1594534317056.f / 2);
+      g6[s] = dgm * (-1776094331.f / 19743644256.f / 2);
+      const float g7 = fmaf(dgm, 11237099.f / 235043384.f / 2, gf1);
+      // stage 7: k7 = a5 - d5 * y1
+      gxa[5][s] = g7 * A[5][s] * (1.f - A[5][s]);
+      gxd[5][s] = -g7 * y1[s] * D[5][s] * (1.f - D[5][s]);
+      gy1[s] = fmaf(-D[5][s], g7, gy1[s]);
+      // y1 = y + dt * sum b_i k_i
+      gy[s] += gy1[s];
+      const float dg = dt * gy1[s];
+      g1[s] = fmaf(dg, 35.f / 384, g1[s]); g3[s] = fmaf(dg, 500.f / 1113, g3[s]); g4[s] = fmaf(dg, 125.f / 192, g4[s]);
+      g5[s] = fmaf(dg, -2187.f / 6784, g5[s]); g6[s] = fmaf(dg, 11.f / 84, g6[s]);
+      // stage 6 (same time as stage 7: one weight-gradient accumulation for both)
+      gxa[5][s] = fmaf(g6[s], A[5][s] * (1.f - A[5][s]), gxa[5][s]);
+      gxd[5][s] = fmaf(-g6[s] * y6[s], D[5][s] * (1.f - D[5][s]), gxd[5][s]);
+      const float e6 = -D[5][s] * g6[s];
+      gy[s] += e6;
+      const float d6 = dt * e6;
+      g1[s] = fmaf(d6, 9017.f / 3168, g1[s]); g2[s] = fmaf(d6, -355.f / 33, g2[s]); g3[s] = fmaf(d6, 46732.f / 5247, g3[s]);
+      g4[s] = fmaf(d6, 49.f / 176, g4[s]); g5[s] = fmaf(d6, -5103.f / 18656, g5[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {   // stage 5
+      gxa[4][s] = g5[s] * A[4][s] * (1.f - A[4][s]);
+      gxd[4][s] = -g5[s] * y5[s] * D[4][s] * (1.f - D[4][s]);
+      const float e = -D[4][s] * g5[s];
+      gy[s] += e;
+      const float de = dt * e;
+      g1[s] = fmaf(de, 19372.f / 6561, g1[s]); g2[s] = fmaf(de, -25360.f / 2187, g2[s]); g3[s] = fmaf(de, 64448.f / 6561, g3[s]);
+      g4[s] = fmaf(de, -212.f / 729, g4[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {   // stage 4
+      gxa[3][s] = g4[s] * A[3][s] * (1.f - A[3][s]);
+      gxd[3][s] = -g4[s] * y4[s] * D[3][s] * (1.f - D[3][s]);
+      const float e = -D[3][s] * g4[s];
+      gy[s] += e;
+      const float de = dt * e;
+      g1[s] = fmaf(de, 44.f / 45, g1[s]); g2[s] = fmaf(de, -56.f / 15, g2[s]); g3[s] = fmaf(de, 32.f / 9, g3[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {   // stage 3
+      gxa[2][s] = g3[s] * A[2][s] * (1.f - A[2][s]);
+      gxd[2][s] = -g3[s] * y3[s] * D[2][s] * (1.f - D[2][s]);
+      const float e = -D[2][s] * g3[s];
+      gy[s] += e;
+      const float de = dt * e;
+      g1[s] = fmaf(de, 3.f / 40, g1[s]); g2[s] = fmaf(de, 9.f / 40, g2[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {   // stage 2
+      gxa[1][s] = g2[s] * A[1][s] * (1.f - A[1][s]);
+      gxd[1][s] = -g2[s] * y2[s] * D[1][s] * (1.f - D[1][s]);
+      const float e = -D[1][s] * g2[s];
+      gy[s] += e;
+      g1[s] = fmaf(dt * e, 1.f / 5, g1[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {   // stage 1
+      gxa[0][s] = g1[s] * A[0][s] * (1.f - A[0][s]);
+      gxd[0][s] = -g1[s] * y[s] * D[0][s] * (1.f - D[0][s]);
+      gy[s] = fmaf(-D[0][s], g1[s], gy[s]);
+    }
+    {
+      const float te[6] = {t, t + dt * (1.f / 5), t + dt * (3.f / 10), t + dt * (4.f / 5), t + dt * (8.f / 9), t + dt};
+      accum_step<S, H>(te, s_wt, s_ul, wg, wd, gxa, gxd, acc);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) lam[s] = act ? gy[s] : lam[s];
+  }
+  // ---- init net: x0 = sigmoid(W2 relu(W1 z + b1) + b2); the j = 0 output is x0 itself ---------------------------------
+  float go[S];
+  {
+    float o[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) o[s] = b2[s];
+    for (int jj = 0; jj < H; ++jj) {
+      float p0 = b1[jj];
+      for (int l = 0; l < L; ++l) p0 = fmaf(w1[jj * L + l], s_z[l * DPW + lane], p0);
+      const float hj = fmaxf(p0, 0.f);
+#pragma unroll
+      for (int s = 0; s < S; ++s) o[s] = fmaf(w2[s * H + jj], hj, o[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const float x0 = sigmoidf_fast(o[s]);
+      const float g = (live && !bad) ? lam[s] + gxb[s] : 0.f;
+      go[s] = g * x0 * (1.f - x0);
+    }
+  }
+  // zero this workgroup's slab row, then fill in the entries it owns
+  float* row = k.slabs + (long long)blockIdx.x * k.slab_stride;
+  const bool any_bad = __any(live && bad);
+  for (int i = lane; i <= k.nseg; i += DPW) row[i] = (i == 0 && any_bad) ? __builtin_nanf("") : 0.f;
+  __syncthreads();
+  float* prm = row + 1;
+  for (int jj = 0; jj < H; ++jj) {
+    float p0 = b1[jj];
+    for (int l = 0; l < L; ++l) p0 = fmaf(w1[jj * L + l], s_z[l * DPW + lane], p0);
+    const float hj = fmaxf(p0, 0.f);
+    float gh = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      gh = fmaf(w2[s * H + jj], go[s], gh);
+      const float v = wave_sum(go[s] * hj);
+      if (lane == 0) prm[k.o_w2 + s * H + jj] = v;
+    }
+    const float gp = p0 > 0.f ? gh : 0.f;
+    s_u[jj * DPW + lane] = gp;            // u is dead: the column now holds dL/d(init pre-activation j)
+    const float v = wave_sum(gp);
+    if (lane == 0) prm[k.o_b1 + jj] = v;
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const float v = wave_sum(go[s]);
+    if (lane == 0) prm[k.o_b2 + s] = v;
+  }
+  __syncthreads();
+  // latent gradient of this trajectory: through the init net and (exact mode) through u = W_z z + b_h
+  const float* s_gu = s_acc + (2 * S * H + 2 * S) * DPW;
+  for (int l = 0; l < L; ++l) {
+    float g = 0.f;
+    for (int jj = 0; jj < H; ++jj) {
+      g = fmaf(w1[jj * L + l], s_u[jj * DPW + lane], g);
+      if (!k.drop_z) g = fmaf(wh[jj * (1 + L) + 1 + l], s_gu[jj * DPW + lane], g);
+    }
+    if (live) k.gz[(long long)b * L + l] = g;
+  }
+  // outer products with z over the workgroup's trajectories: lane = latent dim l (rotated column reads: no bank conflicts)
+  for (int l0 = 0; l0 < L; l0 += DPW) {
+    const int l = l0 + lane;
+    if (l < L)
+      for (int jj = 0; jj < H; ++jj) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int r = 0; r < DPW; ++r) {
+          const int c = (r + lane) & (DPW - 1);
+          const float zl = s_z[l * DPW + c];
+          a1 = fmaf(s_u[jj * DPW + c], zl, a1);
+          a2 = fmaf(s_gu[jj * DPW + c], zl, a2);
+        }
+        prm[k.o_w1 + jj * L + l] = a1;
+        prm[k.o_wh + jj * (1 + L) + 1 + l] = a2;
+      }
+  }
+  // per-lane columns -> sums over the workgroup's trajectories
+  for (int i = lane; i < NACC; i += DPW) {
+    float a = 0.f;
+    for (int r = 0; r < DPW; ++r) a += s_acc[i * DPW + ((r + lane) & (DPW - 1))];
+    int o;
+    if (i < S * H) o = k.o_wg + i;
+    else if (i < 2 * S * H) o = k.o_wd + (i - S * H);
+    else if (i < 2 * S * H + S) o = k.o_bg + (i - 2 * S * H);
+    else if (i < 2 * S * H + 2 * S) o = k.o_bd + (i - 2 * S * H - S);
+    else if (i < 2 * S * H + 2 * S + H) o = k.o_bh + (i - 2 * S * H - 2 * S);
+    else o = k.o_wh + (i - 2 * S * H - 2 * S - H) * (1 + L);
+    prm[o] = a;
+  }
 }
 
 }  // namespace
 
+int slode_dopri5_kmax(const slode_shape& s) {
+  // record capacity per trajectory: 256 MB of (t, dt, y) records, within [64, 2048] steps
+  long long kmax = (1ll << 26) / ((long long)s.B * (s.S + 2));
+  return (int)(kmax < 64 ? 64 : (kmax > 2048 ? 2048 : kmax));
+}
+
 hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, const float* p, const float* times, const float* z,
-                               float* x, hipStream_t stream) {
+                               float* x, hipStream_t stream, const DopriRec* rec) {
   DpK k;
   k.B = s.B; k.T = s.T; k.L = s.L; k.times = times; k.z = z; k.x = x;
+  k.loc = k.scale = k.eps = nullptr; k.z_out = nullptr; k.rec = nullptr; k.nrec = nullptr; k.kmax = 0;
+  if (rec) { k.loc = rec->loc; k.scale = rec->scale; k.eps = rec->eps; k.z_out = rec->z_out; k.rec = rec->rec; k.nrec = rec->nrec; k.kmax = rec->kmax; }
   k.w1 = p + lay.init_w1; k.b1 = p + lay.init_b1; k.w2 = p + lay.init_w2; k.b2 = p + lay.init_b2;
   k.wh = p + lay.dyn_wh; k.bh = p + lay.dyn_bh; k.wg = p + lay.dyn_wg; k.bg = p + lay.dyn_bg; k.wd = p + lay.dyn_wd; k.bd = p + lay.dyn_bd;
   k.rtol = s.rtol > 0.f ? s.rtol : 1e-7f;
@@ -209,5 +580,30 @@ hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, co
   if (s.H == 25 && s.S == 5) hipLaunchKernelGGL((dopri5_kernel<5, 25>), dim3(grid), dim3(DPW), lds, stream, k);
   else if (s.H == 25 && s.S == 8) hipLaunchKernelGGL((dopri5_kernel<8, 25>), dim3(grid), dim3(DPW), lds, stream, k);
   else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay, const float* p, const float* times, const DopriRec& rec,
+                                   const float* gx, float* gz, float* slabs, int slab_stride, int drop_z, hipStream_t stream) {
+  DpBK k;
+  k.B = s.B; k.T = s.T; k.L = s.L; k.kmax = rec.kmax; k.drop_z = drop_z;
+  k.times = times; k.z = rec.z_out; k.gx = gx; k.rec = rec.rec; k.nrec = rec.nrec;
+  k.w1 = p + lay.init_w1; k.b1 = p + lay.init_b1; k.w2 = p + lay.init_w2; k.b2 = p + lay.init_b2;
+  k.wh = p + lay.dyn_wh; k.bh = p + lay.dyn_bh; k.wg = p + lay.dyn_wg; k.bg = p + lay.dyn_bg; k.wd = p + lay.dyn_wd; k.bd = p + lay.dyn_bd;
+  k.gz = gz; k.slabs = slabs; k.slab_stride = slab_stride; k.nseg = lay.ode_end - lay.ode_begin;
+  const int ob = lay.ode_begin;
+  k.o_w1 = lay.init_w1 - ob; k.o_b1 = lay.init_b1 - ob; k.o_w2 = lay.init_w2 - ob; k.o_b2 = lay.init_b2 - ob;
+  k.o_wh = lay.dyn_wh - ob; k.o_bh = lay.dyn_bh - ob; k.o_wg = lay.dyn_wg - ob; k.o_bg = lay.dyn_bg - ob;
+  k.o_wd = lay.dyn_wd - ob; k.o_bd = lay.dyn_bd - ob;
+  const int grid = (s.B + DPW - 1) / DPW;
+  const size_t lds = sizeof(float) * (32 + (size_t)s.H * DPW + (size_t)s.L * DPW + (size_t)(2 * s.S * s.H + 2 * s.S + 2 * s.H) * DPW);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (s.H == 25 && s.S == 5) {
+    (void)hipFuncSetAttribute((const void*)dopri5_bwd_kernel<5, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((dopri5_bwd_kernel<5, 25>), dim3(grid), dim3(DPW), lds, stream, k);
+  } else if (s.H == 25 && s.S == 8) {
+    (void)hipFuncSetAttribute((const void*)dopri5_bwd_kernel<8, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((dopri5_bwd_kernel<8, 25>), dim3(grid), dim3(DPW), lds, stream, k);
+  } else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -74,6 +74,9 @@ struct OdeK {
   // fused encoder-head backward (folded encoder path): g_pre[b][m] = (1 - hid^2) * (zloc_w^T g_loc + zls_w^T (g_scale * scale))
   const float *enc_hid, *enc_zloc_w, *enc_zls_w;
   float *g_pre, *glat;   // g_pre [B][64]; glat [B][128], row = [g_loc (L) | pad to 64 | g_scale * scale (L) | pad]
+  // externally solved trajectories (dopri5 training, generic instantiation only; see OdeLaunch)
+  const float *x_ext, *gz_ext;
+  float* gx_out;
   int Hc;
 };
 
@@ -693,6 +696,11 @@ ode_elbo_kernel(const OdeK k) {
     if (tid < 64) wave_affine_scan<S, false>(s_A, s_x, T, tid);
     __syncthreads();
     STAMP(5);
+    if (T_ == 0 && k.x_ext) {   // score the adaptive solver's trajectory instead (the scan result is discarded)
+      const float* xe = k.x_ext + (long long)b * T * S;
+      for (int i = tid; i < T * S; i += NT) s_x[i] = xe[i];
+      __syncthreads();
+    }
     if (k.x_out) {
       float* xo = k.x_out + (long long)b * T * S;
       for (int i = tid; i < T * S; i += NT) xo[i] = s_x[i];
@@ -746,8 +754,16 @@ ode_elbo_kernel(const OdeK k) {
         }
         loss_acc -= ll;
         if (BWD) {
+          if (T_ == 0 && k.x_ext) {   // dLoss/dx goes to the adaptive solver's backward pass; nothing flows through this kernel's solver
 #pragma unroll
-          for (int s = 0; s < S; ++s) s_lam[t * S + s] = gx[s];
+            for (int s = 0; s < S; ++s) {
+              if (k.gx_out) k.gx_out[((long long)b * T + t) * S + s] = gx[s];
+              s_lam[t * S + s] = 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int s = 0; s < S; ++s) s_lam[t * S + s] = gx[s];
+          }
         }
       }
     } else if (BWD) {
@@ -970,6 +986,7 @@ ode_elbo_kernel(const OdeK k) {
         for (int off = Lp; off < 64; off <<= 1) gz += __shfl_xor(gz, off, 64);
         if (tid < L) {
           gz += s_gzl[l];
+          if (T_ == 0 && k.gz_ext) gz += k.gz_ext[(long long)b * L + l];
           for (int hd = 0; hd < k.n_aux; ++hd) {
             const slode_aux ax = k.aux[hd];
             if (l >= ax.z_off && l < ax.z_off + ax.z_dim)
@@ -1245,6 +1262,7 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   k.x_out = a.x_out; k.z_out = a.z_out; k.g_loc = a.g_loc; k.g_scale = a.g_scale; k.slabs = a.slabs;
   k.slab_stride = a.slab_stride; k.backward = a.backward; k.with_ll = a.with_ll;
   k.enc_hid = a.enc_hid; k.g_pre = a.g_pre; k.glat = a.glat; k.Hc = s.Hc;
+  k.x_ext = a.x_ext; k.gx_out = a.gx_out; k.gz_ext = a.gz_ext;
   k.enc_zloc_w = p + lay.zloc_w; k.enc_zls_w = p + lay.zls_w;
 
   const int nthreads = slode_ode_threads(s);
@@ -1266,7 +1284,7 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   }
   // shape-specialised instantiations (compile-time LDS offsets, loop bounds, solver): the BASELINE.json shapes and the reference default
   const bool ra = bwd && s.grad_mode == SLODE_GRAD_REFERENCE_ADJOINT;
-  if (s.H == 25 && !getenv("SLODE_ODE_GENERIC")) {
+  if (s.H == 25 && !a.x_ext && !getenv("SLODE_ODE_GENERIC")) {
 #define SLODE_STATIC(SS, TT, CC, LL, QQ, MM)                                                              \
     if (s.S == SS && s.T == TT && s.C == CC && s.L == LL && k.Q == QQ && s.method == MM)                  \
       return launch_sh<SS, 25, TT, CC, LL, QQ, MM>(k, a.grid, nthreads, lds, bwd, stream, ra)

@@ -169,6 +169,10 @@ struct Workspace {
   float *loc, *scale, *pooled, *hid, *g_loc, *g_scale, *g_pre, *ode_slabs, *ode_part, *small_slabs, *small_part, *lin_slabs;
   float *weff, *rowsum, *wprime, *beff, *gslabs, *conv_slabs, *glat, *gslabs2, *gslabs3;  // folded encoder path
   unsigned int* counter;
+  // dopri5 training: solution, dLoss/dx, external latent gradient, latent sample, step records
+  float *dp_x, *dp_gx, *dp_gz, *dp_z, *dp_rec;
+  int* dp_nrec;
+  int dp_kmax, dp_rows;
   int gsplit;
   int ode_grid, ode_stride, small_grid, small_stride, lin_splitk;
   size_t bytes;
@@ -194,8 +198,19 @@ static int ode_grid_for(slode_handle h, const slode_shape& s) {
 
 static size_t align_up(size_t v) { return (v + 63) & ~(size_t)63; }  // in floats: 256-byte alignment
 
-static Workspace carve(slode_handle h, const slode_shape& s, const slode_layout& lay, void* base) {
+// dopri5 training runs the fixed-grid ELBO kernel as the scorer of the adaptive solution (explicit Euler on the data grid as its
+// placeholder solver: nothing flows through it) -- the shape that kernel, the grid and the workspace are sized for
+static slode_shape scorer_shape(const slode_shape& s) {
+  slode_shape e = s;
+  if (s.method == SLODE_DOPRI5) { e.method = SLODE_EULER; e.grad_mode = SLODE_GRAD_EXACT; }
+  return e;
+}
+
+static Workspace carve(slode_handle h, const slode_shape& s_in, const slode_layout& lay, void* base) {
   Workspace w{};
+  const slode_shape s = scorer_shape(s_in);
+  const bool dp5 = s_in.method == SLODE_DOPRI5;
+  w.dp_rows = dp5 ? (s.B + 63) / 64 : 0;
   const int n_conv = s.T - s.K + 1, FQ = s.F * (n_conv - s.P + 1);
   w.ode_grid = ode_grid_for(h, s);
   w.ode_stride = (int)align_up((size_t)(lay.ode_end - lay.ode_begin) + 1);
@@ -212,7 +227,7 @@ static Workspace carve(slode_handle h, const slode_shape& s, const slode_layout&
   w.g_loc = take((size_t)s.B * s.L);
   w.g_scale = take((size_t)s.B * s.L);
   w.g_pre = take((size_t)s.B * 64);
-  w.ode_slabs = take((size_t)w.ode_grid * w.ode_stride);
+  w.ode_slabs = take((size_t)(w.ode_grid + w.dp_rows) * w.ode_stride);   // dopri5: its backward kernel's rows follow the scorer's
   w.ode_part = take((size_t)SLODE_REDUCE_GROUPS * w.ode_stride);
   w.small_slabs = take((size_t)w.small_grid * w.small_stride);
   w.small_part = take((size_t)SLODE_REDUCE_GROUPS * w.small_stride);
@@ -228,6 +243,15 @@ static Workspace carve(slode_handle h, const slode_shape& s, const slode_layout&
   w.gslabs2 = take((size_t)w.gsplit * s.L * (s.Hc + 1));
   w.gslabs3 = take((size_t)w.gsplit * s.L * (s.Hc + 1));
   w.counter = reinterpret_cast<unsigned int*>(take(64));
+  if (dp5) {
+    w.dp_kmax = slode_dopri5_kmax(s);
+    w.dp_x = take((size_t)s.B * s.T * s.S);
+    w.dp_gx = take((size_t)s.B * s.T * s.S);
+    w.dp_gz = take((size_t)s.B * s.L);
+    w.dp_z = take((size_t)s.B * s.L);
+    w.dp_nrec = reinterpret_cast<int*>(take((size_t)s.B));
+    w.dp_rec = take((size_t)w.dp_kmax * s.B * (s.S + 2));
+  }
   w.bytes = o * sizeof(float);
   return w;
 }
@@ -365,8 +389,11 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     return fail(h, SLODE_EINVAL, "a required pointer is NULL");
   if (aux_mode && (s->n_aux < 1 || !u)) return fail(h, SLODE_EINVAL, "the auxiliary loss needs label heads (n_aux >= 1) and labels u");
   if (s->n_groups > 0 && !u) return fail(h, SLODE_EINVAL, "u is NULL but the shape has conditional prior groups");
-  if (!aux_mode && s->method == SLODE_DOPRI5)
-    return fail(h, SLODE_EINVAL, "dopri5 is forward-only (slode_ode_solve_fwd); the ELBO step needs a fixed-grid method");
+  const bool dp5 = !aux_mode && s->method == SLODE_DOPRI5;
+  if (dp5 && !(s->H == 25 && (s->S == 5 || s->S == 8)))
+    return fail(h, SLODE_EINVAL, "dopri5 kernels are instantiated for (S,H) in {(5,25),(8,25)}");
+  if (dp5 && (s->B > 65536 || getenv("SLODE_ODE_LOOP")))
+    return fail(h, SLODE_EINVAL, "the dopri5 ELBO step takes at most 65,536 trajectories per call");
   Workspace w = carve(h, *s, *lay, workspace);
   if (workspace_bytes < w.bytes) return fail(h, SLODE_ENOSPC, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
   hipStream_t st = (hipStream_t)stream;
@@ -408,12 +435,31 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     HIP_TRY(h, slode_launch_aux(al, st));
   } else {
     OdeLaunch a{};
-    a.s = *s; a.lay = *lay; a.params = params; a.times = times; a.stage_t = stage_t;
+    a.s = scorer_shape(*s); a.lay = *lay; a.params = params; a.times = times; a.stage_t = dp5 ? times : stage_t;
     a.obs = obs; a.sb = obs_strides[0]; a.sc = obs_strides[1]; a.st = obs_strides[2];
     a.u = u; a.eps = eps; a.loc = w.loc; a.scale = w.scale; a.x_out = x_out; a.z_out = z_out;
     a.g_loc = w.g_loc; a.g_scale = w.g_scale; a.slabs = w.ode_slabs; a.slab_stride = w.ode_stride; a.grid = w.ode_grid;
     a.backward = bwd ? 1 : 0; a.with_ll = 1;
     if (bwd && folded) { a.enc_hid = w.hid; a.g_pre = w.g_pre; a.glat = w.glat; a.g_loc = nullptr; a.g_scale = nullptr; }
+    if (dp5) {
+      // adaptive solve (per-trajectory controller, accepted steps recorded) -> scorer pass 1: loss terms, dLoss/dx -> reverse mode
+      // over the records: solver-side gradients as extra slab rows + the latent gradient -> scorer pass 2 (below) folds that in
+      DopriRec rc{w.loc, w.scale, eps, w.dp_z, bwd ? w.dp_rec : nullptr, w.dp_nrec, w.dp_kmax};
+      HIP_TRY(h, slode_launch_dopri5(*s, *lay, params, times, nullptr, w.dp_x, st, &rc));
+      a.x_ext = w.dp_x;
+      if (bwd) {
+        a.gx_out = w.dp_gx;
+        e = slode_launch_ode(a, st, h->err, sizeof(h->err));
+        if (e == hipErrorInvalidValue) return SLODE_EINVAL;
+        HIP_TRY(h, e);
+        rc.rec = w.dp_rec;
+        HIP_TRY(h, slode_launch_dopri5_bwd(*s, *lay, params, times, rc, w.dp_gx, w.dp_gz, w.ode_slabs + (size_t)w.ode_grid * w.ode_stride,
+                                           w.ode_stride, s->grad_mode == SLODE_GRAD_REFERENCE_ADJOINT ? 1 : 0, st));
+        a.gx_out = nullptr;
+        a.gz_ext = w.dp_gz;
+        n_slabs = w.ode_grid + w.dp_rows;
+      }
+    }
     for (int rep = 0; rep <= h->repeat_ode; ++rep) {   // repeat_ode > 0: measurement aid (the kernel is idempotent)
       e = slode_launch_ode(a, st, h->err, sizeof(h->err));
       if (e == hipErrorInvalidValue) return SLODE_EINVAL;

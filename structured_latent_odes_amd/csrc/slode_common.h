@@ -235,6 +235,11 @@ struct OdeLaunch {
   const float* enc_hid = nullptr;
   float* g_pre = nullptr;
   float* glat = nullptr;   // [B][128] = [g_loc (L) | pad to 64 | g_scale * scale (L) | pad]
+  // externally solved trajectories (dopri5 training; generic instantiation only): the kernel scores x_ext instead of its own solve,
+  // writes dLoss/dx to gx_out, back-propagates nothing through its solver and adds gz_ext to the latent gradient
+  const float* x_ext = nullptr;   // [B][T][S]
+  float* gx_out = nullptr;        // [B][T][S]
+  const float* gz_ext = nullptr;  // [B][L]
 };
 hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, size_t errlen);
 size_t slode_ode_lds_bytes(const slode_shape& s, int nthreads);
@@ -343,8 +348,13 @@ hipError_t slode_launch_decode_heads(const slode_shape& s, const slode_layout& l
                                      const float* x, float* mu, float* std_ct, hipStream_t stream);
 hipError_t slode_launch_dynamics_eval(const slode_shape& s, const slode_layout& lay, const float* params, float t,
                                       const float* state, const float* z, float* out, hipStream_t stream);
+// adaptive solve with step records (training): z = loc + scale * eps is formed in the kernel and written to z_out
+struct DopriRec { const float *loc, *scale, *eps; float* z_out; float* rec; int* nrec; int kmax; };
+int slode_dopri5_kmax(const slode_shape& s);
 hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const float* z,
-                               float* x, hipStream_t stream);
+                               float* x, hipStream_t stream, const DopriRec* rec = nullptr);
+hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const DopriRec& rec,
+                                   const float* gx, float* gz, float* slabs, int slab_stride, int drop_z, hipStream_t stream);
 hipError_t slode_launch_adam_k(int64_t n, const float* g, const AdamHost& a, hipStream_t stream);
 hipError_t slode_launch_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2,
                              float eps, int64_t step, hipStream_t stream);

@@ -104,7 +104,7 @@ class MechanisticBase(nn.Module):
                          solver=cfg.solver, quantile_diff=cfg.quantile_diff,
                          # config.adjoint_solver (True in all three reference configs) selects torchdiffeq.odeint_adjoint
                          # (models/blackbox_ode.py:40-42): its gradients are reproduced by grad_mode "reference_adjoint"
-                         grad_mode="reference_adjoint" if (getattr(cfg, "adjoint_solver", False) and cfg.solver != "dopri5") else "exact")
+                         grad_mode="reference_adjoint" if getattr(cfg, "adjoint_solver", False) else "exact")
 
     def _bind(self):
         """Create the engine and move every parameter into the flat vector (first hot-path use; needs a HIP device)."""

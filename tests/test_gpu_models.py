@@ -190,14 +190,16 @@ def test_adam_kernel_matches_torch_adam():
     assert (flat.cpu() - ref.detach()).abs().max().item() < 1e-6
 
 
-@pytest.mark.parametrize("family", ["cvs", "challenge", "proc"])
+@pytest.mark.parametrize("family", ["cvs", "challenge", "proc", "proc_dopri5"])
 def test_training_entry_points_run(family):
     import importlib
+    solver = "dopri5" if family.endswith("_dopri5") else "rk4"     # proc_dopri5: BASELINE config[2]'s solver, trained end to end
+    family = family.split("_")[0]
     tc = importlib.import_module("training_" + family)
     cfg = tc.load_config()
     cfg.num_epochs, cfg.mini_batch_size = 2, 48
     if family == "proc":
-        cfg.solver = "rk4"
+        cfg.solver = solver
     var_model, best_model, best_epoch = tc.train(cfg, batches_per_epoch=3)
     assert 0 <= best_epoch <= 2
     assert all(torch.isfinite(p).all() for p in var_model.parameters())

@@ -287,10 +287,72 @@ def test_dopri5_forward_solution_level(fam):
     assert err_gpu < 3.0 * err_ref + 1e-5, (err_gpu, err_ref)
     assert err_gpu < 1e-3
     assert torch.equal(x[:, 0].cpu(), O.initialize_state(p, z)) or ((x[:, 0].cpu() - O.initialize_state(p, z)).abs().max() < 2e-6)
-    # gradients through the adaptive solver are not provided: the ABI says so loudly
+    # gradients through the adaptive solver come with the ELBO step (test_dopri5_elbo_step_solution_level); the stand-alone
+    # solve-backward entry point is fixed-grid only and says so loudly
     from structured_latent_odes_amd._lib import SlodeError
     with pytest.raises(SlodeError):
         eng.ode_solve_bwd(eng.pack(p), z.to(dev), torch.zeros(B, T, S, device=dev), torch.zeros(eng.n_params, device=dev))
+
+
+@pytest.mark.parametrize("fam,mode", [("cvs", "exact"), ("proc", "exact"), ("cvs", "reference_adjoint")])
+def test_dopri5_elbo_step_solution_level(fam, mode):
+    """ELBO step with the adaptive solver (BASELINE config[2]): forward solve with recorded steps, reverse mode over the records.
+    Parity is at solution level (see test_dopri5_forward_solution_level): -ELBO and every gradient against the fp64 oracle run at tight
+    tolerances -- `exact`: autograd through the oracle's per-trajectory dopri5; `reference_adjoint`: the same with the latent detached
+    inside the dynamics (oracle solve_ode).  Tolerances: -ELBO 2e-5 relative; gradients: see the bar below."""
+    from structured_latent_odes_amd import engine as E
+    dev = torch.device("cuda:0")
+    kw = dict(z_g=3, z_eps=2) if fam == "proc" else dict(z_iext=3, z_rtpr=3, z_eps=2)
+    S, T, B = (8, 100, 70) if fam == "proc" else (5, 60, 70)       # two 64-lane workgroups, ragged tail
+    mk_o, mk_e = (O.proc_spec, E.proc_spec) if fam == "proc" else (O.cvs_spec, E.cvs_spec)
+    ospec = mk_o(solver="dopri5", **kw)
+    ospec.solver_kw = dict(rtol=1e-8, atol=1e-10, per_trajectory=True)
+    espec = mk_e(solver="dopri5", **kw)
+    espec.rtol, espec.atol, espec.grad_mode = 1e-6, 1e-8, mode
+    p = O.init_params(ospec, T=T, S=S)
+    g = torch.Generator().manual_seed(31)
+    p = {k: v + 0.05 * torch.randn(v.shape, generator=g) for k, v in p.items()}
+    obs, u, eps, times = O.synthetic_batch(ospec, B, T)
+    if fam == "cvs":
+        times = times * 0.25
+    eng = E.Engine(espec, T, dev)
+    eng.set_times(times)
+    flat = eng.pack(p)
+    obs_d = obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)
+    loss = torch.zeros(1, device=dev)
+    grads = torch.full((eng.n_params,), float("nan"), device=dev)
+    x = torch.empty(B, T, S, device=dev)
+    eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss, grads=grads, x_out=x)
+    assert torch.isfinite(loss).all() and torch.isfinite(grads).all()
+    p64 = {k: v.double() for k, v in p.items()}
+    ospec.grad_mode = mode
+    q = {k: v.clone().requires_grad_(True) for k, v in p64.items()}
+    want_loss, parts = O.main_loss(q, ospec, obs.double(), u.double(), eps.double(), times.double(), return_parts=True)
+    want_loss.backward()
+    want = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in q.items()}
+    want_loss, tight = want_loss.detach(), parts["dec"][0].detach()
+    assert abs(loss.item() - want_loss.item()) / abs(want_loss.item()) < 2e-5, (loss.item(), want_loss.item())
+    got = eng.unpack(grads)
+    # Bar per tensor: 5e-4 (the fixed-grid bar) + 3x the oracle's own sensitivity to the step sequence -- its gradient at the engine's
+    # tolerances (fp64) against the tight one.  The solver controls the error of the SOLUTION; gradients that integrate relu'(.) of
+    # the hidden layer over time (dynamics_hidden, and through z the encoder) see an O(step) quadrature error at every kink and differ
+    # by ~1e-3 between any two adaptive step sequences, the rest by ~1e-5.
+    ospec.solver_kw = dict(rtol=1e-6, atol=1e-8, per_trajectory=True)
+    _, loose = O.loss_and_grads(p64, ospec, obs.double(), u.double(), eps.double(), times.double())
+    bad = {k: (_rel(v, want[k]), _rel(loose[k], want[k])) for k, v in got.items() if _rel(v, want[k]) > 5e-4 + 3.0 * _rel(loose[k], want[k])}
+    assert not bad, bad
+    assert all(_rel(v, want[k]) < 1e-2 for k, v in got.items())
+    # the trajectories handed back are the adaptive solver's
+    err_x = ((x.cpu().double() - tight).abs() / tight.abs().clamp_min(1.0)).max().item()
+    assert err_x < 1e-3, err_x                                    # same absolute bar as test_dopri5_forward_solution_level
+    # loss-only evaluation (SVI.evaluate_loss) scores the same solution
+    loss2 = torch.zeros(1, device=dev)
+    eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss2, grads=None)
+    assert loss2.item() == loss.item()
+    # bitwise reproducible
+    grads2 = torch.zeros_like(grads)
+    eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss2, grads=grads2)
+    assert torch.equal(grads, grads2)
 
 
 @pytest.mark.parametrize("layout", ["c_major", "strided"])
@@ -419,7 +481,7 @@ def test_abi_error_paths():
     bad2 = eng.shape(B).__class__.from_buffer_copy(eng.shape(B))
     bad2.method = L.DOPRI5
     a = args(); a[1] = C.byref(bad2)
-    assert lib.slode_elbo_step(*a) == -1 and b"forward-only" in lib.slode_last_error(h)
+    assert lib.slode_elbo_step(*a) == -3 and b"workspace" in lib.slode_last_error(h)   # dopri5 training needs its record workspace
     assert lib.slode_adam_step(h, 10, p(flat), p(grads), p(flat), p(flat), 1e-3, 0.9, 0.999, 1e-8, 0, None) == -1   # step < 1
     assert lib.slode_elbo_step(*args()) == 0 and torch.isfinite(loss).all()      # the handle stays usable after errors
 

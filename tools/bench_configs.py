@@ -12,9 +12,13 @@ dev = torch.device("cuda:0")
 CASES = [("config[0] cvs B=32 T=100 L=4 rk4", "cvs", False, 32, 100, dict(z_iext_dim=1, z_rtpr_dim=1, z_epsilon_dim=2, solver="rk4")),
          ("config[1] cvs B=1024 T=200 L=8 rk4", "cvs", False, 1024, 200, dict(z_iext_dim=3, z_rtpr_dim=3, z_epsilon_dim=2, solver="rk4")),
          ("config[2] proc B=4096 T=100 L=50 S=8 rk4 (fixed-grid stand-in for dopri5)", "proc", False, 4096, 100, dict(solver="rk4")),
+         ("config[2] proc B=4096 T=100 L=50 S=8 dopri5 (rtol 1e-7, atol 1e-9: torchdiffeq defaults)", "proc", False, 4096, 100, dict(solver="dopri5")),
          ("config[4] challenge-Gauss B=512 T=300 L=15 rk4", "challenge", True, 512, 300, dict(solver="rk4")),
          ("reference default cvs B=128 T=86 L=15 midpoint", "cvs", False, 128, 86, dict())]
+only = sys.argv[1] if len(sys.argv) > 1 else ""      # substring filter on the case name
 for name, fam, gauss, B, T, kw in CASES:
+    if only not in name:
+        continue
     set_seed(12)
     cfg = getattr(CF, "load_config_" + fam)(); cfg.update(seq_len=T, **kw)
     mod = importlib.import_module("structured_latent_odes_amd.models.mechanistic_%s%s" % (fam, "_Gauss" if gauss else ""))

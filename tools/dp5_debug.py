@@ -1,0 +1,32 @@
+"""Debug aid: dopri5 ELBO step vs the oracle, per-tensor errors and timings."""
+import sys, time, torch
+sys.path.insert(0, ".")
+from oracle import slode_oracle as O
+from structured_latent_odes_amd import engine as E
+fam, mode = sys.argv[1], sys.argv[2]
+dev = torch.device("cuda:0")
+kw = dict(z_g=3, z_eps=2) if fam == "proc" else dict(z_iext=3, z_rtpr=3, z_eps=2)
+S, T, B = (8, 100, 70) if fam == "proc" else (5, 60, 70)
+mk_o, mk_e = (O.proc_spec, E.proc_spec) if fam == "proc" else (O.cvs_spec, E.cvs_spec)
+ospec = mk_o(solver="dopri5", **kw); ospec.solver_kw = dict(rtol=1e-8, atol=1e-10, per_trajectory=True); ospec.grad_mode = mode
+espec = mk_e(solver="dopri5", **kw); espec.rtol, espec.atol, espec.grad_mode = 1e-6, 1e-8, mode
+p = O.init_params(ospec, T=T, S=S)
+g = torch.Generator().manual_seed(31)
+p = {k: v + 0.05 * torch.randn(v.shape, generator=g) for k, v in p.items()}
+obs, u, eps, times = O.synthetic_batch(ospec, B, T)
+if fam == "cvs": times = times * 0.25
+eng = E.Engine(espec, T, dev); eng.set_times(times); flat = eng.pack(p)
+obs_d = obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)
+loss = torch.zeros(1, device=dev); grads = torch.full((eng.n_params,), float("nan"), device=dev)
+for i in range(3):
+    torch.cuda.synchronize(); t0 = time.time()
+    eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss, grads=grads)
+    torch.cuda.synchronize(); print("step %d: %.3f ms" % (i, 1e3 * (time.time() - t0)), flush=True)
+p64 = {k: v.double() for k, v in p.items()}
+t0 = time.time()
+wl, want = O.loss_and_grads(p64, ospec, obs.double(), u.double(), eps.double(), times.double())
+print("oracle %.1f s; loss %.6f vs %.6f" % (time.time() - t0, loss.item(), wl.item()))
+got = eng.unpack(grads)
+for k, v in got.items():
+    a, b = v.double().cpu(), want[k]
+    print("%-60s rel %.2e  |got| %.3e |want| %.3e" % (k, ((a - b).norm() / b.norm().clamp_min(1e-30)).item(), a.norm().item(), b.norm().item()))
