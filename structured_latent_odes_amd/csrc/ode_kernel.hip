@@ -770,6 +770,8 @@ ode_elbo_kernel(const OdeK k) {
       const float* gi = k.gx_in + (long long)b * T * S;
       for (int i = tid; i < T * S; i += NT) s_lam[i] = gi[i];
     }
+    // scorer pass 1 of dopri5 training only produces dLoss/dx: the workgroup is done (uniform exit; pass 2 rewrites every other output)
+    if (BWD && ONE && T_ == 0 && k.gx_out) return;
 
     if (BWD) {
       if (RA) {

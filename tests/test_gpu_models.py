@@ -231,7 +231,7 @@ def test_recon_samples_is_one_batched_launch_of_recon(tmp_path):
 
 
 def test_training_on_reference_format_files(tmp_path):
-    """SURVEY row N3 end to end: cvs / challenge files in the reference's on-disk formats -> data.py readers, transforms, splits ->
+    """SURVEY row N3 end to end: cvs / challenge / proc files in the reference's on-disk formats -> data.py readers, transforms, splits ->
     pinned-buffer feeder -> the epoch loop (two SVI objects, one Adam)."""
     import pickle
     import training_cvs, training_challenge
@@ -261,6 +261,29 @@ def test_training_on_reference_format_files(tmp_path):
     trb, vab, _ = TR.real_batches(cfg, "challenge", d)
     assert len(trb) == 2 and len(vab) == 1                       # 28 / 7 by the seeded 5-fold split
     vm, bm, be = training_challenge.train(cfg, train_batches=trb, val_batches=vab)
+    assert all(torch.isfinite(p).all() for p in vm.parameters())
+    # proc: plate-reader CSVs -> cassettes / inputs labels, the data's own (non-uniform) time grid
+    import csv
+    import training_proc
+    devs = ["Pcat_Y81C76", "RS100S32_Y81C76", "RS100S34_Y81C76", "R33S32_Y81C76", "R33S34_Y81C76", "R33S175_Y81C76"]
+    T = 40
+    tgrid = np.cumsum(rng.uniform(0.1, 0.3, T))
+    sigs = ["EYFP", "ECFP", "mRFP1", "OD"]
+    with open(d + "proc140916.csv", "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Content", "Colony", "Well Col", "Well Row", "Content"] + ["Raw Data (%s) %d - x" % (sg, k + 1) for sg in sigs for k in range(T)])
+        w.writerow(["", "", "", "", ""] + [float(t) for _ in sigs for t in tgrid])
+        for i in range(40):
+            cond = ("C6=%g" % rng.choice([0.0, 1.5, 250.0])) if i % 2 else ("C12=%g" % rng.choice([0.0, 3.8, 2777.0]))
+            curve = [float(50 + 10 * si + 30 * (1 - np.exp(-t)) + rng.normal() * 0.5) for si in range(4) for t in tgrid]
+            w.writerow([devs[i % 6], "", str(i % 12 + 1), "A", cond] + curve)
+    cfg = training_proc.load_config()
+    cfg.num_epochs, cfg.mini_batch_size, cfg.solver = 1, 12, "rk4"
+    trb, vab, times = TR.real_batches(cfg, "proc", d)
+    assert cfg.seq_len == T and times.shape == (T,) and len(trb) == 3 and len(vab) == 1      # 30 / 10 by the seeded 4-fold split
+    b0 = next(iter(trb))
+    assert b0["observations"].shape == (12, 4, T) and b0["aR"].shape == (12, 3) and b0["aS"].shape == (12, 4) and b0["C6"].shape == (12, 1)
+    vm, bm, be = training_proc.train(cfg, train_batches=trb, val_batches=vab, times=times)
     assert all(torch.isfinite(p).all() for p in vm.parameters())
 
 
@@ -311,27 +334,3 @@ def test_two_svi_objects_share_adam_with_per_parameter_step_counts():
     for k, v in p.items():
         err = (got[k].double() - v).abs().max().item()
         assert err < 3e-6, (k, err)
-    # proc: plate-reader CSVs -> cassettes / inputs labels, the data's own (non-uniform) time grid
-    import csv
-    import training_proc
-    devs = ["Pcat_Y81C76", "RS100S32_Y81C76", "RS100S34_Y81C76", "R33S32_Y81C76", "R33S34_Y81C76", "R33S175_Y81C76"]
-    T = 40
-    tgrid = np.cumsum(rng.uniform(0.1, 0.3, T))
-    sigs = ["EYFP", "ECFP", "mRFP1", "OD"]
-    with open(d + "proc140916.csv", "w", newline="") as fh:
-        w = csv.writer(fh)
-        w.writerow(["Content", "Colony", "Well Col", "Well Row", "Content"] + ["Raw Data (%s) %d - x" % (sg, k + 1) for sg in sigs for k in range(T)])
-        w.writerow(["", "", "", "", ""] + [float(t) for _ in sigs for t in tgrid])
-        for i in range(40):
-            cond = ("C6=%g" % rng.choice([0.0, 1.5, 250.0])) if i % 2 else ("C12=%g" % rng.choice([0.0, 3.8, 2777.0]))
-            curve = [float(50 + 10 * si + 30 * (1 - np.exp(-t)) + rng.normal() * 0.5) for si in range(4) for t in tgrid]
-            w.writerow([devs[i % 6], "", str(i % 12 + 1), "A", cond] + curve)
-    cfg = training_proc.load_config()
-    cfg.num_epochs, cfg.mini_batch_size, cfg.solver = 1, 12, "rk4"
-    trb, vab, times = TR.real_batches(cfg, "proc", d)
-    assert cfg.seq_len == T and times.shape == (T,) and len(trb) == 3 and len(vab) == 1      # 30 / 10 by the seeded 4-fold split
-    b0 = next(iter(trb))
-    assert b0["observations"].shape == (12, 4, T) and b0["aR"].shape == (12, 3) and b0["aS"].shape == (12, 4) and b0["C6"].shape == (12, 1)
-    vm, bm, be = training_proc.train(cfg, train_batches=trb, val_batches=vab, times=times)
-    assert all(torch.isfinite(p).all() for p in vm.parameters())
-
