@@ -3,22 +3,33 @@
 //
 // torchdiffeq's controller uses ONE step size for the whole [B,S] tensor (its error norm is an RMS over the batch), which
 // makes results depend on batch composition and cannot shard.  Contract here (SURVEY hard part 3): one controller PER
-// TRAJECTORY -- lane = trajectory, every lane runs torchdiffeq's algorithm on its own state (FSAL, Hairer initial step,
-// ratio = rms(err / (atol + rtol*max(|y0|,|y1|))), factor clamp [0.2, 10] with safety 0.9, quartic dense output through
-// (y0, y_mid, y1, f0, f1)) -- validated at solution level against the oracle's per-trajectory restatement and scipy RK45.
-// The dynamics weights arrive as SGPR operands (uniform), the per-trajectory hidden offsets u = W_z z + b live in LDS.
+// TRAJECTORY, running torchdiffeq's algorithm on its own state (FSAL, Hairer initial step, ratio = rms(err / (atol +
+// rtol*max(|y0|,|y1|))), factor clamp [0.2, 10] with safety 0.9, quartic dense output through (y0, y_mid, y1, f0, f1)) --
+// validated at solution level against the oracle's per-trajectory restatement and scipy RK45.
+//
+// Mapping: EIGHT LANES PER TRAJECTORY (8 trajectories per wave).  An adaptive solve is one long dependent chain per trajectory,
+// so its latency -- not the FLOPs -- sets the kernel time; the chain is shortened by spreading the hidden layer over the group:
+// lane g owns hidden units {g, g+8, g+16, g+24} (weights in its registers) and state component g.  One evaluation of the
+// dynamics coefficients is 4 relu + 8*S partial FMAs per lane and a halving butterfly over the group (7 shuffles per 8-vector)
+// that leaves lane g with pre-activation g: one sigmoid pair per lane, and all the Runge-Kutta arithmetic is scalar per lane.
 //
 // Training with dopri5 (BASELINE config[2]): the forward kernel also records every accepted step (t, dt, y) and
 // `dopri5_bwd_kernel` walks a trajectory's record backwards -- the exact reverse mode of the accepted Dormand-Prince steps and of
-// the dense-output polynomial, step sizes held fixed (the controller is not differentiated), lane = trajectory.  The right-hand
-// side is linear in the state with coefficients that depend on time only, so a step's seven stages are re-evaluated from its
-// recorded (t, dt, y) instead of being stored.  Dynamics-weight gradients accumulate in per-lane LDS columns and leave the
-// workgroup as one slab row in the layout of the fixed-grid kernel's slabs (summed by the same deterministic tail).
+// the dense-output polynomial, step sizes held fixed (the controller is not differentiated), lane = trajectory (weights as SGPR
+// operands, hidden offsets u in LDS).  The right-hand side is linear in the state with coefficients that depend on time only, so a
+// step's seven stages are re-evaluated from its recorded (t, dt, y) instead of being stored.  All six evaluation times of a step are
+// folded into one pass over the hidden units: every per-lane accumulator column in LDS is read-modified-written once per step.
+// The workgroup's 64 columns are summed in a fixed order into one slab row in the layout of the fixed-grid kernel's slabs (reduced
+// by the same deterministic tail).  (A reverse sweep in the forward kernel's 8-lane mapping was 4x faster but computed the
+// hidden-layer bias gradient of units >= 16 about 1e-2 off -- cause not found -- and is not shipped.)
 #include "slode_common.h"
 
-typedef const __attribute__((address_space(4))) float* cptr;
-
 namespace {
+
+constexpr int G = 8;            // lanes per trajectory
+constexpr int DNT = 256;        // threads per workgroup
+constexpr int TPB = DNT / G;    // trajectories per workgroup
+constexpr int JL = 4;           // hidden units per lane (H <= 32)
 
 struct DpK {
   int B, T, L;
@@ -33,176 +44,205 @@ struct DpK {
   int max_steps;
 };
 
-constexpr int DPW = 64;  // lanes (= trajectories) per workgroup
-
-template <int S, int H>
-__device__ __forceinline__ void dyn(float t, const float* __restrict__ s_wt, const float* __restrict__ s_ul, cptr wg, cptr bg, cptr wd,
-                                    cptr bd, const float (&y)[S], float (&f)[S]) {
-  asm volatile("" : "+s"(wg), "+s"(wd), "+s"(bg), "+s"(bd));
-  float h[H];
+// reduce-scatter over the 8 lanes of a trajectory: lane g returns the group's sum of v[g] (halving butterfly, 4 + 2 + 1 shuffles)
+__device__ __forceinline__ float group_scatter8(float (&v)[8], int g) {
+  {
+    const bool hi = (g & 4) != 0;
 #pragma unroll
-  for (int j = 0; j < H; ++j) h[j] = fmaxf(fmaf(s_wt[j], t, s_ul[j * DPW]), 0.f);
-#pragma unroll
-  for (int s = 0; s < S; ++s) {
-    float xa = bg[s], xd = bd[s];
-#pragma unroll
-    for (int j = 0; j < H; ++j) {
-      xa = fmaf(wg[s * H + j], h[j], xa);
-      xd = fmaf(wd[s * H + j], h[j], xd);
+    for (int i = 0; i < 4; ++i) {
+      const float keep = hi ? v[i + 4] : v[i], send = hi ? v[i] : v[i + 4];
+      v[i] = keep + __shfl_xor(send, 4, 64);
     }
-    f[s] = sigmoidf_fast(xa) - sigmoidf_fast(xd) * y[s];
   }
+  {
+    const bool hi = (g & 2) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float keep = hi ? v[i + 2] : v[i], send = hi ? v[i] : v[i + 2];
+      v[i] = keep + __shfl_xor(send, 2, 64);
+    }
+  }
+  const bool hi = (g & 1) != 0;
+  const float keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1];
+  return keep + __shfl_xor(send, 1, 64);
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  return v;
+}
+
+// a lane's share of the dynamics net: its hidden units (time weight, offset u = W_z z + b, rows of the two heads) and the head
+// biases of its state component
+template <int S>
+struct Unit {
+  float wt[JL], u[JL], wg[JL][S], wd[JL][S];
+  float bg, bd;
+};
+
+// growth / degradation coefficient of this lane's state component at time t: a = sigmoid(Wg h + bg), d = sigmoid(Wd h + bd),
+// h = relu(wt t + u)   (blackbox_ode.py:97-109)
+template <int S>
+__device__ __forceinline__ void eval_ad(float t, const Unit<S>& w, int g, bool own, float& a, float& d) {
+  float xa[8], xd[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) xa[s] = xd[s] = 0.f;
+#pragma unroll
+  for (int i = 0; i < JL; ++i) {
+    const float h = fmaxf(fmaf(w.wt[i], t, w.u[i]), 0.f);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      xa[s] = fmaf(w.wg[i][s], h, xa[s]);
+      xd[s] = fmaf(w.wd[i][s], h, xd[s]);
+    }
+  }
+  const float pa = group_scatter8(xa, g) + w.bg, pd = group_scatter8(xd, g) + w.bd;
+  a = own ? sigmoidf_fast(pa) : 0.f;
+  d = own ? sigmoidf_fast(pd) : 0.f;
+}
+
+// latent sample of the workgroup's trajectories -> LDS; this lane's units; returns the init-net hidden values of its units
+template <int S, int H>
+__device__ __forceinline__ void load_units(const float* wh, const float* bh, const float* wg, const float* bg, const float* wd, const float* bd,
+                                           const float* w1, const float* b1, const float* zrow, int L, int g, bool own, Unit<S>& w,
+                                           float (&pre0)[JL]) {
+#pragma unroll
+  for (int i = 0; i < JL; ++i) {
+    const int j = g + G * i;
+    const bool valid = j < H;
+    const int jj = valid ? j : 0;
+    float uj = bh[jj], pj = b1[jj];
+    for (int l = 0; l < L; ++l) {
+      const float zl = zrow[l];
+      uj = fmaf(wh[jj * (1 + L) + 1 + l], zl, uj);
+      pj = fmaf(w1[jj * L + l], zl, pj);
+    }
+    w.wt[i] = valid ? wh[jj * (1 + L)] : 0.f;
+    w.u[i] = valid ? uj : 0.f;
+    pre0[i] = valid ? pj : 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      w.wg[i][s] = valid ? wg[s * H + jj] : 0.f;
+      w.wd[i][s] = valid ? wd[s * H + jj] : 0.f;
+    }
+  }
+  w.bg = own ? bg[g] : 0.f;
+  w.bd = own ? bd[g] : 0.f;
+}
+
+// x0 = sigmoid(W2 relu(W1 z + b1) + b2), this lane's component (blackbox_ode.py:19-22)
+template <int S, int H>
+__device__ __forceinline__ float init_state(const float* w2, const float* b2, const float (&pre0)[JL], int g, bool own) {
+  float o[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) o[s] = 0.f;
+#pragma unroll
+  for (int i = 0; i < JL; ++i) {
+    const int j = g + G * i, jj = j < H ? j : 0;
+    const float hp = j < H ? fmaxf(pre0[i], 0.f) : 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) o[s] = fmaf(w2[s * H + jj], hp, o[s]);
+  }
+  const float v = group_scatter8(o, g);
+  return own ? sigmoidf_fast(v + b2[g]) : 0.f;
 }
 
 template <int S>
-__device__ __forceinline__ float rms(const float (&v)[S]) {
-  float a = 0.f;
-#pragma unroll
-  for (int s = 0; s < S; ++s) a = fmaf(v[s], v[s], a);
-  return sqrtf(a * (1.0f / S));
-}
+__device__ __forceinline__ float group_rms(float v, bool own) { return sqrtf(group_sum(own ? v * v : 0.f) * (1.0f / S)); }
 
 template <int S, int H>
-__global__ void __launch_bounds__(DPW) dopri5_kernel(const DpK k) {
+__global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
+  static_assert(S <= G && H <= G * JL, "one state component and JL hidden units per lane");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_wt = smem;                 // [32] time column of dynamics_hidden
-  float* s_u = s_wt + 32;             // [H][DPW] per-trajectory hidden offsets
-  float* s_z = s_u + H * DPW;         // [L][DPW]
-  const int lane = threadIdx.x, b = blockIdx.x * DPW + lane, L = k.L, T = k.T;
-  const bool live = b < k.B;
-  const cptr wg = (cptr)k.wg, bg = (cptr)k.bg, wd = (cptr)k.wd, bd = (cptr)k.bd;
-  if (lane < 32) s_wt[lane] = lane < H ? k.wh[lane * (1 + L)] : 0.f;
-  for (int l = 0; l < L; ++l) {
-    const long long i = (long long)(live ? b : 0) * L + l;
+  float* s_z = smem;                  // [TPB][L]
+  const int tid = threadIdx.x, g = tid & (G - 1), slot = tid >> 3, b = blockIdx.x * TPB + slot, L = k.L, T = k.T;
+  const bool live = b < k.B, own = g < S;
+  const long long bb = live ? b : 0;
+  for (int l = g; l < L; l += G) {
+    const long long i = bb * L + l;
     float zl = 0.f;
     if (live) {
       zl = k.z ? k.z[i] : fmaf(k.scale[i], k.eps[i], k.loc[i]);
       if (k.z_out) k.z_out[i] = zl;
     }
-    s_z[l * DPW + lane] = zl;
+    s_z[slot * L + l] = zl;
   }
   __syncthreads();
-  // u = W_z z + b_h ; x0 = sigmoid(W2 relu(W1 z + b1) + b2)   (blackbox_ode.py:19-22, 97-101)
-  float y[S];
-  {
-    const cptr wh = (cptr)k.wh, bh = (cptr)k.bh, w1 = (cptr)k.w1, b1 = (cptr)k.b1, w2 = (cptr)k.w2, b2 = (cptr)k.b2;
-    float o[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) o[s] = b2[s];
-    for (int j = 0; j < H; ++j) {
-      float uj = bh[j], p0 = b1[j];
-      for (int l = 0; l < L; ++l) {
-        const float zl = s_z[l * DPW + lane];
-        uj = fmaf(wh[j * (1 + L) + 1 + l], zl, uj);
-        p0 = fmaf(w1[j * L + l], zl, p0);
-      }
-      s_u[j * DPW + lane] = uj;
-      const float hj = fmaxf(p0, 0.f);
-#pragma unroll
-      for (int s = 0; s < S; ++s) o[s] = fmaf(w2[s * H + j], hj, o[s]);
-    }
-#pragma unroll
-    for (int s = 0; s < S; ++s) y[s] = sigmoidf_fast(o[s]);
-  }
-  const float* s_ul = s_u + lane;
-  float* xo = k.x + (long long)(live ? b : 0) * T * S;
-  if (live) {
-#pragma unroll
-    for (int s = 0; s < S; ++s) xo[s] = y[s];
-  }
+  Unit<S> w;
+  float pre0[JL];
+  load_units<S, H>(k.wh, k.bh, k.wg, k.bg, k.wd, k.bd, k.w1, k.b1, s_z + slot * L, L, g, own, w, pre0);
+  float y = init_state<S, H>(k.w2, k.b2, pre0, g, own);
+  const int gs = own ? g : 0;
+  float* xo = k.x + bb * T * S;
+  if (live && own) xo[gs] = y;
   const float rtol = k.rtol, atol = k.atol;
   float t = k.times[0];
-  float fcur[S];
-  dyn<S, H>(t, s_wt, s_ul, wg, bg, wd, bd, y, fcur);
+  float a, d;
+  eval_ad<S>(t, w, g, own, a, d);
+  float fcur = a - d * y;
   // Hairer's initial step (torchdiffeq _select_initial_step, order 4)
   float dt;
   {
-    float a0[S], a1[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) { const float sc = atol + fabsf(y[s]) * rtol; a0[s] = y[s] / sc; a1[s] = fcur[s] / sc; }
-    const float d0 = rms<S>(a0), d1 = rms<S>(a1);
+    const float sc = atol + fabsf(y) * rtol;
+    const float d0 = group_rms<S>(y / sc, own), d1 = group_rms<S>(fcur / sc, own);
     const float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
-    float y1[S], f1[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) y1[s] = fmaf(h0, fcur[s], y[s]);
-    dyn<S, H>(t + h0, s_wt, s_ul, wg, bg, wd, bd, y1, f1);
-#pragma unroll
-    for (int s = 0; s < S; ++s) a0[s] = (f1[s] - fcur[s]) / (atol + fabsf(y[s]) * rtol);
-    const float d2 = rms<S>(a0) / h0;
+    const float y1 = fmaf(h0, fcur, y);
+    eval_ad<S>(t + h0, w, g, own, a, d);
+    const float f1 = a - d * y1;
+    const float d2 = group_rms<S>((f1 - fcur) / sc, own) / h0;
     const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
     dt = fminf(100.f * h0, h1);
   }
   int j = 1;
   int steps = 0, nacc = 0;
-  // every lane leaves the loop: either all outputs written or max_steps reached (outputs then hold the last state)
+  // every lane leaves the loop: either all outputs written or max_steps reached (outputs then hold the last state).  The shuffles
+  // inside eval_ad / group_rms sit at the top level of the loop body: all 64 lanes execute them.
   while (__any(live && j < T && steps < k.max_steps)) {
     const bool act = live && j < T && steps < k.max_steps;
     ++steps;
-    float k2[S], k3[S], k4[S], k5[S], k6[S], k7[S], yi[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) yi[s] = fmaf(dt, (1.f / 5) * fcur[s], y[s]);
-    dyn<S, H>(t + dt * (1.f / 5), s_wt, s_ul, wg, bg, wd, bd, yi, k2);
-#pragma unroll
-    for (int s = 0; s < S; ++s) yi[s] = fmaf(dt, (3.f / 40) * fcur[s] + (9.f / 40) * k2[s], y[s]);
-    dyn<S, H>(t + dt * (3.f / 10), s_wt, s_ul, wg, bg, wd, bd, yi, k3);
-#pragma unroll
-    for (int s = 0; s < S; ++s) yi[s] = fmaf(dt, (44.f / 45) * fcur[s] + (-56.f / 15) * k2[s] + (32.f / 9) * k3[s], y[s]);
-    dyn<S, H>(t + dt * (4.f / 5), s_wt, s_ul, wg, bg, wd, bd, yi, k4);
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-      yi[s] = fmaf(dt, (19372.f / 6561) * fcur[s] + (-25360.f / 2187) * k2[s] + (64448.f / 6561) * k3[s] + (-212.f / 729) * k4[s], y[s]);
-    dyn<S, H>(t + dt * (8.f / 9), s_wt, s_ul, wg, bg, wd, bd, yi, k5);
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-      yi[s] = fmaf(dt, (9017.f / 3168) * fcur[s] + (-355.f / 33) * k2[s] + (46732.f / 5247) * k3[s] + (49.f / 176) * k4[s] + (-5103.f / 18656) * k5[s], y[s]);
-    dyn<S, H>(t + dt, s_wt, s_ul, wg, bg, wd, bd, yi, k6);
-    float y1[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-      y1[s] = fmaf(dt, (35.f / 384) * fcur[s] + (500.f / 1113) * k3[s] + (125.f / 192) * k4[s] + (-2187.f / 6784) * k5[s] + (11.f / 84) * k6[s], y[s]);
-    dyn<S, H>(t + dt, s_wt, s_ul, wg, bg, wd, bd, y1, k7);
-    float er[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const float e = dt * ((35.f / 384 - 1951.f / 21600) * fcur[s] + (500.f / 1113 - 22642.f / 50085) * k3[s] + (125.f / 192 - 451.f / 720) * k4[s] +
-                            (-2187.f / 6784 + 12231.f / 42400) * k5[s] + (11.f / 84 - 649.f / 6300) * k6[s] + (-1.f / 60) * k7[s]);
-      er[s] = e / (atol + rtol * fmaxf(fabsf(y[s]), fabsf(y1[s])));
-    }
-    const float ratio = rms<S>(er);
+    eval_ad<S>(t + dt * (1.f / 5), w, g, own, a, d);
+    const float k2 = a - d * fmaf(dt, (1.f / 5) * fcur, y);
+    eval_ad<S>(t + dt * (3.f / 10), w, g, own, a, d);
+    const float k3 = a - d * fmaf(dt, (3.f / 40) * fcur + (9.f / 40) * k2, y);
+    eval_ad<S>(t + dt * (4.f / 5), w, g, own, a, d);
+    const float k4 = a - d * fmaf(dt, (44.f / 45) * fcur + (-56.f / 15) * k2 + (32.f / 9) * k3, y);
+    eval_ad<S>(t + dt * (8.f / 9), w, g, own, a, d);
+    const float k5 = a - d * fmaf(dt, (19372.f / 6561) * fcur + (-25360.f / 2187) * k2 + (64448.f / 6561) * k3 + (-212.f / 729) * k4, y);
+    eval_ad<S>(t + dt, w, g, own, a, d);   // stages 6 and 7 share t + dt
+    const float k6 = a - d * fmaf(dt, (9017.f / 3168) * fcur + (-355.f / 33) * k2 + (46732.f / 5247) * k3 + (49.f / 176) * k4 + (-5103.f / 18656) * k5, y);
+    const float y1 = fmaf(dt, (35.f / 384) * fcur + (500.f / 1113) * k3 + (125.f / 192) * k4 + (-2187.f / 6784) * k5 + (11.f / 84) * k6, y);
+    const float k7 = a - d * y1;
+    const float e = dt * ((35.f / 384 - 1951.f / 21600) * fcur + (500.f / 1113 - 22642.f / 50085) * k3 + (125.f / 192 - 451.f / 720) * k4 +
+                          (-2187.f / 6784 + 12231.f / 42400) * k5 + (11.f / 84 - 649.f / 6300) * k6 + (-1.f / 60) * k7);
+    const float ratio = group_rms<S>(e / (atol + rtol * fmaxf(fabsf(y), fabsf(y1))), own);
     // a step at the resolution floor of fp32 time is accepted regardless (torchdiffeq would raise 'underflow in dt')
     const bool accept = act && (ratio <= 1.f || dt <= 16.f * 1.1920929e-7f * fmaxf(fabsf(t), 1.f));
     if (accept) {
       const float t1 = t + dt;
       if (k.rec && nacc < k.kmax) {
         float* r = k.rec + ((long long)nacc * k.B + b) * (S + 2);
-        r[0] = t; r[1] = dt;
-#pragma unroll
-        for (int s = 0; s < S; ++s) r[2 + s] = y[s];
+        if (g == 0) { r[0] = t; r[1] = dt; }
+        if (own) r[2 + gs] = y;
       }
       ++nacc;
       if (j < T && k.times[j] <= t1) {
-        float ymid[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-          ymid[s] = fmaf(dt, (6025192743.f / 30085553152.f / 2) * fcur[s] + (51252292925.f / 65400821598.f / 2) * k3[s] +
-                                 (-2691868925.f / 45128329728.f / 2) * k4[s] + (187940372067.f / 1594534317056.f / 2) * k5[s] +
-                                 (-1776094331.f / 19743644256.f / 2) * k6[s] + (11237099.f / 235043384.f / 2) * k7[s], y[s]);
+        const float ymid = fmaf(dt, (6025192743.f / 30085553152.f / 2) * fcur + (51252292925.f / 65400821598.f / 2) * k3 +
+                                        (-2691868925.f / 45128329728.f / 2) * k4 + (187940372067.f / 1594534317056.f / 2) * k5 +
+                                        (-1776094331.f / 19743644256.f / 2) * k6 + (11237099.f / 235043384.f / 2) * k7, y);
+        const float ca = 2.f * dt * (k7 - fcur) - 8.f * (y1 + y) + 16.f * ymid;
+        const float cb = dt * (5.f * fcur - 3.f * k7) + 18.f * y + 14.f * y1 - 32.f * ymid;
+        const float cc = dt * (k7 - 4.f * fcur) - 11.f * y - 5.f * y1 + 16.f * ymid;
+        const float cd = dt * fcur;
         while (j < T && k.times[j] <= t1) {
           const float xq = (k.times[j] - t) / dt;
-#pragma unroll
-          for (int s = 0; s < S; ++s) {
-            const float ca = 2.f * dt * (k7[s] - fcur[s]) - 8.f * (y1[s] + y[s]) + 16.f * ymid[s];
-            const float cb = dt * (5.f * fcur[s] - 3.f * k7[s]) + 18.f * y[s] + 14.f * y1[s] - 32.f * ymid[s];
-            const float cc = dt * (k7[s] - 4.f * fcur[s]) - 11.f * y[s] - 5.f * y1[s] + 16.f * ymid[s];
-            const float cd = dt * fcur[s];
-            xo[j * S + s] = y[s] + xq * (cd + xq * (cc + xq * (cb + xq * ca)));
-          }
+          if (own) xo[j * S + gs] = y + xq * (cd + xq * (cc + xq * (cb + xq * ca)));
           ++j;
         }
       }
       t = t1;
-#pragma unroll
-      for (int s = 0; s < S; ++s) { y[s] = y1[s]; fcur[s] = k7[s]; }
+      y = y1;
+      fcur = k7;
     }
     if (act) {
       float factor;
@@ -215,11 +255,10 @@ __global__ void __launch_bounds__(DPW) dopri5_kernel(const DpK k) {
     }
   }
   if (live) {
-    if (k.nrec) k.nrec[b] = (j < T) ? -1 : nacc;
+    if (k.nrec && g == 0) k.nrec[b] = (j < T) ? -1 : nacc;
     // max_steps exhausted: fill the remaining outputs with the last state (finite; the training path turns nrec < 0 into a NaN loss)
     for (; j < T; ++j)
-#pragma unroll
-      for (int s = 0; s < S; ++s) xo[j * S + s] = y[s];
+      if (own) xo[j * S + gs] = y;
   }
 }
 
@@ -233,6 +272,10 @@ struct DpBK {
   int slab_stride, nseg;
   int o_w1, o_b1, o_w2, o_b2, o_wh, o_bh, o_wg, o_bg, o_wd, o_bd;
 };
+
+namespace lane64 {
+typedef const __attribute__((address_space(4))) float* cptr;
+constexpr int DPW = 64;  // lanes (= trajectories) per workgroup
 
 // growth / degradation coefficients at time t: a = sigmoid(Wg h + bg), d = sigmoid(Wd h + bd), h = relu(wt t + u)
 template <int S, int H>
@@ -556,7 +599,11 @@ __global__ void __launch_bounds__(DPW) dopri5_bwd_kernel(const DpBK k) {
   }
 }
 
+}  // namespace lane64
+
 }  // namespace
+
+int slode_dopri5_rows(const slode_shape& s) { return (s.B + 63) / 64; }   // slab rows of the reverse sweep: one per workgroup of 64 trajectories
 
 int slode_dopri5_kmax(const slode_shape& s) {
   // record capacity per trajectory: 256 MB of (t, dt, y) records, within [64, 2048] steps
@@ -575,10 +622,10 @@ hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, co
   k.rtol = s.rtol > 0.f ? s.rtol : 1e-7f;
   k.atol = s.atol > 0.f ? s.atol : 1e-9f;
   k.max_steps = 20000;
-  const int grid = (s.B + DPW - 1) / DPW;
-  const size_t lds = sizeof(float) * (32 + (size_t)s.H * DPW + (size_t)s.L * DPW);
-  if (s.H == 25 && s.S == 5) hipLaunchKernelGGL((dopri5_kernel<5, 25>), dim3(grid), dim3(DPW), lds, stream, k);
-  else if (s.H == 25 && s.S == 8) hipLaunchKernelGGL((dopri5_kernel<8, 25>), dim3(grid), dim3(DPW), lds, stream, k);
+  const int grid = (s.B + TPB - 1) / TPB;
+  const size_t lds = sizeof(float) * ((size_t)TPB * s.L);
+  if (s.H == 25 && s.S == 5) hipLaunchKernelGGL((dopri5_kernel<5, 25>), dim3(grid), dim3(DNT), lds, stream, k);
+  else if (s.H == 25 && s.S == 8) hipLaunchKernelGGL((dopri5_kernel<8, 25>), dim3(grid), dim3(DNT), lds, stream, k);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -595,15 +642,18 @@ hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay
   k.o_w1 = lay.init_w1 - ob; k.o_b1 = lay.init_b1 - ob; k.o_w2 = lay.init_w2 - ob; k.o_b2 = lay.init_b2 - ob;
   k.o_wh = lay.dyn_wh - ob; k.o_bh = lay.dyn_bh - ob; k.o_wg = lay.dyn_wg - ob; k.o_bg = lay.dyn_bg - ob;
   k.o_wd = lay.dyn_wd - ob; k.o_bd = lay.dyn_bd - ob;
-  const int grid = (s.B + DPW - 1) / DPW;
-  const size_t lds = sizeof(float) * (32 + (size_t)s.H * DPW + (size_t)s.L * DPW + (size_t)(2 * s.S * s.H + 2 * s.S + 2 * s.H) * DPW);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  if (s.H == 25 && s.S == 5) {
-    (void)hipFuncSetAttribute((const void*)dopri5_bwd_kernel<5, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((dopri5_bwd_kernel<5, 25>), dim3(grid), dim3(DPW), lds, stream, k);
-  } else if (s.H == 25 && s.S == 8) {
-    (void)hipFuncSetAttribute((const void*)dopri5_bwd_kernel<8, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((dopri5_bwd_kernel<8, 25>), dim3(grid), dim3(DPW), lds, stream, k);
-  } else return hipErrorInvalidValue;
+  {
+    using namespace lane64;
+    const int grid = slode_dopri5_rows(s);
+    const size_t lds = sizeof(float) * (32 + (size_t)s.H * DPW + (size_t)s.L * DPW + (size_t)(2 * s.S * s.H + 2 * s.S + 2 * s.H) * DPW);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (s.H == 25 && s.S == 5) {
+      (void)hipFuncSetAttribute((const void*)lane64::dopri5_bwd_kernel<5, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((lane64::dopri5_bwd_kernel<5, 25>), dim3(grid), dim3(DPW), lds, stream, k);
+    } else if (s.H == 25 && s.S == 8) {
+      (void)hipFuncSetAttribute((const void*)lane64::dopri5_bwd_kernel<8, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((lane64::dopri5_bwd_kernel<8, 25>), dim3(grid), dim3(DPW), lds, stream, k);
+    } else return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }

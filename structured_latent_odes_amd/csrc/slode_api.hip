@@ -210,7 +210,7 @@ static Workspace carve(slode_handle h, const slode_shape& s_in, const slode_layo
   Workspace w{};
   const slode_shape s = scorer_shape(s_in);
   const bool dp5 = s_in.method == SLODE_DOPRI5;
-  w.dp_rows = dp5 ? (s.B + 63) / 64 : 0;
+  w.dp_rows = dp5 ? slode_dopri5_rows(s) : 0;
   const int n_conv = s.T - s.K + 1, FQ = s.F * (n_conv - s.P + 1);
   w.ode_grid = ode_grid_for(h, s);
   w.ode_stride = (int)align_up((size_t)(lay.ode_end - lay.ode_begin) + 1);

@@ -351,6 +351,7 @@ hipError_t slode_launch_dynamics_eval(const slode_shape& s, const slode_layout& 
 // adaptive solve with step records (training): z = loc + scale * eps is formed in the kernel and written to z_out
 struct DopriRec { const float *loc, *scale, *eps; float* z_out; float* rec; int* nrec; int kmax; };
 int slode_dopri5_kmax(const slode_shape& s);
+int slode_dopri5_rows(const slode_shape& s);
 hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const float* z,
                                float* x, hipStream_t stream, const DopriRec* rec = nullptr);
 hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const DopriRec& rec,

@@ -1,4 +1,5 @@
-"""Debug aid: dopri5 ELBO step vs the oracle, per-tensor errors and timings."""
+"""Diagnostic: dopri5 ELBO step vs the fp64 oracle (`python tools/dp5_debug.py cvs|proc exact|reference_adjoint`): per-tensor
+gradient errors and step timings."""
 import sys, time, torch
 sys.path.insert(0, ".")
 from oracle import slode_oracle as O
@@ -7,6 +8,7 @@ fam, mode = sys.argv[1], sys.argv[2]
 dev = torch.device("cuda:0")
 kw = dict(z_g=3, z_eps=2) if fam == "proc" else dict(z_iext=3, z_rtpr=3, z_eps=2)
 S, T, B = (8, 100, 70) if fam == "proc" else (5, 60, 70)
+B = int(sys.argv[3]) if len(sys.argv) > 3 else B
 mk_o, mk_e = (O.proc_spec, E.proc_spec) if fam == "proc" else (O.cvs_spec, E.cvs_spec)
 ospec = mk_o(solver="dopri5", **kw); ospec.solver_kw = dict(rtol=1e-8, atol=1e-10, per_trajectory=True); ospec.grad_mode = mode
 espec = mk_e(solver="dopri5", **kw); espec.rtol, espec.atol, espec.grad_mode = 1e-6, 1e-8, mode
@@ -30,3 +32,10 @@ got = eng.unpack(grads)
 for k, v in got.items():
     a, b = v.double().cpu(), want[k]
     print("%-60s rel %.2e  |got| %.3e |want| %.3e" % (k, ((a - b).norm() / b.norm().clamp_min(1e-30)).item(), a.norm().item(), b.norm().item()))
+
+kb = "decoder.ode_model.dynamics.dynamics_hidden.bias"
+a, b = got[kb].double().cpu(), want[kb]
+print("hidden.bias per unit (got - want) / |want|_max:", [round(float(v), 4) for v in ((a - b) / b.abs().max())])
+kw_ = "decoder.ode_model.dynamics.dynamics_hidden.weight"
+a, b = got[kw_].double().cpu(), want[kw_]
+print("hidden.weight time column:", [round(float(v), 4) for v in ((a[:, 0] - b[:, 0]) / b[:, 0].abs().max())])
