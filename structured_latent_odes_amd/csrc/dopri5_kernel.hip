@@ -1,4 +1,4 @@
-// Adaptive Dormand-Prince 5(4) latent-ODE solve (forward) for gfx950: the `solver="dopri5"` string the reference can pass
+// Adaptive Dormand-Prince 5(4) latent-ODE solve and its reverse sweep for gfx950: the `solver="dopri5"` string the reference can pass
 // through to torchdiffeq.odeint (models/blackbox_ode.py:41-45; BASELINE config[2]).
 //
 // torchdiffeq's controller uses ONE step size for the whole [B,S] tensor (its error norm is an RMS over the batch), which
