@@ -248,3 +248,167 @@ def main_step(p, spec, obs, u, eps, times):
     g.update(gode)
     g.update(encoder_backward(p, esv, scale, g_loc, g_scale))
     return nll + lat_loss, g, dict(x=x, loc=loc, scale=scale, z=z, g_loc=g_loc, g_scale=g_scale)
+
+
+# ---- adaptive Dormand-Prince: per-trajectory controller with step records, and the reverse sweep over the records -----------
+# (csrc/dopri5_kernel.hip: dopri5_kernel / dopri5_bwd_kernel; one trajectory at a time here)
+_DP_A = [[1 / 5], [3 / 40, 9 / 40], [44 / 45, -56 / 15, 32 / 9], [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+         [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656]]
+_DP_C = [0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0]                      # six distinct stage times (stages 6 and 7 share t + dt)
+_DP_B = [35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84]
+_DP_E = [35 / 384 - 1951 / 21600, 0.0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720, -2187 / 6784 + 12231 / 42400,
+         11 / 84 - 649 / 6300, -1 / 60]
+_DP_M = [6025192743 / 30085553152 / 2, 0.0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+         187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2]
+
+
+def _dp_unpack(p):
+    Wh, bh = p[_O + "dynamics.dynamics_hidden.weight"], p[_O + "dynamics.dynamics_hidden.bias"]
+    Wg, bg = p[_O + "dynamics.dyanamics_growth.weight"], p[_O + "dynamics.dyanamics_growth.bias"]
+    Wd, bd = p[_O + "dynamics.dyanmics_degradation.weight"], p[_O + "dynamics.dyanmics_degradation.bias"]
+    return Wh, bh, Wg, bg, Wd, bd
+
+
+def _dp_coef(t, wt, u, Wg, bg, Wd, bd):
+    pre = wt * t + u
+    h = np.maximum(pre, 0)
+    return sigmoid(Wg @ h + bg), sigmoid(Wd @ h + bd), pre, h
+
+
+def _dp_stages(t, dt, y, wt, u, Wg, bg, Wd, bd):
+    """The seven stage slopes, the stage states and the coefficients at the six stage times of one step."""
+    A, D, PRE, HID = zip(*[_dp_coef(t + c * dt if c != 1.0 else t + dt, wt, u, Wg, bg, Wd, bd) for c in _DP_C])
+    ks, ys = [A[0] - D[0] * y], [y]
+    for i, row in enumerate(_DP_A):
+        yi = y + dt * sum(c * k for c, k in zip(row, ks))
+        ys.append(yi)
+        ks.append(A[i + 1] - D[i + 1] * yi)
+    y1 = y + dt * sum(c * k for c, k in zip(_DP_B, ks))
+    ks.append(A[5] - D[5] * y1)                                          # k7 = f(t + dt, y1)
+    return A, D, PRE, HID, ks, ys, y1
+
+
+def dopri5_forward(p, z, times, rtol, atol, max_steps=100000):
+    """x[B,T,S] and, per trajectory, the accepted steps [(t, dt, y)] -- torchdiffeq's algorithm with one controller per trajectory."""
+    Wh, bh, Wg, bg, Wd, bd = _dp_unpack(p)
+    W1, b1 = p[_O + "latent_to_ode_net.0.weight"], p[_O + "latent_to_ode_net.0.bias"]
+    W2, b2 = p[_O + "latent_to_ode_net.2.weight"], p[_O + "latent_to_ode_net.2.bias"]
+    B, T, S = z.shape[0], times.shape[0], Wg.shape[0]
+    x, recs = np.empty((B, T, S)), []
+    rms = lambda v: np.sqrt(np.mean(v * v))
+    for b in range(B):
+        wt, u = Wh[:, 0], Wh[:, 1:] @ z[b] + bh
+        y = sigmoid(W2 @ np.maximum(W1 @ z[b] + b1, 0) + b2)
+        x[b, 0] = y
+        t = times[0]
+        f = (lambda tt, yy: (lambda a, d, *_: a - d * yy)(*_dp_coef(tt, wt, u, Wg, bg, Wd, bd)))
+        f0 = f(t, y)
+        sc = atol + np.abs(y) * rtol
+        d0, d1 = rms(y / sc), rms(f0 / sc)
+        h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+        d2 = rms((f(t + h0, y + h0 * f0) - f0) / sc) / h0
+        h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** 0.2
+        dt = min(100 * h0, h1)
+        j, rec = 1, []
+        for _ in range(max_steps):
+            if j >= T:
+                break
+            A, D, PRE, HID, ks, ys, y1 = _dp_stages(t, dt, y, wt, u, Wg, bg, Wd, bd)
+            err = dt * sum(c * k for c, k in zip(_DP_E, ks))
+            ratio = rms(err / (atol + rtol * np.maximum(np.abs(y), np.abs(y1))))
+            if ratio <= 1:
+                rec.append((t, dt, y.copy()))
+                t1 = t + dt
+                ymid = y + dt * sum(c * k for c, k in zip(_DP_M, ks))
+                f0_, f1_ = ks[0], ks[6]
+                ca = 2 * dt * (f1_ - f0_) - 8 * (y1 + y) + 16 * ymid
+                cb = dt * (5 * f0_ - 3 * f1_) + 18 * y + 14 * y1 - 32 * ymid
+                cc = dt * (f1_ - 4 * f0_) - 11 * y - 5 * y1 + 16 * ymid
+                cd = dt * f0_
+                while j < T and times[j] <= t1:
+                    q = (times[j] - t) / dt
+                    x[b, j] = y + q * (cd + q * (cc + q * (cb + q * ca)))
+                    j += 1
+                t, y = t1, y1
+            factor = 10.0 if ratio == 0 else min(10.0, max(0.9 * ratio ** -0.2, 1.0 if ratio < 1 else 0.2))
+            dt *= factor
+        assert j >= T, "max_steps exceeded"
+        recs.append(rec)
+    return x, recs
+
+
+def dopri5_backward(p, z, times, recs, gx, drop_z=False):
+    """Reverse mode of the accepted steps and of the dense output (step sizes fixed): the formulas of dopri5_bwd_kernel.
+    gx[B,T,S] = dLoss/dx.  Returns gz[B,L] and the gradients of the ode parameters."""
+    Wh, bh, Wg, bg, Wd, bd = _dp_unpack(p)
+    W1, b1 = p[_O + "latent_to_ode_net.0.weight"], p[_O + "latent_to_ode_net.0.bias"]
+    W2, b2 = p[_O + "latent_to_ode_net.2.weight"], p[_O + "latent_to_ode_net.2.bias"]
+    B, T, S = gx.shape
+    H = Wh.shape[0]
+    GWg, GWd, Gbg, Gbd = np.zeros_like(Wg), np.zeros_like(Wd), np.zeros(S), np.zeros(S)
+    GWh, Gbh = np.zeros_like(Wh), np.zeros(H)
+    GW1, Gb1, GW2, Gb2 = np.zeros_like(W1), np.zeros(H), np.zeros_like(W2), np.zeros(S)
+    gz = np.zeros_like(z)
+    for b in range(B):
+        wt, u = Wh[:, 0], Wh[:, 1:] @ z[b] + bh
+        lam, j, gu = np.zeros(S), T - 1, np.zeros(H)
+        for (t, dt, y) in reversed(recs[b]):
+            A, D, PRE, HID, ks, ys, y1 = _dp_stages(t, dt, y, wt, u, Wg, bg, Wd, bd)
+            Ga = Gb = Gc = Gd = np.zeros(S)
+            gy = np.zeros(S)
+            while j >= 1 and times[j] > t:                                     # dense outputs inside (t, t + dt]
+                q = (times[j] - t) / dt
+                g = gx[b, j]
+                gy = gy + g
+                Gd, Gc, Gb, Ga = Gd + q * g, Gc + q * q * g, Gb + q ** 3 * g, Ga + q ** 4 * g
+                j -= 1
+            gf0 = dt * (-2 * Ga + 5 * Gb - 4 * Gc + Gd)
+            gf1 = dt * (2 * Ga - 3 * Gb + Gc)
+            gm = 16 * Ga - 32 * Gb + 16 * Gc
+            gy = gy - 8 * Ga + 18 * Gb - 11 * Gc + gm
+            gy1 = lam - 8 * Ga + 14 * Gb - 5 * Gc
+            gk = [dt * gm * m for m in _DP_M]                                   # dL/dk_1..7 from y_mid
+            gk[0] = gk[0] + gf0
+            gk[6] = gk[6] + gf1
+            sig = [None] * 6                                                    # (dL/d pre-sigmoid growth, degradation) per stage time
+            # stage 7: k7 = a5 - d5 * y1
+            sa, sd = gk[6] * A[5] * (1 - A[5]), -gk[6] * y1 * D[5] * (1 - D[5])
+            gy1 = gy1 - D[5] * gk[6]
+            gy = gy + gy1
+            for i in range(6):
+                gk[i] = gk[i] + dt * _DP_B[i] * gy1
+            # stages 6 .. 2: k_i = a - d * y_i, y_i = y + dt * sum_j a_ij k_j
+            for st in range(5, 0, -1):
+                ga_, gd_ = gk[st] * A[st] * (1 - A[st]), -gk[st] * ys[st] * D[st] * (1 - D[st])
+                if st == 5:
+                    ga_, gd_ = ga_ + sa, gd_ + sd
+                sig[st] = (ga_, gd_)
+                ev = -D[st] * gk[st]
+                gy = gy + ev
+                for jj, c in enumerate(_DP_A[st - 1]):
+                    gk[jj] = gk[jj] + dt * c * ev
+            sig[0] = (gk[0] * A[0] * (1 - A[0]), -gk[0] * y * D[0] * (1 - D[0]))
+            gy = gy - D[0] * gk[0]
+            lam = gy
+            for e in range(6):
+                te = t + _DP_C[e] * dt if _DP_C[e] != 1.0 else t + dt
+                ga_, gd_ = sig[e]
+                GWg += np.outer(ga_, HID[e]); GWd += np.outer(gd_, HID[e]); Gbg += ga_; Gbd += gd_
+                gh = (ga_ @ Wg + gd_ @ Wd) * (PRE[e] > 0)
+                gu += gh
+                GWh[:, 0] += gh * te
+        pre0 = W1 @ z[b] + b1
+        hp = np.maximum(pre0, 0)
+        x0 = sigmoid(W2 @ hp + b2)
+        go = (lam + gx[b, 0]) * x0 * (1 - x0)
+        GW2 += np.outer(go, hp); Gb2 += go
+        gp = (W2.T @ go) * (pre0 > 0)
+        GW1 += np.outer(gp, z[b]); Gb1 += gp
+        GWh[:, 1:] += np.outer(gu, z[b]); Gbh += gu
+        gz[b] = W1.T @ gp + (0 if drop_z else Wh[:, 1:].T @ gu)
+    g = {_O + "dynamics.dynamics_hidden.weight": GWh, _O + "dynamics.dynamics_hidden.bias": Gbh,
+         _O + "dynamics.dyanamics_growth.weight": GWg, _O + "dynamics.dyanamics_growth.bias": Gbg,
+         _O + "dynamics.dyanmics_degradation.weight": GWd, _O + "dynamics.dyanmics_degradation.bias": Gbd,
+         _O + "latent_to_ode_net.0.weight": GW1, _O + "latent_to_ode_net.0.bias": Gb1,
+         _O + "latent_to_ode_net.2.weight": GW2, _O + "latent_to_ode_net.2.bias": Gb2}
+    return gz, g

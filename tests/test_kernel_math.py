@@ -37,3 +37,34 @@ def test_kernel_algorithm_matches_oracle_autograd(name, method):
     assert set(main_keys) <= set(kg.keys())
     for k in main_keys:
         np.testing.assert_allclose(kg[k], grads[k].numpy(), rtol=1e-8, atol=1e-9, err_msg=k)
+
+
+@pytest.mark.parametrize("mode", ["exact", "reference_adjoint"])
+def test_dopri5_reverse_sweep_matches_oracle_autograd(mode):
+    """The adaptive path of csrc/dopri5_kernel.hip -- per-trajectory controller with recorded steps, then the hand-derived reverse
+    mode of the Dormand-Prince stages and of the quartic dense output (step sizes fixed) -- against autograd through the oracle's
+    per-trajectory dopri5, fp64, same tolerances => same accepted steps.  `reference_adjoint`: no z -> dynamics path."""
+    spec = O.cvs_spec(3, 3, 2, solver="dopri5")
+    T, B, S = 16, 3, 5
+    p = {k: v.double() for k, v in O.init_params(spec, T=T).items()}
+    g = torch.Generator().manual_seed(7)
+    p = {k: v + 0.1 * torch.randn(v.shape, generator=g, dtype=torch.float64) for k, v in p.items()}
+    times = torch.arange(T, dtype=torch.float64) * 0.6
+    z = torch.randn(B, spec.latent_dim, generator=g, dtype=torch.float64)
+    gx = torch.randn(B, T, S, generator=g, dtype=torch.float64)
+    kw = dict(rtol=1e-6, atol=1e-8, per_trajectory=True)
+    q = {k: v.clone().requires_grad_("ode_model" in k) for k, v in p.items()}
+    zz = z.clone().requires_grad_(True)
+    x = O.solve_ode(q, zz, times, "dopri5", grad_mode=mode, **kw)
+    (x * gx).sum().backward()
+    pn = {k: v.numpy() for k, v in p.items()}
+    xk, recs = KM.dopri5_forward(pn, z.numpy(), times.numpy(), 1e-6, 1e-8)
+    # same algorithm => the same accepted steps, up to the conditioning of the error estimate: it is a difference of O(1) slopes
+    # worth ~1e-6 of them, so last-bit differences in f (torch cat + linear vs the split hidden layer here) move dt by ~1e-10
+    np.testing.assert_allclose(xk, x.detach().numpy(), rtol=0, atol=1e-7)
+    assert all(len(r) >= T - 1 for r in recs)
+    gz, kg = KM.dopri5_backward(pn, z.numpy(), times.numpy(), recs, gx.numpy(), drop_z=(mode == "reference_adjoint"))
+    # gradients inherit that 1e-10 jitter of the step sizes times the sensitivity of the kink quadrature (observed <= 2e-5 relative)
+    np.testing.assert_allclose(gz, zz.grad.numpy(), rtol=2e-4, atol=1e-5)
+    for k, v in kg.items():
+        np.testing.assert_allclose(v, q[k].grad.numpy(), rtol=2e-4, atol=1e-5, err_msg=k)
