@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -88,7 +89,11 @@ int slode_create(slode_handle* out, int device_id) {
   c->err[0] = 0;
   c->profile = 0; c->ev_ready = 0; c->ev_valid = 0; c->repeat_ode = 0;
   c->adam_lo2 = c->adam_hi2 = 0; c->adam_delta2 = 0;
-  c->no_fold = getenv("SLODE_NO_FOLD") != nullptr;   // diagnostics: force the layer-by-layer encoder kernels
+  // diagnostics and test hooks: the environment is read here, once per handle, never at launch time
+  c->no_fold = getenv("SLODE_NO_FOLD") != nullptr;   // force the layer-by-layer encoder kernels
+  c->ode_loop = getenv("SLODE_ODE_LOOP") != nullptr;
+  c->ode_generic = getenv("SLODE_ODE_GENERIC") != nullptr;
+  c->ode_alg = getenv("SLODE_ODE_ALG") ? atoi(getenv("SLODE_ODE_ALG")) : 0;
   *out = c;
   return SLODE_OK;
 }
@@ -188,10 +193,9 @@ static int ode_grid_for(slode_handle h, const slode_shape& s) {
   if (occ < 1) occ = 1;
   const int cus = h ? h->num_cu : 256;
   long long g = (long long)cus * occ;
-  // One workgroup per trajectory up to 65,536 trajectories: the loop-free instantiation (no register spills) with the hardware
-  // queueing the workgroups beats the persistent loop by ~10 % (tools/batch_sweep.py) at the price of one 9 KB slab per trajectory;
-  // beyond that (and under SLODE_ODE_LOOP, which the persistent-loop test sets) a resident grid loops over the trajectories.
-  if (s.B <= 65536 && !getenv("SLODE_ODE_LOOP")) g = s.B;
+  // One workgroup per trajectory up to 65,536 trajectories (the hardware queues the workgroups; one slab per trajectory);
+  // beyond that (and under the SLODE_ODE_LOOP handle flag, which the persistent-loop tests set) a resident grid loops over them.
+  if (s.B <= 65536 && !(h && h->ode_loop)) g = s.B;
   if (g > s.B) g = s.B;
   return (int)g;
 }
@@ -329,19 +333,11 @@ int slode_ode_solve_fwd(slode_handle h, const slode_shape* s, const slode_layout
     return SLODE_OK;
   }
   if (!stage_t) return fail(h, SLODE_EINVAL, "stage_t is NULL");
-  // forward-only solve needs one loss slot per workgroup; borrow the head of x? no: use a tiny static scratch in x's tail
-  // is not possible => the kernel writes its (zero) loss partial into slabs; give it the first floats of a scratch we own.
-  static thread_local float* scratch = nullptr;
-  static thread_local int scratch_n = 0;
   const int grid = ode_grid_for(h, *s);
-  if (scratch_n < grid) {
-    if (scratch) (void)hipFree(scratch);
-    HIP_TRY(h, hipMalloc(&scratch, sizeof(float) * (size_t)grid));
-    scratch_n = grid;
-  }
   OdeLaunch a{};
   a.s = *s; a.lay = *lay; a.params = params; a.times = times; a.stage_t = stage_t; a.z_in = z; a.x_out = x;
-  a.slabs = scratch; a.slab_stride = 1; a.grid = grid; a.backward = 0; a.with_ll = 0;
+  a.slabs = nullptr; a.slab_stride = 0; a.grid = grid; a.backward = 0; a.with_ll = 0;   // pure solve: no loss slot, nothing allocated
+  a.force_loop = h->ode_loop; a.force_generic = h->ode_generic;
   hipError_t e = slode_launch_ode(a, (hipStream_t)stream, h->err, sizeof(h->err));
   if (e == hipErrorInvalidValue) return SLODE_EINVAL;
   HIP_TRY(h, e);
@@ -360,6 +356,7 @@ int slode_ode_solve_bwd(slode_handle h, const slode_shape* s, const slode_layout
   OdeLaunch a{};
   a.s = *s; a.lay = *lay; a.params = params; a.times = times; a.stage_t = stage_t; a.z_in = z; a.gx_in = g_x;
   a.g_loc = g_z; a.slabs = w.ode_slabs; a.slab_stride = w.ode_stride; a.grid = w.ode_grid; a.backward = 1; a.with_ll = 0;
+  a.force_loop = h->ode_loop; a.force_generic = h->ode_generic;
   hipError_t e = slode_launch_ode(a, (hipStream_t)stream, h->err, sizeof(h->err));
   if (e == hipErrorInvalidValue) return SLODE_EINVAL;
   HIP_TRY(h, e);
@@ -392,7 +389,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
   const bool dp5 = !aux_mode && s->method == SLODE_DOPRI5;
   if (dp5 && !(s->H == 25 && (s->S == 5 || s->S == 8)))
     return fail(h, SLODE_EINVAL, "dopri5 kernels are instantiated for (S,H) in {(5,25),(8,25)}");
-  if (dp5 && (s->B > 65536 || getenv("SLODE_ODE_LOOP")))
+  if (dp5 && (s->B > 65536 || h->ode_loop))
     return fail(h, SLODE_EINVAL, "the dopri5 ELBO step takes at most 65,536 trajectories per call");
   Workspace w = carve(h, *s, *lay, workspace);
   if (workspace_bytes < w.bytes) return fail(h, SLODE_ENOSPC, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
@@ -440,6 +437,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     a.u = u; a.eps = eps; a.loc = w.loc; a.scale = w.scale; a.x_out = x_out; a.z_out = z_out;
     a.g_loc = w.g_loc; a.g_scale = w.g_scale; a.slabs = w.ode_slabs; a.slab_stride = w.ode_stride; a.grid = w.ode_grid;
     a.backward = bwd ? 1 : 0; a.with_ll = 1;
+    a.force_loop = h->ode_loop; a.force_generic = h->ode_generic; a.alg = h->ode_alg;
     if (bwd && folded) { a.enc_hid = w.hid; a.g_pre = w.g_pre; a.glat = w.glat; a.g_loc = nullptr; a.g_scale = nullptr; }
     if (dp5) {
       // adaptive solve (per-trajectory controller, accepted steps recorded) -> scorer pass 1: loss terms, dLoss/dx -> reverse mode

@@ -28,6 +28,10 @@ struct slode_ctx {
   int adam_lo2, adam_hi2; // slode_adam_region: elements with their own Adam step count = step + adam_delta2
   int64_t adam_delta2;
   int repeat_ode;         // measurement aid: extra (idempotent) launches of the ode_elbo kernel per step (slode_profile_enable)
+  // diagnostics / test hooks, read from the environment ONCE in slode_create (never at launch time):
+  int ode_loop;           // SLODE_ODE_LOOP: persistent-loop grid even when every trajectory could have its own workgroup
+  int ode_generic;        // SLODE_ODE_GENERIC: skip the shape-specialised instantiations
+  int ode_alg;            // SLODE_ODE_ALG = 1 / 2: measured A/B arms of the fused kernel (metric shape only; ode_kernel.hip)
 };
 
 // ---- device helpers -------------------------------------------------------------------------------------
@@ -240,9 +244,10 @@ struct OdeLaunch {
   const float* x_ext = nullptr;   // [B][T][S]
   float* gx_out = nullptr;        // [B][T][S]
   const float* gz_ext = nullptr;  // [B][L]
+  int force_loop = 0, force_generic = 0, alg = 0;   // handle flags (slode_ctx)
 };
 hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, size_t errlen);
-size_t slode_ode_lds_bytes(const slode_shape& s, int nthreads);
+size_t slode_ode_lds_bytes(const slode_shape& s, int nthreads, bool one = false);
 int slode_ode_threads(const slode_shape& s);
 
 struct EncLaunch {
