@@ -21,6 +21,7 @@
 //     trajectories and written once as a slab (fixed-order reduction in misc_kernels.hip => bitwise reproducible).
 #include "slode_common.h"
 #include <cstdlib>
+#include <vector>
 
 typedef const __attribute__((address_space(4))) float* cptr;  // uniform loads => s_load + SGPR operands
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -78,10 +79,12 @@ struct OdeK {
   const float *x_ext, *gz_ext;
   float* gx_out;
   int Hc;
+  // gradient-segment elements no phase of this launch owns (zero gradient: written as zeros once per workgroup), relative to ode_begin
+  int nz, zlo[8], zhi[8];
 };
 
 struct LdsMap {  // offsets in floats
-  int ts, sig, A, x, lam, st, stn, ax, ct, gm, hp, tau, ps, ord, sgs, ms, sf, acc, par, uu, auxh, auxd, auxgo, z, gzl, gpl, gls, u, wt, pre0,
+  int ts, sig, A, x, lam, st, stn, ax, ct, gm, hp, tau, ps, ord, sgs, ewt, epre, epre0, esw, ms, sf, par, uu, auxh, auxd, auxgo, z, gzl, gpl, gls, u, wt, pre0,
       hid0, x0, go, gp0, gu, red, pf, meta, total;
 };
 
@@ -106,12 +109,16 @@ __host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int
   stn = imax2(stn, nt * 2 * S - 3 * m.ax);              // G rows overlay the whole block
   m.st = o; m.stn = pad4(stn); o += m.stn;
   m.ct = o; o += pad4((nthreads / (2 * S)) * 4 * S);    // chunk sums [NQ][sum g (2S) | sum g t (2S)]
-  m.gm = o; o += 2 * 2 * S * 32;                        // GM | GT: [2][2S][32]
+  m.gm = o; o += 2 * 2 * S * 32;                        // GM | GT: [2][2S][32] (unit H = the constant-1 unit)
   m.hp = o; o += pad4(4 * Q * C * S);                   // head-weight partials [hsplit][Q*C*S]
   m.tau = o; o += 32;
   m.ps = o; o += 32;
   m.ord = o; o += 32;
   m.sgs = o; o += 32;
+  m.ewt = o; o += 32;
+  m.epre = o; o += 32;
+  m.epre0 = o; o += 32;
+  m.esw = o; o += 32 * 2 * S;                           // events in table order: sign * W[c][unit], [32][2S]
   m.ms = o; o += 32;
   m.sf = o; o += 32;
   m.uu = o; o += SLODE_MAX_NU;
@@ -134,8 +141,7 @@ __host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int
   m.auxh = o; o += naux * 32;   // label heads scored in the main loss only
   m.auxd = o; o += naux * 32;
   m.auxgo = o; o += pad4(naux * 12);
-  m.acc = o; o += pad4(npar + 1);  // [loss | priors | init net | dynamics | heads]; constant_std goes straight to the slab
-  m.par = o; o += pad4(npar);
+  m.par = o; o += pad4(npar);      // [priors | init net | dynamics | heads]: the gradient of every element goes straight to the slab
   m.total = o;
   return m;
 }
@@ -361,10 +367,10 @@ __host__ __device__ constexpr int ode_threads_for(int T, int Q, int C, int S) {
 
 // Register budget = 512 / (waves per SIMD the declared block size forces).  Loop-free forms fit 128 (S = 5) / 168-256 (S = 8, short
 // grids) without spilling.  The persistent-loop forms hoist kernel-argument loads and need more: the specialised ones declare their
-// exact block size, the generic ones cap the grid length they accept (768 / 512 threads) -- NO instantiation may spill a VGPR
+// exact block size, the generic ones cap the grid length they accept (512 threads) -- NO instantiation may spill a VGPR
 // (tools/check_spills.py).
 __host__ __device__ constexpr int ode_max_threads(int S, int T_, int C_, int Q_, bool one, bool bwd) {
-  if (!one && bwd) return T_ > 0 ? ode_threads_for(T_, Q_, C_, S) : (S > 5 ? 512 : 768);
+  if (!one && bwd) return T_ > 0 ? ode_threads_for(T_, Q_, C_, S) : 512;
   return (S > 5 && T_ > 0 && T_ <= 128) ? 512 : ((S > 5 || (T_ > 0 && T_ <= 128)) ? 768 : 1024);
 }
 
@@ -381,7 +387,7 @@ __host__ __device__ constexpr int ode_max_threads(int S, int T_, int C_, int Q_,
 // S = 8 carries 60% more live state per thread: its instantiations trade one wave/SIMD for a 168-VGPR budget (T <= 768).
 // T_, C_, L_, Q_, M_ (time points, channels, latent dim, decoder heads, solver): 0 / -1 = read from the launch struct; the
 // shape-specialised instantiations get compile-time LDS offsets, loop bounds and solver.
-// ONE: the grid has one workgroup per trajectory: no persistent loop.  In BOTH forms every gradient accumulator lives in LDS (s_acc):
+// ONE: the grid has one workgroup per trajectory: no persistent loop.  In BOTH forms every gradient element goes to its slab entry as soon as it is final:
 // nothing but the scalar loss partial is carried in registers from one trajectory to the next (the round-1 looped form kept
 // 2S+2 accumulators per thread live across the loop, spilled, and hipcc placed one spill store ahead of the exec restore of a
 // control-flow join -- wrong gradients; tools/check_spills.py now rejects any kernel that uses scratch).
@@ -413,10 +419,13 @@ ode_elbo_kernel(const OdeK k) {
   float* s_tau = smem + m.tau;
   int* s_ps = reinterpret_cast<int*>(smem + m.ps);
   int* s_ord = reinterpret_cast<int*>(smem + m.ord);
-  float* s_sgs = smem + m.sgs;
+  float* s_sgs = smem + m.sgs;     // events in table order: sign, unit's w_t, unit's pre-activation at the event time (= s_tau[k+1])
+  float* s_ewt = smem + m.ewt;
+  float* s_epre = smem + m.epre;
+  float* s_epre0 = smem + m.epre0;   // ... and at the first stage time
+  float* s_esw = smem + m.esw;       // sign * (column `unit` of [W_g; W_d]), [event][2S]
   int* s_ms = reinterpret_cast<int*>(smem + m.ms);
   int* s_sf = reinterpret_cast<int*>(smem + m.sf);
-  float* s_acc = smem + m.acc;
   float* s_par = smem + m.par;  // small weights, staged once per workgroup (cold phases read LDS, not HBM/L2)
   float* s_uu = smem + m.uu;  // this trajectory's label row u[b, :]
   float* s_auxh = smem + m.auxh;    // label heads: hidden activations [head][32]
@@ -517,7 +526,11 @@ ode_elbo_kernel(const OdeK k) {
     }
   }
   STAMP(13);
-  for (int i = tid; i < k.npar + 1; i += NT) s_acc[i] = 0.f;
+  if (BWD) {   // elements no phase owns (e.g. label-head parameters the main loss does not score): zero gradient
+    float* sl = k.slabs + (long long)blockIdx.x * k.slab_stride + 1;
+    for (int z = 0; z < k.nz; ++z)
+      for (int i = k.zlo[z] + tid; i < k.zhi[z]; i += NT) sl[i] = 0.f;
+  }
   __syncthreads();
   STAMP(14);
   if (tid < 32) s_wt[tid] = (tid < H) ? s_par[k.o_wh + tid * (1 + L)] : 0.f;  // time column of dynamics_hidden (col 0)
@@ -551,6 +564,11 @@ ode_elbo_kernel(const OdeK k) {
     // address computations of the phases below out of this loop (which only lengthens live ranges and spills).
     int tid = tid_outer;
     if (!ONE) asm volatile("" : "+v"(tid));
+    // Every gradient element of the segment has exactly one owning thread per trajectory and goes straight to this workgroup's
+    // slab (no LDS copy): written on the workgroup's first trajectory, added to on later ones (same owner, program order).
+    float* const sl1 = k.slabs + (long long)blockIdx.x * k.slab_stride + 1;
+    const bool first_traj = ONE || b == (int)blockIdx.x;
+    auto accum = [&](int idx, float v) { float* d = sl1 + idx; *d = first_traj ? v : (*d + v); };
     __syncthreads();   // s_pf / s_uu of this trajectory are in place
 
     // ---- P0a: latent sample, log q, log p (mechanistic_cvs.py:125-135, 225-237) -------------------------
@@ -617,31 +635,69 @@ ode_elbo_kernel(const OdeK k) {
         // table is monotone, so the predicate flips at most once along it: bisection on the predicate itself.
         //   sf = 1: on for m >= ms (ms = 0: always, ms = nt: never);   sf = 0: on for m < ms.
         const float wtj = s_wt[j];
-        const bool p_first = fmaf(wtj, s_ts[0], uj) > 0.f, p_last = fmaf(wtj, s_ts[n_stage_t - 1], uj) > 0.f;
-        int lo = 0, hi = n_stage_t - 1;
-        for (int it = 0; it < n_it; ++it) {
-          const int mid = (lo + hi) >> 1;
-          const bool pm = fmaf(wtj, s_ts[mid], uj) > 0.f;
-          const bool go = hi - lo > 1;
-          if (go && pm == p_last) hi = mid;
-          if (go && pm != p_last) lo = mid;
+        const int nt = n_stage_t;
+        const float t_first = s_ts[0], t_last = s_ts[nt - 1];
+        const bool p_first = fmaf(wtj, t_first, uj) > 0.f, p_last = fmaf(wtj, t_last, uj) > 0.f;
+        const bool flips = p_first != p_last;
+        int hi = nt - 1;
+        bool need = flips;
+        if (nt >= 16) {
+          // a near-uniform table puts the flip next to the interpolated index: eight probes around it, accepted only if they bracket it
+          const float gf = (-uj / wtj - t_first) / (t_last - t_first) * (float)(nt - 1);
+          const int c0 = min(max((int)gf - 3, 0), nt - 8);
+          float tp[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) tp[i] = s_ts[flips ? c0 + i : i];
+          int cnt = 0;
+          bool pa = p_first, pb = p_last;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const bool pi = fmaf(wtj, tp[i], uj) > 0.f;
+            cnt += (pi == p_first) ? 1 : 0;
+            if (i == 0) pa = pi;
+            if (i == 7) pb = pi;
+          }
+          if (flips && pa == p_first && pb == p_last) { hi = c0 + cnt; need = false; }
+        }
+        if (__builtin_amdgcn_ballot_w64(need) != 0ull) {   // irregular tables: plain bisection on the predicate
+          int lo = 0;
+          hi = need ? nt - 1 : hi;
+          for (int it = 0; it < n_it; ++it) {
+            const int mid = (lo + hi) >> 1;
+            const bool pm = fmaf(wtj, s_ts[mid], uj) > 0.f;
+            const bool go = need && hi - lo > 1;
+            if (go && pm == p_last) hi = mid;
+            if (go && pm != p_last) lo = mid;
+          }
         }
         int ms = hi, sf = p_last ? 1 : 0;
-        if (p_first == p_last) { sf = 1; ms = p_first ? 0 : n_stage_t; }
-        if (j >= H) { sf = 1; ms = n_stage_t; }
+        if (!flips) { sf = 1; ms = p_first ? 0 : nt; }
+        if (j >= H) { sf = 1; ms = nt; }
         s_ms[j] = ms;
         s_sf[j] = sf;
         if (ALG == 0) {
           // rank of this unit's switching index among the 32 lanes (ties by lane; idle lanes sort last): the events in table order
+          const int key = ms * 32 + j;
           int rk = 0;
 #pragma unroll
-          for (int i = 0; i < 32; ++i) {
-            const int mi = __builtin_amdgcn_readlane(ms, i);
-            rk += (mi < ms || (mi == ms && i < j)) ? 1 : 0;
-          }
+          for (int i = 0; i < 32; ++i) rk += (__builtin_amdgcn_readlane(key, i) < key) ? 1 : 0;
+          const float tn = s_ts[min(ms, nt - 1)];
           s_ps[rk] = ms;
           s_ord[rk] = j;
           s_sgs[rk] = sf ? 1.f : -1.f;
+          s_ewt[rk] = wtj;
+          s_epre[rk] = fmaf(wtj, tn, uj);
+          s_epre0[rk] = fmaf(wtj, t_first, uj);
+          {
+            const float sg = sf ? 1.f : -1.f;
+            const int jc = min(j, H - 1);
+            float wc[2 * S];
+#pragma unroll
+            for (int c = 0; c < 2 * S; ++c) wc[c] = s_par[(c < S ? k.o_wg + c * H : k.o_wd + (c - S) * H) + jc];
+#pragma unroll
+            for (int c = 0; c < 2 * S; ++c) s_esw[rk * 2 * S + c] = (j < H) ? sg * wc[c] : 0.f;
+          }
+          s_tau[rk + 1 < 32 ? rk + 1 : 0] = (rk + 1 < 32) ? tn : t_first;   // segment k+1 starts at event k's time; s_tau[0] = first stage time
         }
       }
     }
@@ -670,34 +726,53 @@ ode_elbo_kernel(const OdeK k) {
       // Head c's pre-activation o_c(t) = bias_c + sum_j W_cj relu(w_t,j t + u_j) is continuous and piecewise linear in t; segment k
       // starts at the k-th switching event (table order).  Row k = [value at the segment's first stage time tau_k | slope], advanced
       // event by event in a form whose terms stay at the scale of o_c itself: V += slope (tau' - tau) + sign W_ce pre_e(tau').
+      // The rows stay in registers until the chain is done: with no store in the loops every LDS read is issued up front.
       const int c = tid - 32;
-      const float* Wc = s_par + (c < S ? k.o_wg + c * H : k.o_wd + (c - S) * H);
-      const float t0 = s_ts[0];
+      // pass 1: the units that are on over a prefix (sign -1) are on at the first stage time
       float al = 0.f, V = s_par[c < S ? k.o_bg + c : k.o_bd + (c - S)];
-#pragma unroll 5
-      for (int j = 0; j < H; ++j) {
-        if (s_sf[j] == 0) {   // on over a prefix: on at the first stage time
-          const float w = Wc[j], wtj = s_wt[j];
-          al = fmaf(w, wtj, al);
-          V = fmaf(w, fmaf(wtj, t0, s_u[j]), V);
+#pragma unroll
+      for (int k0 = 0; k0 < H; k0 += 8) {
+        float sw[8], ew[8], p0[8], sg[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int kk = min(k0 + q, H - 1);
+          sw[q] = s_esw[kk * 2 * S + c]; ew[q] = s_ewt[kk]; p0[q] = s_epre0[kk]; sg[q] = s_sgs[kk];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the batch's LDS reads above, the arithmetic below
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float w = -sw[q] * ((k0 + q < H && sg[q] < 0.f) ? 1.f : 0.f);   // sign -1: sw = -W
+          al = fmaf(w, ew[q], al);
+          V = fmaf(w, p0[q], V);
         }
       }
-      s_tab[c] = V;
-      s_tab[2 * S + c] = al;
-      if (c == 0) s_tau[0] = t0;
-      float tau = t0;
-#pragma unroll 5
-      for (int kk = 0; kk < H; ++kk) {
-        const int e = s_ord[kk];
-        const float tn = s_ts[min(s_ps[kk], n_stage_t - 1)];
-        const float sw = s_sgs[kk] * Wc[e], wte = s_wt[e];
-        V = fmaf(al, tn - tau, V);
-        V = fmaf(sw, fmaf(wte, tn, s_u[e]), V);
-        al = fmaf(sw, wte, al);
-        tau = tn;
-        s_tab[(kk + 1) * 4 * S + c] = V;
-        s_tab[(kk + 1) * 4 * S + 2 * S + c] = al;
-        if (c == 0) s_tau[kk + 1] = tn;
+      float Vr[H + 1], Ar[H + 1];
+      Vr[0] = V; Ar[0] = al;
+      // pass 2: event by event
+#pragma unroll
+      for (int k0 = 0; k0 < H; k0 += 8) {
+        float sw[8], ew[8], pe[8], ta[9];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int kk = min(k0 + q, H - 1);
+          sw[q] = s_esw[kk * 2 * S + c]; ew[q] = s_ewt[kk]; pe[q] = s_epre[kk]; ta[q] = s_tau[min(k0 + q, H)];
+        }
+        ta[8] = s_tau[min(k0 + 8, H)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (k0 + q < H) {
+            V = fmaf(al, ta[q + 1] - ta[q], V);
+            V = fmaf(sw[q], pe[q], V);
+            al = fmaf(sw[q], ew[q], al);
+            Vr[k0 + q + 1] = V; Ar[k0 + q + 1] = al;
+          }
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk <= H; ++kk) {
+        s_tab[kk * 4 * S + c] = Vr[kk];
+        s_tab[kk * 4 * S + 2 * S + c] = Ar[kk];
       }
     }
     if (k.n_aux > 0 && tid >= 64 && tid < 64 + k.n_aux) {
@@ -1065,37 +1140,70 @@ ode_elbo_kernel(const OdeK k) {
       //   GM[r][j] = sum_{m: unit j on} g[m][r],  GT[r][j] = sum_{m: unit j on} g[m][r] t_m   (unit H = constant 1: the head biases)
       //   dW[r][j] = w_t,j GT + u_j GM;   dLoss/du_j = sum_r W[r][j] GM[r][j];   dLoss/dw_t,j = sum_r W[r][j] GT[r][j]
       if (ALG != 2) {
-        // (A) chunk sums: lane (chunk q, channel r) adds up CL consecutive samples
+        // (A) chunk sums: lane (chunk q, channel r) adds up CL consecutive samples.  Loads go in batches of 8 samples with a
+        // scheduling barrier behind them (left alone, the scheduler waits for each LDS read in turn); a 0/1 mask keeps them
+        // unconditional (a select on a loaded value is turned into a branch + wait).
         if (tid < NQ * 2 * S) {
           const int q = tid / (2 * S), r = tid - q * (2 * S);
-          const int m0 = q * CL, m1 = min(n_stage_t, m0 + CL);
           float cg = 0.f, cgt = 0.f;
-          for (int mm = m0; mm < m1; ++mm) {
-            const float g = s_G[mm * GP + r];
-            cg += g;
-            cgt = fmaf(g, s_ts[mm], cgt);
+          for (int i0 = 0; i0 < CL; i0 += 8) {
+            float gv[8], tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int mc = min(q * CL + i0 + u, n_stage_t - 1);
+              gv[u] = s_G[mc * GP + r]; tv[u] = s_ts[mc];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const float g = gv[u] * ((i0 + u < CL && q * CL + i0 + u < n_stage_t) ? 1.f : 0.f);
+              cg += g;
+              cgt = fmaf(g, tv[u], cgt);
+            }
           }
           s_ct[q * 4 * S + r] = cg;
           s_ct[q * 4 * S + 2 * S + r] = cgt;
         }
         __syncthreads();
         // (B) lane (unit j, channel r): whole chunks on the unit's "on" side + the samples of the chunk its switching index cuts.
-        //     Only additions on the "on" side: no total-minus-prefix cancellation.
+        //     Only additions on the "on" side: no total-minus-prefix cancellation.  Fixed trip counts, masked adds.
         for (int e = tid; e < H * 2 * S; e += NT) {
           const int j = e / (2 * S), r = e - j * (2 * S);
           const int ms = s_ms[j], sf = s_sf[j];
-          const int qs = min(ms / CL, NQ);          // chunk that holds sample ms (NQ: none)
+          const int qs = ms / CL;          // chunk that holds sample ms (>= NQ: none)
+          const int qa = sf ? qs + 1 : 0, qn = sf ? NQ - qa : qs;            // whole chunks [qa, qa + qn)
+          const int ma = sf ? ms : qs * CL, mn = sf ? (qs + 1) * CL - ms : ms - qs * CL;   // cut chunk: samples [ma, ma + mn)
           float gmv = 0.f, gtv = 0.f;
-          const int qa = sf ? qs + 1 : 0, qb = sf ? NQ : qs;      // whole chunks [qa, qb)
-          for (int q = qa; q < qb; ++q) {
-            gmv += s_ct[q * 4 * S + r];
-            gtv += s_ct[q * 4 * S + 2 * S + r];
+          for (int q0 = 0; q0 < NQ; q0 += 8) {
+            float v[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int qc = min(q0 + u, NQ - 1);
+              v[u] = s_ct[qc * 4 * S + r]; w[u] = s_ct[qc * 4 * S + 2 * S + r];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const float on = (q0 + u < NQ && (unsigned)(q0 + u - qa) < (unsigned)qn) ? 1.f : 0.f;
+              gmv = fmaf(on, v[u], gmv);
+              gtv = fmaf(on, w[u], gtv);
+            }
           }
-          const int ma = sf ? ms : qs * CL, mb = sf ? min(n_stage_t, (qs + 1) * CL) : ms;   // cut chunk: samples [ma, mb)
-          for (int mm = ma; mm < mb; ++mm) {
-            const float g = s_G[mm * GP + r];
-            gmv += g;
-            gtv = fmaf(g, s_ts[mm], gtv);
+          for (int i0 = 0; i0 < CL; i0 += 8) {
+            float gv[8], tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int mc = min(qs * CL + i0 + u, n_stage_t - 1);
+              gv[u] = s_G[mc * GP + r]; tv[u] = s_ts[mc];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int mm = qs * CL + i0 + u;
+              const float g = gv[u] * ((i0 + u < CL && mm < n_stage_t && (unsigned)(mm - ma) < (unsigned)mn) ? 1.f : 0.f);
+              gmv += g;
+              gtv = fmaf(g, tv[u], gtv);
+            }
           }
           s_gm[r * 32 + j] = gmv;
           s_gm[(2 * S + r) * 32 + j] = gtv;
@@ -1103,6 +1211,7 @@ ode_elbo_kernel(const OdeK k) {
         if (tid >= NT - 2 * S) {   // the constant-1 unit: every sample
           const int r = tid - (NT - 2 * S);
           float gmv = 0.f;
+#pragma unroll 8
           for (int q = 0; q < NQ; ++q) gmv += s_ct[q * 4 * S + r];
           s_gm[r * 32 + H] = gmv;
         }
@@ -1151,11 +1260,10 @@ ode_elbo_kernel(const OdeK k) {
       STAMP(9);
       // (C) into the gradient segment: head weights / biases, dLoss/du (P7 reads it), time column of the hidden layer
       {
-        float* acc = s_acc + 1;
         for (int e = tid; e < H * 2 * S; e += NT) {
           const int j = e / (2 * S), r = e - j * (2 * S);
           const float v = fmaf(s_wt[j], s_gm[(2 * S + r) * 32 + j], s_u[j] * s_gm[r * 32 + j]);
-          acc[(r < S ? k.o_wg + r * H : k.o_wd + (r - S) * H) + j] += v;
+          accum((r < S ? k.o_wg + r * H : k.o_wd + (r - S) * H) + j, v);
         }
         if (tid >= NT - 32) {
           const int j = tid - (NT - 32);
@@ -1167,18 +1275,24 @@ ode_elbo_kernel(const OdeK k) {
               gu = fmaf(w, s_gm[r * 32 + j], gu);
               gwt = fmaf(w, s_gm[(2 * S + r) * 32 + j], gwt);
             }
-            acc[k.o_wh + j * (1 + L)] += gwt;
+            accum(k.o_wh + j * (1 + L), gwt);
           }
           s_gu[j] = gu;
         }
         if (tid >= NT - 64 && tid < NT - 64 + 2 * S) {
           const int r = tid - (NT - 64);
-          acc[r < S ? k.o_bg + r : k.o_bd + (r - S)] += s_gm[r * 32 + H];
+          accum(r < S ? k.o_bg + r : k.o_bd + (r - S), s_gm[r * 32 + H]);
         }
       }
-      } else {   // ext: no gradient reaches the dynamics or x0 through this kernel
+      } else {   // ext: no gradient reaches the dynamics or x0 through this kernel (the elements step (C) owns are zeros)
         if (tid < 32) s_gu[tid] = 0.f;
         if (tid >= 64 && tid < 64 + S) s_go[tid - 64] = 0.f;
+        for (int e = tid; e < H * 2 * S; e += NT) {
+          const int j = e / (2 * S), r = e - j * (2 * S);
+          accum((r < S ? k.o_wg + r * H : k.o_wd + (r - S) * H) + j, 0.f);
+        }
+        if (tid < H) accum(k.o_wh + tid * (1 + L), 0.f);
+        if (tid >= 64 && tid < 64 + 2 * S) accum((tid - 64) < S ? k.o_bg + (tid - 64) : k.o_bd + (tid - 64 - S), 0.f);
       }
       __syncthreads();
       STAMP(17);
@@ -1256,48 +1370,47 @@ ode_elbo_kernel(const OdeK k) {
                                                (__attribute__((address_space(3))) void*)(s_encw + base), 4, 0, 0);
           }
         }
-        float* acc = s_acc + 1;
         for (int e = t1; e < H * L; e += n1) {
           const int j = e / L, l = e - j * L;
-          acc[k.o_wh + j * (1 + L) + 1 + l] += s_gu[j] * s_z[l];
-          acc[k.o_w1 + e] += s_gp0[j] * s_z[l];
+          accum(k.o_wh + j * (1 + L) + 1 + l, s_gu[j] * s_z[l]);
+          accum(k.o_w1 + e, s_gp0[j] * s_z[l]);
         }
         for (int e = t1; e < S * H; e += n1) {
           const int s = e / H, j = e - s * H;
-          acc[k.o_w2 + e] += s_go[s] * s_hid0[j];
+          accum(k.o_w2 + e, s_go[s] * s_hid0[j]);
         }
-        if (t1 < H) { acc[k.o_bh + t1] += s_gu[t1]; acc[k.o_b1 + t1] += s_gp0[t1]; }
-        if (t1 < S) acc[k.o_b2 + t1] += s_go[t1];
+        if (t1 < H) { accum(k.o_bh + t1, s_gu[t1]); accum(k.o_b1 + t1, s_gp0[t1]); }
+        if (t1 < S) accum(k.o_b2 + t1, s_go[t1]);
         if (k.with_ll && t1 < n_headw) {   // decoder head weights: the hsplit partials of P4, fixed order
           const int qc = t1 / S, s = t1 - qc * S, q = qc / C, c = qc - q * C;
           float v = 0.f;
           for (int part = 0; part < hsplit; ++part) v += s_hp[part * n_headw + t1];
-          acc[k.o_head[q] + c * S + s] += v;
+          accum(k.o_head[q] + c * S + s, v);
         }
         for (int hd = 0; hd < k.n_aux; ++hd) {
           const slode_aux ax = k.aux[hd];
           for (int e = t1; e < k.U * ax.z_dim; e += n1) {
             const int j = e / ax.z_dim, l = e - j * ax.z_dim;
-            acc[k.o_aux_w1[hd] + e] += s_auxd[hd * 32 + j] * s_z[ax.z_off + l];
+            accum(k.o_aux_w1[hd] + e, s_auxd[hd * 32 + j] * s_z[ax.z_off + l]);
           }
           for (int e = t1; e < ax.u_dim * k.U; e += n1) {
             const int q = e / k.U, j = e - q * k.U;
-            acc[k.o_aux_w2[hd] + e] += s_auxgo[hd * 12 + q] * s_auxh[hd * 32 + j];
+            accum(k.o_aux_w2[hd] + e, s_auxgo[hd * 12 + q] * s_auxh[hd * 32 + j]);
           }
-          if (t1 < k.U) acc[k.o_aux_b1[hd] + t1] += s_auxd[hd * 32 + t1];
-          if (t1 < ax.u_dim) acc[k.o_aux_b2[hd] + t1] += s_auxgo[hd * 12 + t1];
-          if (t1 == 0 && ax.kind == SLODE_AUX_EXPEXP) acc[k.o_aux_c[hd]] += s_auxgo[hd * 12 + 8];
+          if (t1 < k.U) accum(k.o_aux_b1[hd] + t1, s_auxd[hd * 32 + t1]);
+          if (t1 < ax.u_dim) accum(k.o_aux_b2[hd] + t1, s_auxgo[hd * 12 + t1]);
+          if (t1 == 0 && ax.kind == SLODE_AUX_EXPEXP) accum(k.o_aux_c[hd], s_auxgo[hd * 12 + 8]);
         }
         if (k.loc != nullptr && t1 < L) {  // prior nets: latent dim t1 owns its bias entries and weight rows (setup's lookup table)
           const int4 m0 = reinterpret_cast<const int4*>(s_meta)[2 * t1], m1 = reinterpret_cast<const int4*>(s_meta)[2 * t1 + 1];
           if (m0.x) {
             const float gpl = s_gpl[t1], gls = s_gls[t1];
-            acc[m0.y] += gpl;
-            acc[m0.z] += gls;
+            accum(m0.y, gpl);
+            accum(m0.z, gls);
             for (int q = 0; q < m1.z; ++q) {
               const float uv = s_uu[m1.y + q];
-              acc[m0.w + q] += gpl * uv;
-              acc[m1.x + q] += gls * uv;
+              accum(m0.w + q, gpl * uv);
+              accum(m1.x + q, gls * uv);
             }
           }
         }
@@ -1360,7 +1473,6 @@ ode_elbo_kernel(const OdeK k) {
     if (!k.with_ll) {  // pure solve backward: the likelihood-only entries of the segment carry no gradient
       for (int i = tid; i < C * T; i += NT) slab[1 + k.o_cstd + i] = 0.f;
     }
-    for (int i = tid + 1; i < k.npar + 1; i += NT) slab[i] = s_acc[i];
   }
   STAMP(11);
 }
@@ -1453,6 +1565,38 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
 
   const int nthreads = slode_ode_threads(s);
   const bool bwd = a.backward != 0;
+  {
+    // which elements of the segment [ode_begin, cstd) a backward launch writes (owner threads in P6 (C) / P7); the rest carry no
+    // gradient in this launch and are written as zeros: e.g. the label heads when the main loss does not score them, the unused
+    // second Exp head of a Laplace label head, the decoder heads and prior nets in a pure solve backward
+    std::vector<char> cov((size_t)k.npar, 0);
+    auto mark = [&](int off, int n) { for (int i = 0; i < n; ++i) cov[(size_t)(off - ob) + i] = 1; };
+    if (a.loc != nullptr)
+      for (int g = 0; g < s.n_groups; ++g) {
+        const slode_group& gr = s.groups[g];
+        mark(lay.ploc_w[g], gr.z_dim * gr.u_dim); mark(lay.ploc_b[g], gr.z_dim);
+        mark(lay.pls_w[g], gr.z_dim * gr.u_dim);  mark(lay.pls_b[g], gr.z_dim);
+      }
+    mark(lay.init_w1, s.H * s.L); mark(lay.init_b1, s.H); mark(lay.init_w2, s.S * s.H); mark(lay.init_b2, s.S);
+    mark(lay.dyn_wh, s.H * (1 + s.L)); mark(lay.dyn_bh, s.H);
+    mark(lay.dyn_wg, s.S * s.H); mark(lay.dyn_bg, s.S); mark(lay.dyn_wd, s.S * s.H); mark(lay.dyn_bd, s.S);
+    if (a.with_ll)
+      for (int q = 0; q < k.Q; ++q) mark(lay.head_w[q], s.C * s.S);
+    for (int q = 0; q < k.n_aux; ++q) {
+      const slode_aux& x = s.aux[q];
+      mark(lay.aux_w1[q], s.U * x.z_dim); mark(lay.aux_b1[q], s.U); mark(lay.aux_w2[q], x.u_dim * s.U); mark(lay.aux_b2[q], x.u_dim);
+      if (x.kind == SLODE_AUX_EXPEXP) mark(lay.aux_c[q], 1);
+    }
+    k.nz = 0;
+    for (int i = 0; i < k.npar;) {
+      if (cov[(size_t)i]) { ++i; continue; }
+      int j = i;
+      while (j < k.npar && !cov[(size_t)j]) ++j;
+      if (k.nz == 8) { snprintf(err, errlen, "ode kernel: more than 8 unowned gradient ranges (layout not supported)"); return hipErrorInvalidValue; }
+      k.zlo[k.nz] = i; k.zhi[k.nz] = j; ++k.nz;
+      i = j;
+    }
+  }
   // loop-free form when every trajectory has its own workgroup (the grid policy is the caller's: ode_grid_for)
   const bool one = bwd && a.grid == s.B && !a.force_loop;
   const size_t lds = slode_ode_lds_bytes(s, nthreads, one);

@@ -26,30 +26,22 @@ for it in range(5):   # the bench's step: fused Adam
     eng.elbo_adam_step(flat, obs_d, u_d, eps_d, loss, grads, m_, v_, 1e-3, it + 1)
 torch.cuda.synchronize()
 lib = _lib.load()
-for name, labels in (("ode", ["setup", "P0 latent/init", "P1 eval a,d", "P1 coeffs", "P2 scan", "P3 heads+LL", "P4 adj scan|head grads",
-                              "P5 step bwd", "P6 weight grads", "P7 small nets", "epilogue"]),
-                     ("enc", ["fwd: loads", "fwd: conv", "fwd: pool", "fwd: lin", "fwd: heads", None, None, None,
-                              "bwd: loads", "bwd: heads/tanh", "bwd: lin^T", "bwd: pool^T", "bwd: conv grad", "bwd: reduce+slab"])):
-    buf = (C.c_ulonglong * 32)()
-    rc = getattr(lib, "slode_debug_stamps_" + name)(buf)
-    assert rc == 0
-    v = list(buf)
-    print("== %s kernel, workgroup 0 (us)" % name)
-    for i, lab in enumerate(labels):
-        if lab is not None and v[i + 1] and v[i]:
-            print("  %-26s %8.2f" % (lab, (v[i + 1] - v[i]) / 100.0))
-
-if name == "ode":
-    pass
-v = None
 buf = (C.c_ulonglong * 32)()
-if lib.slode_debug_stamps_ode(buf) == 0:
-    v = list(buf)
-    for lab, i, j in (("setup: prefetch issue", 0, 12), ("setup: table loads -> LDS", 12, 13), ("setup: zero acc + barrier", 13, 14), ("setup: rest", 14, 1), ("P0a latent sample/log-probs", 1, 15), ("P0b u, init hidden, aux hidden", 15, 16), ("P0c x0, aux heads", 16, 2),
-                      ("P7: gu sum, aux, go", 9, 17), ("P7: gp0", 17, 18), ("P7: gz + stores", 18, 19), ("P7: owner accumulation", 19, 20), ("P7: last barrier", 20, 21), ("P7: g_pre block", 21, 10),
-                      ("epi: block_sum", 10, 22), ("epi: chunk reduce", 22, 23), ("epi: heads + cstd", 23, 24), ("epi: slab write", 24, 11)):
-        if v[i] and v[j]:
-            print("  %-42s %8.2f" % (lab, (v[j] - v[i]) / 100.0))
+assert lib.slode_debug_stamps_ode(buf) == 0
+v = list(buf)
+print("== ode kernel, workgroup 0 (us)")
+tot = 0.0
+for lab, i, j in (("setup: table loads -> LDS", 0, 13), ("setup: zero acc + barrier", 13, 14), ("setup: w_t, table check", 14, 1),
+                  ("P0a latent sample / log-probs", 1, 15), ("P0b u, init hidden, switching indices, rank", 15, 16),
+                  ("P0c x0 || piecewise-linear table", 16, 2), ("P1 stage evaluations + exchange", 2, 3), ("P1 step coefficients", 3, 4),
+                  ("P2 forward scan", 4, 5), ("P3 heads + likelihood", 5, 6), ("P4 adjoint scan | head grads", 6, 7),
+                  ("P5 step reverse mode + sample rows", 7, 8), ("P6 chunk sums + switching-index sums", 8, 9), ("P6 into the segment", 9, 17),
+                  ("P7 aux, gp0", 17, 18), ("P7 latent gradient | owner accumulation", 18, 20), ("P7 last barrier", 20, 21),
+                  ("g_pre block, prefetch", 21, 10), ("epilogue: loss", 10, 22), ("epilogue: slab write", 22, 11)):
+    if v[i] and v[j]:
+        print("  %-46s %8.2f" % (lab, (v[j] - v[i]) / 100.0))
+        tot += (v[j] - v[i]) / 100.0
+print("  %-46s %8.2f" % ("total", tot))
 import numpy as np
 n = 1024
 buf = (C.c_ulonglong * (2 * n))()
