@@ -455,75 +455,68 @@ ode_elbo_kernel(const OdeK k) {
   const bool ext = (T_ == 0) && k.x_ext != nullptr;
 
   // ---- per-workgroup setup (shared by all trajectories this workgroup integrates) ----------------------
-  // the tables are staged with ALL their global loads in flight together (clamped addresses, no predicated loads; one L2/HBM
-  // round trip for the common sizes instead of one per table); tables longer than DEPTH * NT elements take further rounds
+  // The stage-time table and the parameter segment go global -> LDS by LDS-DMA (global_load_lds: 64 consecutive floats per wave
+  // instruction, no registers, no address arithmetic per element); the few per-thread values (this trajectory's latent inputs, its
+  // constant_std column) go through registers meanwhile.
   float sigr[SLODE_MAX_C] = {1.f, 1.f, 1.f, 1.f};   // ONE: softplus(constant_std[c, t = tid]) stays in registers until P3
   {
-    constexpr int DEPTH = 8;
     const int n_ts = n_stage_t, n_par = k.npar, n_sig = (!ONE && k.with_ll) ? C * T : 0;
-    const int nmax = max(max(n_ts, n_par), n_sig);
-    const int rounds = (nmax + DEPTH * NT - 1) / (DEPTH * NT);
-    for (int r = 0; r < rounds; ++r) {
-      const int i0 = r * DEPTH * NT + tid;
-      float v_ts[DEPTH], v_par[DEPTH], v_sig[DEPTH];
-      float v_l0 = 0.f, v_l1 = 1.f, v_l2 = 0.f, v_u = 0.f;
-      float v_c[SLODE_MAX_C] = {0.f, 0.f, 0.f, 0.f};
-      const int b_first = blockIdx.x;
-      if (r == 0 && b_first < k.B) {
-        const int lc = min(tid, L - 1);
-        if (k.loc != nullptr) {
-          v_l0 = k.loc[(long long)b_first * L + lc];
-          v_l1 = k.scale[(long long)b_first * L + lc];
-          v_l2 = k.eps[(long long)b_first * L + lc];
-        } else {
-          v_l0 = k.z_in[(long long)b_first * L + lc];
-        }
-        if (k.u != nullptr) v_u = k.u[(long long)b_first * k.nu + min(tid, k.nu - 1)];
-      }
-      if (ONE && r == 0 && k.with_ll) {
-#pragma unroll
-        for (int c = 0; c < SLODE_MAX_C; ++c) v_c[c] = k.cstd[min(c, C - 1) * T + min(tid, T - 1)];
-      }
-#pragma unroll
-      for (int q = 0; q < DEPTH; ++q) {
-        const int i = i0 + q * NT;
-        v_ts[q] = k.stage_t[min(i, n_ts - 1)];
-        v_par[q] = k.pseg[min(i, n_par - 1)];
-        v_sig[q] = ONE ? 0.f : k.cstd[min(i, max(n_sig, 1) - 1)];
-      }
-      if (r == 0 && tid < L) {
-        // prior-net lookup table for latent dim l (mechanistic_cvs.py:225-237): resolved once per workgroup, while the loads fly
-        //   [0] in a conditional group  [1] loc bias  [2] log-scale bias  [3] loc weight row  [4] log-scale weight row  [5] u_off  [6] u_dim
-        const int l = tid;
-        int me[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int g = 0; g < k.ng; ++g) {
-          const slode_group gr = k.grp[g];
-          if (l >= gr.z_off && l < gr.z_off + gr.z_dim) {
-            const int ll = l - gr.z_off;
-            me[0] = 1; me[1] = k.o_ploc_b[g] + ll; me[2] = k.o_pls_b[g] + ll;
-            me[3] = k.o_ploc_w[g] + ll * gr.u_dim; me[4] = k.o_pls_w[g] + ll * gr.u_dim; me[5] = gr.u_off; me[6] = gr.u_dim;
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s_meta[l * 8 + q] = me[q];
-      }
-      if (r == 0 && tid < L) { s_pf[tid] = v_l0; s_pf[pad4(L) + tid] = v_l1; s_pf[2 * pad4(L) + tid] = v_l2; }
-      if (r == 0 && tid < k.nu) s_uu[tid] = v_u;
-      if (ONE && r == 0 && k.with_ll) {
-#pragma unroll
-        for (int c = 0; c < SLODE_MAX_C; ++c)
-          if (c < C) sigr[c] = softplusf(v_c[c]);
-      }
-#pragma unroll
-      for (int q = 0; q < DEPTH; ++q) {
-        const int i = i0 + q * NT;
-        if (i < n_ts) s_ts[i] = v_ts[q];
-        if (i < n_par) s_par[i] = v_par[q];
-        if (!ONE && r * DEPTH * NT + q * NT < n_sig) {   // wave-uniform: slots past the table skip the (long) softplus altogether
-          if (i < n_sig) s_sig[i] = softplusf(v_sig[q]);
-        }
-      }
+    {
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, lane = tid & 63;
+      for (int base = wv * 64; base < n_ts; base += NW * 64)
+        if (base + lane < n_ts)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(k.stage_t + base + lane),
+                                           (__attribute__((address_space(3))) void*)(s_ts + base), 4, 0, 0);
+      for (int base = wv * 64; base < n_par; base += NW * 64)
+        if (base + lane < n_par)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(k.pseg + base + lane),
+                                           (__attribute__((address_space(3))) void*)(s_par + base), 4, 0, 0);
     }
+    float v_l0 = 0.f, v_l1 = 1.f, v_l2 = 0.f, v_u = 0.f;
+    float v_c[SLODE_MAX_C] = {0.f, 0.f, 0.f, 0.f};
+    const int b_first = blockIdx.x;
+    if (b_first < k.B) {
+      const int lc = min(tid, L - 1);
+      if (k.loc != nullptr) {
+        v_l0 = k.loc[(long long)b_first * L + lc];
+        v_l1 = k.scale[(long long)b_first * L + lc];
+        v_l2 = k.eps[(long long)b_first * L + lc];
+      } else {
+        v_l0 = k.z_in[(long long)b_first * L + lc];
+      }
+      if (k.u != nullptr) v_u = k.u[(long long)b_first * k.nu + min(tid, k.nu - 1)];
+    }
+    if (ONE && k.with_ll) {
+#pragma unroll
+      for (int c = 0; c < SLODE_MAX_C; ++c) v_c[c] = k.cstd[min(c, C - 1) * T + min(tid, T - 1)];
+    }
+    if (tid < L) {
+      // prior-net lookup table for latent dim l (mechanistic_cvs.py:225-237): resolved once per workgroup, while the loads fly
+      //   [0] in a conditional group  [1] loc bias  [2] log-scale bias  [3] loc weight row  [4] log-scale weight row  [5] u_off  [6] u_dim
+      const int l = tid;
+      int me[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int g = 0; g < k.ng; ++g) {
+        const slode_group gr = k.grp[g];
+        if (l >= gr.z_off && l < gr.z_off + gr.z_dim) {
+          const int ll = l - gr.z_off;
+          me[0] = 1; me[1] = k.o_ploc_b[g] + ll; me[2] = k.o_pls_b[g] + ll;
+          me[3] = k.o_ploc_w[g] + ll * gr.u_dim; me[4] = k.o_pls_w[g] + ll * gr.u_dim; me[5] = gr.u_off; me[6] = gr.u_dim;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s_meta[l * 8 + q] = me[q];
+    }
+    if (!ONE) {   // persistent-loop form: softplus(constant_std) once per workgroup, kept in LDS
+      for (int i = tid; i < n_sig; i += NT) s_sig[i] = softplusf(k.cstd[i]);
+    }
+    if (tid < L) { s_pf[tid] = v_l0; s_pf[pad4(L) + tid] = v_l1; s_pf[2 * pad4(L) + tid] = v_l2; }
+    if (tid < k.nu) s_uu[tid] = v_u;
+    if (ONE && k.with_ll) {
+#pragma unroll
+      for (int c = 0; c < SLODE_MAX_C; ++c)
+        if (c < C) sigr[c] = softplusf(v_c[c]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA has landed (the barrier below covers the other waves')
   }
   STAMP(13);
   if (BWD) {   // elements no phase owns (e.g. label-head parameters the main loss does not score): zero gradient
@@ -1620,7 +1613,7 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   }
   const bool ra = bwd && s.grad_mode == SLODE_GRAD_REFERENCE_ADJOINT;
   // measured A/B arms: direct evaluation of the dynamics heads, MFMA contraction -- metric shape, exact gradients, loop-free
-  if (a.alg != 0) {
+  if (a.alg != 0 && bwd) {
     if (!(s.H == 25 && s.S == 5 && s.T == 200 && s.C == 3 && s.L == 8 && k.Q == 3 && s.method == SLODE_RK4 && one && !ra && !a.x_ext)) {
       snprintf(err, errlen, "ode kernel variant %d is instantiated for the metric shape only (cvs T=200 L=8 rk4, exact gradients, B <= 65536)", a.alg);
       return hipErrorInvalidValue;

@@ -94,6 +94,7 @@ int slode_create(slode_handle* out, int device_id) {
   c->ode_loop = getenv("SLODE_ODE_LOOP") != nullptr;
   c->ode_generic = getenv("SLODE_ODE_GENERIC") != nullptr;
   c->ode_alg = getenv("SLODE_ODE_ALG") ? atoi(getenv("SLODE_ODE_ALG")) : 0;
+  c->ode_grid_cap = getenv("SLODE_ODE_GRID") ? atoi(getenv("SLODE_ODE_GRID")) : 0;
   *out = c;
   return SLODE_OK;
 }
@@ -196,6 +197,7 @@ static int ode_grid_for(slode_handle h, const slode_shape& s) {
   // One workgroup per trajectory up to 65,536 trajectories (the hardware queues the workgroups; one slab per trajectory);
   // beyond that (and under the SLODE_ODE_LOOP handle flag, which the persistent-loop tests set) a resident grid loops over them.
   if (s.B <= 65536 && !(h && h->ode_loop)) g = s.B;
+  else if (h && h->ode_grid_cap > 0 && g > h->ode_grid_cap) g = h->ode_grid_cap;
   if (g > s.B) g = s.B;
   return (int)g;
 }

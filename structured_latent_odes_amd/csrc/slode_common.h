@@ -32,6 +32,7 @@ struct slode_ctx {
   int ode_loop;           // SLODE_ODE_LOOP: persistent-loop grid even when every trajectory could have its own workgroup
   int ode_generic;        // SLODE_ODE_GENERIC: skip the shape-specialised instantiations
   int ode_alg;            // SLODE_ODE_ALG = 1 / 2: measured A/B arms of the fused kernel (metric shape only; ode_kernel.hip)
+  int ode_grid_cap;       // SLODE_ODE_GRID = n: at most n workgroups in the persistent-loop grid (tests: several trajectories per workgroup at small B)
 };
 
 // ---- device helpers -------------------------------------------------------------------------------------

@@ -193,6 +193,18 @@ class Engine:
             raise ValueError("%s must be contiguous" % name)
         return t
 
+    def _check_batch(self, obs, u, eps):
+        """The kernels read raw device pointers: a CPU / float64 / strided label or noise tensor must not get that far."""
+        B = obs.shape[0]
+        self._f32(obs, "observations", contiguous=False)
+        if u is not None:
+            self._f32(u, "u")
+            if tuple(u.shape) != (B, self.spec.n_u):
+                raise ValueError("u must be [%d, %d], got %s" % (B, self.spec.n_u, tuple(u.shape)))
+        self._f32(eps, "eps")
+        if tuple(eps.shape) != (B, self.spec.latent_dim):
+            raise ValueError("eps must be [%d, %d], got %s" % (B, self.spec.latent_dim, tuple(eps.shape)))
+
     def workspace(self, B: int) -> torch.Tensor:
         w = self._ws.get(B)
         if w is None:
@@ -208,6 +220,9 @@ class Engine:
         times = self._f32(times.to(self.device, torch.float32).contiguous(), "times")
         if times.numel() != self.T:
             raise ValueError("times has %d points, engine built for T=%d" % (times.numel(), self.T))
+        d = times[1:] - times[:-1]
+        if not (bool((d > 0).all()) or bool((d < 0).all())):    # torchdiffeq odeint's own precondition (misc._check_timelike)
+            raise ValueError("t must be strictly increasing or decreasing")
         n = int(self.lib.slode_num_stage_times(C.byref(self.shape(1))))
         st = torch.empty(n, dtype=torch.float32, device=self.device)
         _check(self.lib, self.handle, self.lib.slode_stage_times(self.handle, C.byref(self.shape(1)), self._p(times), self._p(st), self._stream()))
@@ -281,6 +296,7 @@ class Engine:
     def elbo_step(self, params, obs, u, eps, loss_out, grads=None, x_out=None, z_out=None):
         """-ELBO (summed over the batch) into loss_out[0]; exact gradient into grads (flat) unless grads is None."""
         B = obs.shape[0]
+        self._check_batch(obs, u, eps)
         ws = self.workspace(B)
         _check(self.lib, self.handle, self.lib.slode_elbo_step(
             self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._times), self._p(self._stage_t),
@@ -291,6 +307,7 @@ class Engine:
     def elbo_adam_step(self, params, obs, u, eps, loss_out, grads, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), adam_eps=1e-8):
         """elbo_step + Adam with the update fused into the gradient reduction (single-process training)."""
         B = obs.shape[0]
+        self._check_batch(obs, u, eps)
         ws = self.workspace(B)
         _check(self.lib, self.handle, self.lib.slode_elbo_adam_step(
             self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._times), self._p(self._stage_t),
@@ -303,6 +320,7 @@ class Engine:
         """-ELBO of the auxiliary loss (model_meta) and its gradient; `adam` = (exp_avg, exp_avg_sq, lr, step, betas, eps) fuses
         the Adam update into the final reduction."""
         B = obs.shape[0]
+        self._check_batch(obs, u, eps)
         ws = self.workspace(B)
         m, v, lr, step, betas, aeps = adam if adam is not None else (None, None, 0.0, 1, (0.9, 0.999), 1e-8)
         _check(self.lib, self.handle, self.lib.slode_aux_step(

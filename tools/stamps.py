@@ -12,7 +12,7 @@ from structured_latent_odes_amd import _lib, engine as E
 
 dev = torch.device("cuda:0")
 ospec = O.cvs_spec(3, 3, 2, solver="rk4")
-B, T = 1024, 200
+B, T = int(os.environ.get("STAMPS_B", "1024")), 200
 p = O.init_params(ospec, T=T)
 obs, u, eps, times = O.synthetic_batch(ospec, B, T)
 eng = E.Engine(E.cvs_spec(3, 3, 2, solver="rk4"), T, dev)
