@@ -449,6 +449,9 @@ ode_elbo_kernel(const OdeK k) {
   float* s_encw = s_st;   // P7: encoder head weights [2][L][Hc] staged over the (then idle) stage buffer
 
   const cptr wg = (cptr)k.wg, bg = (cptr)k.bg, wd = (cptr)k.wd, bd = (cptr)k.bd;
+  // wave 0 carries every serial stretch of a trajectory (latent sample, switching indices, table, both scans): it issues ahead of the
+  // bulk waves of the co-resident workgroups
+  if (tid < 64) __builtin_amdgcn_s_setprio(2);
   STAMP(0);
   const int tid_outer = tid;
   // scoring an externally solved trajectory (dopri5 training, generic instantiation): no solve, nothing flows through a solver here
@@ -541,15 +544,8 @@ ode_elbo_kernel(const OdeK k) {
   int n_it = 1;                                         // bisection steps that cover [0, nt)
   while ((1 << n_it) < n_stage_t) ++n_it;
   // the stage-time table must be monotone (torchdiffeq rejects anything else: "t must be strictly increasing or decreasing"); every
-  // unit's relu is then switched over a prefix or a suffix of it.  A table that is not turns the loss into NaN.
+  // unit's relu is then switched over a prefix or a suffix of it.  A table that is not turns the loss into NaN (checked in P1).
   bool ts_bad = false;
-  {
-    const bool inc = s_ts[n_stage_t - 1] >= s_ts[0];
-    for (int i = tid; i + 1 < n_stage_t; i += NT) {
-      const float d = s_ts[i + 1] - s_ts[i];
-      if (inc ? !(d >= 0.f) : !(d <= 0.f)) ts_bad = true;
-    }
-  }
   STAMP(1);
 
   for (int b = blockIdx.x; b < k.B; b += gridDim.x) {
@@ -562,7 +558,7 @@ ode_elbo_kernel(const OdeK k) {
     float* const sl1 = k.slabs + (long long)blockIdx.x * k.slab_stride + 1;
     const bool first_traj = ONE || b == (int)blockIdx.x;
     auto accum = [&](int idx, float v) { float* d = sl1 + idx; *d = first_traj ? v : (*d + v); };
-    __syncthreads();   // s_pf / s_uu of this trajectory are in place
+    if (!ONE && b != (int)blockIdx.x) __syncthreads();   // s_pf / s_uu of this trajectory are in place (first one: the setup barrier)
 
     // ---- P0a: latent sample, log q, log p (mechanistic_cvs.py:125-135, 225-237) -------------------------
     if (tid < L) {
@@ -603,7 +599,9 @@ ode_elbo_kernel(const OdeK k) {
       }
     }
     STAMP(15);
-    __syncthreads();
+    // (P0a, P0b and the table part of P0c run on wave 0 only unless label heads are scored here: a wave's LDS accesses execute in
+    //  program order, so the workgroup barriers in between are only needed for the label-head threads of the proc family)
+    if (k.n_aux > 0) __syncthreads();
     // ---- P0b: u = W_z z + b_h (time-invariant part of the hidden layer), init-net hidden; each unit's switching index ------
     if (tid < 32) {
       const int j = tid;
@@ -705,7 +703,7 @@ ode_elbo_kernel(const OdeK k) {
       }
     }
     STAMP(16);
-    __syncthreads();
+    if (k.n_aux > 0) __syncthreads();
     // ---- P0c: x0 = sigmoid(W2 relu(.) + b2)  (blackbox_ode.py:19-22)  ||  the piecewise-linear table ------------------------
     if (tid < S) {
       float o = s_par[k.o_b2 + tid];
@@ -815,7 +813,7 @@ ode_elbo_kernel(const OdeK k) {
       }
       loss_acc -= k.aux_mult * lp;
     }
-    if (ALG == 0) __syncthreads();   // table complete
+    __syncthreads();   // table complete (ALG 0); u, w_t in place for every wave
 
     STAMP(2);
     // ---- P1: stage evaluations + step coefficients (thread n <-> grid step n) ---------------------------
@@ -828,6 +826,16 @@ ode_elbo_kernel(const OdeK k) {
     const int n = tid;
     const bool own_step = n < T - 1;
     const bool own_last = (n == T - 1) && (uses_next || (BWD && need_next));
+    if (!ext && own_step) {   // this step's stretch of the stage-time table runs in the table's overall direction
+      const bool inc = s_ts[n_stage_t - 1] >= s_ts[0];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if (r < R) {
+          const float d = s_ts[R * n + r + 1] - s_ts[R * n + r];
+          if (inc ? !(d >= 0.f) : !(d <= 0.f)) ts_bad = true;
+        }
+      }
+    }
     if (!ext) {
       if (ALG == 0) {
 #pragma unroll
@@ -1036,6 +1044,15 @@ ode_elbo_kernel(const OdeK k) {
       }
       __syncthreads();
       STAMP(7);
+      if (k.n_aux > 0 && tid < k.n_aux * 32) {  // label heads: back through the output layer and the Softplus (read again in P7)
+        const int hd = tid >> 5, j = tid & 31;
+        if (j < k.U) {
+          const slode_aux ax = k.aux[hd];
+          float gh = 0.f;
+          for (int q = 0; q < ax.u_dim; ++q) gh = fmaf(s_par[k.o_aux_w2[hd] + q * k.U + j], s_auxgo[hd * 12 + q], gh);
+          s_auxd[hd * 32 + j] *= gh;
+        }
+      }
       if (!ext) {
       // ---- P5: reverse mode of the step coefficients (thread n <-> step n) ------------------------------
       // (the stage buffer is free again: re-exchange the first-stage values instead of carrying a3/d3 in registers)
@@ -1091,10 +1108,21 @@ ode_elbo_kernel(const OdeK k) {
 #pragma unroll
         for (int s = 0; s < S; ++s) { av[0][s] = 0.f; dv[0][s] = 0.f; }
       }
-      if (tid >= 64 && tid < 64 + S) {  // dLoss/d(x0 pre-activation), before the adjoint is overwritten (NT >= 128 is guaranteed)
-        const int s = tid - 64;
-        const float x0 = s_x0[s];
-        s_go[s] = s_lam[s] * x0 * (1.f - x0);
+      if (tid >= 64 && tid < 128) {  // wave 1 (NT >= 128 is guaranteed): dLoss/d(x0 pre-activation), before the adjoint is overwritten,
+        const int j = tid - 64;      // then back through the init net's output layer (same wave: in-order LDS)
+        if (j < S) {
+          const float x0 = s_x0[j];
+          s_go[j] = s_lam[j] * x0 * (1.f - x0);
+        }
+        if (j < 32) {
+          float gh0 = 0.f;
+          if (j < H) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) gh0 = fmaf(s_par[k.o_w2 + s * H + j], s_go[s], gh0);
+            gh0 = (s_pre0[j] > 0.f) ? gh0 : 0.f;
+          }
+          s_gp0[j] = gh0;
+        }
       }
       __syncthreads();   // every read of A | x | lam | st is done: the block becomes the sample rows G[nt][2S]
       if (need_next && own_step) {
@@ -1278,7 +1306,7 @@ ode_elbo_kernel(const OdeK k) {
         }
       }
       } else {   // ext: no gradient reaches the dynamics or x0 through this kernel (the elements step (C) owns are zeros)
-        if (tid < 32) s_gu[tid] = 0.f;
+        if (tid < 32) { s_gu[tid] = 0.f; s_gp0[tid] = 0.f; }
         if (tid >= 64 && tid < 64 + S) s_go[tid - 64] = 0.f;
         for (int e = tid; e < H * 2 * S; e += NT) {
           const int j = e / (2 * S), r = e - j * (2 * S);
@@ -1290,27 +1318,6 @@ ode_elbo_kernel(const OdeK k) {
       __syncthreads();
       STAMP(17);
       // ---- P7: small nets (init net, z-part of the hidden layer, priors) and the latent gradient ----------
-      if (k.n_aux > 0 && tid < k.n_aux * 32) {  // label heads: back through the output layer and the Softplus
-        const int hd = tid >> 5, j = tid & 31;
-        if (j < k.U) {
-          const slode_aux ax = k.aux[hd];
-          float gh = 0.f;
-          for (int q = 0; q < ax.u_dim; ++q) gh = fmaf(s_par[k.o_aux_w2[hd] + q * k.U + j], s_auxgo[hd * 12 + q], gh);
-          s_auxd[hd * 32 + j] *= gh;
-        }
-      }
-      if (tid >= 64 && tid < 96) {
-        const int j = tid - 64;
-        float gh0 = 0.f;
-        if (j < H) {
-#pragma unroll
-          for (int s = 0; s < S; ++s) gh0 = fmaf(s_par[k.o_w2 + s * H + j], s_go[s], gh0);
-          gh0 = (s_pre0[j] > 0.f) ? gh0 : 0.f;
-        }
-        s_gp0[j] = gh0;
-      }
-      STAMP(18);
-      __syncthreads();
       if (tid < 64) {
         // latent gradient on wave 0: lane = (part, l); the sum over hidden units is split over `parts` lane groups
         const int Lp = (L > 32) ? 64 : ((L > 16) ? 32 : ((L > 8) ? 16 : 8)), parts = 64 / Lp;
