@@ -18,7 +18,7 @@
 // the dense-output polynomial, step sizes held fixed (the controller is not differentiated), lane = trajectory (weights as SGPR
 // operands, hidden offsets u in LDS).  The right-hand side is linear in the state with coefficients that depend on time only, so a
 // step's seven stages are re-evaluated from its recorded (t, dt, y) instead of being stored.  All six evaluation times of a step are
-// folded into one pass over the hidden units: every per-lane accumulator column in LDS is read-modified-written once per step.
+// folded into one pass; the weight gradients come from running sums parked at each hidden unit's switching time (sweep_step).
 // The workgroup's 64 columns are summed in a fixed order into one slab row in the layout of the fixed-grid kernel's slabs (reduced
 // by the same deterministic tail).  (A reverse sweep in the forward kernel's 8-lane mapping was 4x faster but computed the
 // hidden-layer bias gradient of units >= 16 about 1e-2 off -- cause not found -- and is not shipped.)
@@ -269,6 +269,7 @@ struct DpBK {
   const int* nrec;
   const float *w1, *b1, *w2, *b2, *wh, *bh, *wg, *bg, *wd, *bd;
   float *gz, *slabs;           // gz [B][L]; slabs: one row per workgroup, slot 0 = loss (0, or NaN on a failed solve), then the ode segment
+  float* snap;                 // [B][H][4S] running sums parked when a unit's relu flips (see sweep_step)
   int slab_stride, nseg;
   int o_w1, o_b1, o_w2, o_b2, o_wh, o_bh, o_wg, o_bg, o_wd, o_bd;
 };
@@ -299,51 +300,41 @@ __device__ __forceinline__ void coef(float t, const float* __restrict__ s_wt, co
   for (int s = 0; s < S; ++s) { a[s] = sigmoidf_fast(xa[s]); d[s] = sigmoidf_fast(xd[s]); }
 }
 
-// Weight gradients of one accepted step: its six evaluation times at once, so that every accumulator column entry is touched once
-// per step (plain read-modify-write: the column is lane-private) and the weights are fetched once per hidden unit.
-// gxa / gxd: dL/d(pre-sigmoid growth / degradation) per evaluation time.  acc columns (stride DPW): [wg S*H | wd S*H | bg S | bd S | u H | wt H]
+// Weight gradients.  The hidden layer is relu(w_t t + u_j): along the time-ordered sequence of evaluation times (all stages of all
+// accepted steps) unit j is switched on over a prefix or a suffix, so its share of every head-weight gradient is a partial sum of the
+// per-sample head gradients g (and of g t) up to the sample where its predicate fma(w_t, t, u_j) > 0 flips.  The sweep walks the
+// samples backwards in time keeping the running sums RS = sum g, RT = sum g t (2S channels each) and a bit per unit; when a unit's
+// bit flips the running sums are parked in `snap` (global, [trajectory][unit][4S], written once per unit at most).  After the sweep
+//   GM_j = snapshot (unit on at late times) | total - snapshot (on at early times) | total (always on) | 0 (never on),   GT_j likewise,
+//   dW[r][j] = w_t,j GT_j[r] + u_j GM_j[r],  dLoss/du_j = sum_r W[r][j] GM_j[r],  dLoss/dw_t,j = sum_r W[r][j] GT_j[r]
+// -- per step 6 x H predicates and 6 x 4S adds instead of the 6 x H x 4S multiply-adds (and 2S + 2 LDS read-modify-writes per unit)
+// of a per-unit accumulation.
 template <int S, int H>
-__device__ __forceinline__ void accum_step(const float (&te)[6], const float* __restrict__ s_wt, const float* __restrict__ s_ul, cptr wg, cptr wd,
-                                           const float (&gxa)[6][S], const float (&gxd)[6][S], float* __restrict__ acc) {
-  asm volatile("" : "+s"(wg), "+s"(wd));   // keep the weight loads inside the step
-#pragma unroll 1
-  for (int j = 0; j < H; ++j) {
-    const float wt = s_wt[j], uj = s_ul[j * DPW];
-    float wgj[S], wdj[S], ta[S], td[S];
+__device__ __forceinline__ void sweep_step(const float (&te)[6], const float* __restrict__ s_wt, const float* __restrict__ s_ul,
+                                           const float (&gxa)[6][S], const float (&gxd)[6][S], float (&RS)[2 * S], float (&RT)[2 * S],
+                                           unsigned& onmask, unsigned& tmask, bool& first, bool act, float* __restrict__ snap) {
 #pragma unroll
-    for (int s = 0; s < S; ++s) { wgj[s] = wg[s * H + j]; wdj[s] = wd[s * H + j]; ta[s] = 0.f; td[s] = 0.f; }
-    float gu = 0.f, gwt = 0.f;
+  for (int e = 5; e >= 0; --e) {   // decreasing time
+    const float t = te[e];
+    unsigned now = 0u;
+#pragma unroll 5
+    for (int j = 0; j < H; ++j) now |= (fmaf(s_wt[j], t, s_ul[j * DPW]) > 0.f) ? (1u << j) : 0u;
+    unsigned flip = (first || !act) ? 0u : (now ^ onmask);
+    while (flip) {   // rare: at most H flips per trajectory
+      const int j = __builtin_ctz(flip);
+      flip &= flip - 1u;
+      float* d = snap + j * 4 * S;
 #pragma unroll
-    for (int e = 0; e < 6; ++e) {
-      const float pre = fmaf(wt, te[e], uj);
-      const float h = fmaxf(pre, 0.f);
-      float gh = 0.f;
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        gh = fmaf(gxa[e][s], wgj[s], gh);
-        gh = fmaf(gxd[e][s], wdj[s], gh);
-        ta[s] = fmaf(gxa[e][s], h, ta[s]);
-        td[s] = fmaf(gxd[e][s], h, td[s]);
-      }
-      gh = pre > 0.f ? gh : 0.f;
-      gu += gh;
-      gwt = fmaf(gh, te[e], gwt);
+      for (int c = 0; c < 2 * S; ++c) { d[c] = RS[c]; d[2 * S + c] = RT[c]; }
+      tmask |= 1u << j;
     }
+    if (act) { onmask = now; first = false; }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      acc[(s * H + j) * DPW] += ta[s];
-      acc[(S * H + s * H + j) * DPW] += td[s];
+      const float ga = act ? gxa[e][s] : 0.f, gd = act ? gxd[e][s] : 0.f;
+      RS[s] += ga; RS[S + s] += gd;
+      RT[s] = fmaf(ga, t, RT[s]); RT[S + s] = fmaf(gd, t, RT[S + s]);
     }
-    acc[(2 * S * H + 2 * S + j) * DPW] += gu;
-    acc[(2 * S * H + 2 * S + H + j) * DPW] += gwt;
-  }
-#pragma unroll
-  for (int s = 0; s < S; ++s) {
-    float a = 0.f, d = 0.f;
-#pragma unroll
-    for (int e = 0; e < 6; ++e) { a += gxa[e][s]; d += gxd[e][s]; }
-    acc[(2 * S * H + s) * DPW] += a;
-    acc[(2 * S * H + S + s) * DPW] += d;
   }
 }
 
@@ -377,6 +368,12 @@ __global__ void __launch_bounds__(DPW) dopri5_bwd_kernel(const DpBK k) {
   float lam[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) lam[s] = 0.f;
+  float RS[2 * S], RT[2 * S];
+#pragma unroll
+  for (int c = 0; c < 2 * S; ++c) { RS[c] = 0.f; RT[c] = 0.f; }
+  unsigned onmask = 0u, tmask = 0u;
+  bool first = true;
+  float* snap = k.snap + (long long)(live ? b : 0) * H * 4 * S;
   int j = T - 1;
   // every lane leaves the loop after max(K) <= kmax iterations
   for (int it = 0; __any(it < K); ++it) {
@@ -505,10 +502,34 @@ __global__ void __launch_bounds__(DPW) dopri5_bwd_kernel(const DpBK k) {
     }
     {
       const float te[6] = {t, t + dt * (1.f / 5), t + dt * (3.f / 10), t + dt * (4.f / 5), t + dt * (8.f / 9), t + dt};
-      accum_step<S, H>(te, s_wt, s_ul, wg, wd, gxa, gxd, acc);
+      sweep_step<S, H>(te, s_wt, s_ul, gxa, gxd, RS, RT, onmask, tmask, first, act, snap);
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) lam[s] = act ? gy[s] : lam[s];
+  }
+  // ---- the units' partial sums -> this trajectory's column of the accumulators (each entry written once) ---------------------------
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's own snapshot stores are back-readable
+#pragma unroll 1
+    for (int jj = 0; jj < H; ++jj) {
+      const bool flipped = (tmask >> jj) & 1u, on_early = (onmask >> jj) & 1u;
+      const float wt = s_wt[jj], uj = s_ul[jj * DPW];
+      float gu = 0.f, gwt = 0.f;
+#pragma unroll
+      for (int c = 0; c < 2 * S; ++c) {
+        const float sm = flipped ? snap[jj * 4 * S + c] : 0.f, st = flipped ? snap[jj * 4 * S + 2 * S + c] : 0.f;
+        // on at early times: flipped ? total - snapshot : total;   off at early times: flipped ? snapshot : 0
+        const float gm = on_early ? RS[c] - sm : sm, gt = on_early ? RT[c] - st : st;
+        const float w = c < S ? wg[c * H + jj] : wd[(c - S) * H + jj];
+        acc[((c < S ? c * H : S * H + (c - S) * H) + jj) * DPW] = fmaf(wt, gt, uj * gm);
+        gu = fmaf(w, gm, gu);
+        gwt = fmaf(w, gt, gwt);
+      }
+      acc[(2 * S * H + 2 * S + jj) * DPW] = gu;
+      acc[(2 * S * H + 2 * S + H + jj) * DPW] = gwt;
+    }
+#pragma unroll
+    for (int c = 0; c < 2 * S; ++c) acc[(2 * S * H + c) * DPW] = RS[c];
   }
   // ---- init net: x0 = sigmoid(W2 relu(W1 z + b1) + b2); the j = 0 output is x0 itself ---------------------------------
   float go[S];
@@ -631,8 +652,9 @@ hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, co
 }
 
 hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay, const float* p, const float* times, const DopriRec& rec,
-                                   const float* gx, float* gz, float* slabs, int slab_stride, int drop_z, hipStream_t stream) {
+                                   const float* gx, float* gz, float* slabs, int slab_stride, int drop_z, float* snap, hipStream_t stream) {
   DpBK k;
+  k.snap = snap;
   k.B = s.B; k.T = s.T; k.L = s.L; k.kmax = rec.kmax; k.drop_z = drop_z;
   k.times = times; k.z = rec.z_out; k.gx = gx; k.rec = rec.rec; k.nrec = rec.nrec;
   k.w1 = p + lay.init_w1; k.b1 = p + lay.init_b1; k.w2 = p + lay.init_w2; k.b2 = p + lay.init_b2;

@@ -433,8 +433,9 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const Tai
   STAMP(20);
   if (with_tail) {
     // Hand-off of the conv rows to the last block to arrive, without a cache-wide release: the rows are stored with agent-scope (sc1,
-    // write-through) stores, drained (s_waitcnt vmcnt(0) ahead of the barrier) before one lane bumps the agent-scope counter; the block
-    // that sees the final count reads them behind an acquire (invalidate-only) fence.
+    // write-through) stores; EVERY storing wave drains them (explicit s_waitcnt vmcnt(0) below: the compiler does not emit one
+    // for a store it has no later use for) ahead of the barrier behind which one lane bumps the agent-scope counter; the block that
+    // sees the final count reads the rows behind an acquire (invalidate-only) fence followed by a workgroup barrier.
     __shared__ int s_last;
     // conv Adam state of the (up to two) elements this lane would finish as part 0 of the last block: fetched now, off the critical path
     constexpr int NCI = 2;
@@ -446,10 +447,14 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const Tai
       const bool on = fast_conv && tl.ad.p != nullptr && (tid & 3) == 0;
       cm[u] = on ? tl.ad.m[ci] : 0.f; cv[u] = on ? tl.ad.v[ci] : 0.f; cp[u] = on ? tl.ad.p[ci] : 0.f;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's sc1 row stores have reached L2 before the counter can move
     __syncthreads();
     if (tid == 0) {
       s_last = (__hip_atomic_fetch_add(tl.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(k.Hc - 1)) ? 1 : 0;
-      if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // invalidate only (no L2 write-back): this CU's L1 serves the whole block
+      if (s_last) {   // invalidate only (no L2 write-back): this CU's L1 serves the whole block; the invalidate has completed (vmcnt)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // before this lane reaches the barrier the other waves load behind
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     STAMP(21);
     if (tl.ad.p != nullptr) {   // meanwhile: Adam on this block's lin.weight row (its weights live in s_wl), two elements in flight

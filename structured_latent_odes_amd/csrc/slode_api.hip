@@ -176,7 +176,7 @@ struct Workspace {
   float *weff, *rowsum, *wprime, *beff, *gslabs, *conv_slabs, *glat, *gslabs2, *gslabs3;  // folded encoder path
   unsigned int* counter;
   // dopri5 training: solution, dLoss/dx, external latent gradient, latent sample, step records
-  float *dp_x, *dp_gx, *dp_gz, *dp_z, *dp_rec;
+  float *dp_x, *dp_gx, *dp_gz, *dp_z, *dp_rec, *dp_snap;
   int* dp_nrec;
   int dp_kmax, dp_rows;
   int gsplit;
@@ -257,6 +257,7 @@ static Workspace carve(slode_handle h, const slode_shape& s_in, const slode_layo
     w.dp_z = take((size_t)s.B * s.L);
     w.dp_nrec = reinterpret_cast<int*>(take((size_t)s.B));
     w.dp_rec = take((size_t)w.dp_kmax * s.B * (s.S + 2));
+    w.dp_snap = take((size_t)s.B * s.H * 4 * s.S);   // running sums parked at the hidden units' switching times (dopri5_kernel.hip)
   }
   w.bytes = o * sizeof(float);
   return w;
@@ -454,7 +455,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
         HIP_TRY(h, e);
         rc.rec = w.dp_rec;
         HIP_TRY(h, slode_launch_dopri5_bwd(*s, *lay, params, times, rc, w.dp_gx, w.dp_gz, w.ode_slabs + (size_t)w.ode_grid * w.ode_stride,
-                                           w.ode_stride, s->grad_mode == SLODE_GRAD_REFERENCE_ADJOINT ? 1 : 0, st));
+                                           w.ode_stride, s->grad_mode == SLODE_GRAD_REFERENCE_ADJOINT ? 1 : 0, w.dp_snap, st));
         a.gx_out = nullptr;
         a.gz_ext = w.dp_gz;
         n_slabs = w.ode_grid + w.dp_rows;

@@ -361,7 +361,7 @@ int slode_dopri5_rows(const slode_shape& s);
 hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const float* z,
                                float* x, hipStream_t stream, const DopriRec* rec = nullptr);
 hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const DopriRec& rec,
-                                   const float* gx, float* gz, float* slabs, int slab_stride, int drop_z, hipStream_t stream);
+                                   const float* gx, float* gz, float* slabs, int slab_stride, int drop_z, float* snap, hipStream_t stream);
 hipError_t slode_launch_adam_k(int64_t n, const float* g, const AdamHost& a, hipStream_t stream);
 hipError_t slode_launch_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2,
                              float eps, int64_t step, hipStream_t stream);

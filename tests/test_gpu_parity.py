@@ -294,7 +294,7 @@ def test_dopri5_forward_solution_level(fam):
         eng.ode_solve_bwd(eng.pack(p), z.to(dev), torch.zeros(B, T, S, device=dev), torch.zeros(eng.n_params, device=dev))
 
 
-@pytest.mark.parametrize("fam,mode", [("cvs", "exact"), ("proc", "exact"), ("cvs", "reference_adjoint")])
+@pytest.mark.parametrize("fam,mode", [("cvs", "exact"), ("proc", "exact"), ("cvs", "reference_adjoint"), ("proc_c2", "exact")])
 def test_dopri5_elbo_step_solution_level(fam, mode):
     """ELBO step with the adaptive solver (BASELINE config[2]): forward solve with recorded steps, reverse mode over the records.
     Parity is at solution level (see test_dopri5_forward_solution_level): -ELBO and every gradient against the fp64 oracle run at tight
@@ -302,7 +302,10 @@ def test_dopri5_elbo_step_solution_level(fam, mode):
     inside the dynamics (oracle solve_ode).  Tolerances: -ELBO 2e-5 relative; gradients: see the bar below."""
     from structured_latent_odes_amd import engine as E
     dev = torch.device("cuda:0")
-    kw = dict(z_g=3, z_eps=2) if fam == "proc" else dict(z_iext=3, z_rtpr=3, z_eps=2)
+    if fam == "proc_c2":                       # BASELINE config[2] as written: proc, latent dim 50 (4 x 10 + 10), T = 100, dopri5
+        fam, kw = "proc", dict(z_g=10, z_eps=10)
+    else:
+        kw = dict(z_g=3, z_eps=2) if fam == "proc" else dict(z_iext=3, z_rtpr=3, z_eps=2)
     S, T, B = (8, 100, 70) if fam == "proc" else (5, 60, 70)       # two 64-lane workgroups, ragged tail
     mk_o, mk_e = (O.proc_spec, E.proc_spec) if fam == "proc" else (O.cvs_spec, E.cvs_spec)
     ospec = mk_o(solver="dopri5", **kw)
@@ -353,6 +356,42 @@ def test_dopri5_elbo_step_solution_level(fam, mode):
     grads2 = torch.zeros_like(grads)
     eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss2, grads=grads2)
     assert torch.equal(grads, grads2)
+
+
+def test_dopri5_config2_full_size_properties():
+    """BASELINE config[2] at full size (proc, B = 4096, T = 100, latent dim 50, dopri5 at torchdiffeq's default tolerances): the
+    size-independent properties of the step -- finite, bitwise reproducible, and additive over trajectories (per-trajectory step-size
+    control: the whole batch equals the sum of its halves up to fp32 summation order)."""
+    from structured_latent_odes_amd import engine as E
+    dev = torch.device("cuda:0")
+    ospec = O.proc_spec(z_g=10, z_eps=10, solver="dopri5")
+    B, T = 4096, 100
+    p = O.init_params(ospec, T=T, S=8)
+    obs, u, eps, times = O.synthetic_batch(ospec, B, T)
+    eng = E.Engine(E.proc_spec(z_g=10, z_eps=10, solver="dopri5"), T, dev)
+    eng.set_times(times)
+    flat = eng.pack(p)
+    obs_d, u_d, eps_d = obs.contiguous().to(dev), u.to(dev), eps.to(dev)
+
+    def run(sl):
+        loss, grads = torch.zeros(1, device=dev), torch.full((eng.n_params,), float("nan"), device=dev)
+        eng.elbo_step(flat, obs_d[sl].contiguous(), u_d[sl].contiguous(), eps_d[sl].contiguous(), loss, grads)
+        return loss.clone(), grads.clone()
+    l_all, g_all = run(slice(0, B))
+    assert torch.isfinite(l_all).all() and torch.isfinite(g_all).all()
+    l_again, g_again = run(slice(0, B))
+    assert torch.equal(l_all, l_again) and torch.equal(g_all, g_again)
+    l_a, g_a = run(slice(0, B // 2))
+    l_b, g_b = run(slice(B // 2, B))
+    assert abs((l_a + l_b - l_all).item()) / abs(l_all.item()) < 1e-6
+    assert ((g_a + g_b - g_all).double().norm() / g_all.double().norm()).item() < 1e-5
+    # 16 of its trajectories against the fp64 oracle (tight tolerances): the loss
+    sl = slice(100, 116)
+    ospec.solver_kw = dict(rtol=1e-8, atol=1e-10, per_trajectory=True)
+    with torch.no_grad():
+        want = O.main_loss({k: v.double() for k, v in p.items()}, ospec, obs[sl].double(), u[sl].double(), eps[sl].double(), times.double())
+    got, _ = run(sl)
+    assert abs(got.item() - want.item()) / abs(want.item()) < 2e-5
 
 
 @pytest.mark.parametrize("layout", ["c_major", "strided"])
