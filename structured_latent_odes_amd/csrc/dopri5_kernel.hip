@@ -300,6 +300,69 @@ __device__ __forceinline__ void coef(float t, const float* __restrict__ s_wt, co
   for (int s = 0; s < S; ++s) { a[s] = sigmoidf_fast(xa[s]); d[s] = sigmoidf_fast(xd[s]); }
 }
 
+// The same structure makes the coefficients cheap to re-evaluate along the sweep: between two evaluation times only the units whose
+// predicate flips change the head pre-activations o_c(t) = bias_c + sum_{j on} W_cj (w_t,j t + u_j), which are linear in t otherwise.
+// The lane carries (value V_c at the last evaluation time tau, slope AL_c, the units' on/off bits): one evaluation = H predicates +
+// 2S fmas (+ 2 x 2S fmas per flipped unit) + 2S sigmoids instead of the H x 2S product; `coef` re-bases it every 16 steps.
+template <int S, int H>
+struct Incr {
+  float V[2 * S], AL[2 * S], tau;
+  unsigned mask;
+};
+template <int S, int H>
+__device__ __forceinline__ void incr_init(Incr<S, H>& st, float t, const float* __restrict__ s_wt, const float* __restrict__ s_ul, cptr wg, cptr bg,
+                                          cptr wd, cptr bd) {
+  asm volatile("" : "+s"(wg), "+s"(wd), "+s"(bg), "+s"(bd));
+#pragma unroll
+  for (int s = 0; s < S; ++s) { st.V[s] = bg[s]; st.V[S + s] = bd[s]; st.AL[s] = 0.f; st.AL[S + s] = 0.f; }
+  unsigned m = 0u;
+#pragma unroll 5
+  for (int j = 0; j < H; ++j) {
+    const float wt = s_wt[j], pre = fmaf(wt, t, s_ul[j * DPW]);
+    const bool on = pre > 0.f;
+    m |= on ? (1u << j) : 0u;
+    const float h = on ? pre : 0.f, hw = on ? wt : 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      st.V[s] = fmaf(wg[s * H + j], h, st.V[s]);
+      st.V[S + s] = fmaf(wd[s * H + j], h, st.V[S + s]);
+      st.AL[s] = fmaf(wg[s * H + j], hw, st.AL[s]);
+      st.AL[S + s] = fmaf(wd[s * H + j], hw, st.AL[S + s]);
+    }
+  }
+  st.mask = m;
+  st.tau = t;
+}
+// moves the state to time t; returns the on/off bits at t;  a = sigmoid(V[0..S)), d = sigmoid(V[S..2S))
+template <int S, int H>
+__device__ __forceinline__ unsigned incr_eval(Incr<S, H>& st, float t, const float* __restrict__ s_wt, const float* __restrict__ s_ul, const float* wgp,
+                                              const float* wdp, float (&a)[S], float (&d)[S]) {
+  unsigned now = 0u;
+#pragma unroll 5
+  for (int j = 0; j < H; ++j) now |= (fmaf(s_wt[j], t, s_ul[j * DPW]) > 0.f) ? (1u << j) : 0u;
+  const float dtau = t - st.tau;
+#pragma unroll
+  for (int c = 0; c < 2 * S; ++c) st.V[c] = fmaf(st.AL[c], dtau, st.V[c]);
+  unsigned flip = now ^ st.mask;
+  while (flip) {   // rare
+    const int j = __builtin_ctz(flip);
+    flip &= flip - 1u;
+    const float wt = s_wt[j], sg = ((now >> j) & 1u) ? 1.f : -1.f;
+    const float pre = sg * fmaf(wt, t, s_ul[j * DPW]), swt = sg * wt;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const float w1 = wgp[s * H + j], w2 = wdp[s * H + j];
+      st.V[s] = fmaf(w1, pre, st.V[s]);     st.AL[s] = fmaf(w1, swt, st.AL[s]);
+      st.V[S + s] = fmaf(w2, pre, st.V[S + s]); st.AL[S + s] = fmaf(w2, swt, st.AL[S + s]);
+    }
+  }
+  st.mask = now;
+  st.tau = t;
+#pragma unroll
+  for (int s = 0; s < S; ++s) { a[s] = sigmoidf_fast(st.V[s]); d[s] = sigmoidf_fast(st.V[S + s]); }
+  return now;
+}
+
 // Weight gradients.  The hidden layer is relu(w_t t + u_j): along the time-ordered sequence of evaluation times (all stages of all
 // accepted steps) unit j is switched on over a prefix or a suffix, so its share of every head-weight gradient is a partial sum of the
 // per-sample head gradients g (and of g t) up to the sample where its predicate fma(w_t, t, u_j) > 0 flips.  The sweep walks the
@@ -312,13 +375,12 @@ __device__ __forceinline__ void coef(float t, const float* __restrict__ s_wt, co
 template <int S, int H>
 __device__ __forceinline__ void sweep_step(const float (&te)[6], const float* __restrict__ s_wt, const float* __restrict__ s_ul,
                                            const float (&gxa)[6][S], const float (&gxd)[6][S], float (&RS)[2 * S], float (&RT)[2 * S],
-                                           unsigned& onmask, unsigned& tmask, bool& first, bool act, float* __restrict__ snap) {
+                                           unsigned& onmask, unsigned& tmask, bool& first, bool act, float* __restrict__ snap,
+                                           const unsigned (&mk)[6]) {
 #pragma unroll
   for (int e = 5; e >= 0; --e) {   // decreasing time
     const float t = te[e];
-    unsigned now = 0u;
-#pragma unroll 5
-    for (int j = 0; j < H; ++j) now |= (fmaf(s_wt[j], t, s_ul[j * DPW]) > 0.f) ? (1u << j) : 0u;
+    const unsigned now = mk[e];
     unsigned flip = (first || !act) ? 0u : (now ^ onmask);
     while (flip) {   // rare: at most H flips per trajectory
       const int j = __builtin_ctz(flip);
@@ -373,6 +435,7 @@ __global__ void __launch_bounds__(DPW) dopri5_bwd_kernel(const DpBK k) {
   for (int c = 0; c < 2 * S; ++c) { RS[c] = 0.f; RT[c] = 0.f; }
   unsigned onmask = 0u, tmask = 0u;
   bool first = true;
+  Incr<S, H> inc;
   float* snap = k.snap + (long long)(live ? b : 0) * H * 4 * S;
   int j = T - 1;
   // every lane leaves the loop after max(K) <= kmax iterations
@@ -388,12 +451,14 @@ __global__ void __launch_bounds__(DPW) dopri5_bwd_kernel(const DpBK k) {
     }
     // stage coefficients at the six distinct stage times (stages 6 and 7 share t + dt) and the stage slopes
     float A[6][S], D[6][S];
-    coef<S, H>(t, s_wt, s_ul, wg, bg, wd, bd, A[0], D[0]);
-    coef<S, H>(t + dt * (1.f / 5), s_wt, s_ul, wg, bg, wd, bd, A[1], D[1]);
-    coef<S, H>(t + dt * (3.f / 10), s_wt, s_ul, wg, bg, wd, bd, A[2], D[2]);
-    coef<S, H>(t + dt * (4.f / 5), s_wt, s_ul, wg, bg, wd, bd, A[3], D[3]);
-    coef<S, H>(t + dt * (8.f / 9), s_wt, s_ul, wg, bg, wd, bd, A[4], D[4]);
-    coef<S, H>(t + dt, s_wt, s_ul, wg, bg, wd, bd, A[5], D[5]);
+    unsigned mk[6];
+    if ((it & 15) == 0) incr_init<S, H>(inc, t, s_wt, s_ul, wg, bg, wd, bd);   // re-base (bounds the drift of the incremental form)
+    mk[0] = incr_eval<S, H>(inc, t, s_wt, s_ul, k.wg, k.wd, A[0], D[0]);
+    mk[1] = incr_eval<S, H>(inc, t + dt * (1.f / 5), s_wt, s_ul, k.wg, k.wd, A[1], D[1]);
+    mk[2] = incr_eval<S, H>(inc, t + dt * (3.f / 10), s_wt, s_ul, k.wg, k.wd, A[2], D[2]);
+    mk[3] = incr_eval<S, H>(inc, t + dt * (4.f / 5), s_wt, s_ul, k.wg, k.wd, A[3], D[3]);
+    mk[4] = incr_eval<S, H>(inc, t + dt * (8.f / 9), s_wt, s_ul, k.wg, k.wd, A[4], D[4]);
+    mk[5] = incr_eval<S, H>(inc, t + dt, s_wt, s_ul, k.wg, k.wd, A[5], D[5]);
     float k1[S], k2[S], k3[S], k4[S], k5[S], k6[S], y2[S], y3[S], y4[S], y5[S], y6[S], y1[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -502,7 +567,7 @@ __global__ void __launch_bounds__(DPW) dopri5_bwd_kernel(const DpBK k) {
     }
     {
       const float te[6] = {t, t + dt * (1.f / 5), t + dt * (3.f / 10), t + dt * (4.f / 5), t + dt * (8.f / 9), t + dt};
-      sweep_step<S, H>(te, s_wt, s_ul, gxa, gxd, RS, RT, onmask, tmask, first, act, snap);
+      sweep_step<S, H>(te, s_wt, s_ul, gxa, gxd, RS, RT, onmask, tmask, first, act, snap, mk);
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) lam[s] = act ? gy[s] : lam[s];
