@@ -183,7 +183,9 @@ def main():
 
     out = {
         "metric": "trajectories/sec ELBO step (CVS, batch=1024, T=200)", "value": value, "unit": "trajectories/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "n_gpus": world, "nranks": world,
+        "backend": ("gloo (rehearsal)" if rehearse else "nccl (RCCL over xGMI)") if world > 1 else "none (single process)",
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         **({"rehearsal": "all ranks on cuda:0 over gloo: NOT a measurement"} if rehearse else {}),
         "config": {"workload": "BASELINE config[1]: synthetic CVS, B=1024/GPU, T=200, C=3, latent_dim=8 (3,3,2), S=5, "

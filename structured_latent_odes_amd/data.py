@@ -30,26 +30,34 @@ import torch
 
 # ---- normalisation -------------------------------------------------------------------------------------------------------------
 def find_norm_params(data: np.ndarray) -> Dict[str, np.ndarray]:
-    """Per-feature statistics over (sample, time) of ``data[N, T, C]`` -- the dict the reference pickles as data_norm_params."""
-    flat = np.asarray(data).reshape(-1, data.shape[2])
-    return {"mean": flat.mean(0), "std": flat.std(0), "max": flat.max(0), "min": flat.min(0)}
+    """Per-feature statistics over (sample, time) of ``data[N, T, C]`` -- the dict the reference pickles as data_norm_params
+    (utils/utils.py:16-35).  Each statistic is taken over the feature's own [N, T] slice, so numpy's summation order -- and with it
+    the last bit of mean / std -- is the reference's."""
+    data = np.asarray(data)
+    per = [data[:, :, c] for c in range(data.shape[2])]
+    stat = lambda fn: np.array([float(fn(x)) for x in per])
+    return {"mean": stat(np.mean), "std": stat(np.std), "max": stat(np.max), "min": stat(np.min)}
 
 
 class NormalizeToUnitSegment:
-    """(x - min) / (max - min) per feature; ``denormalize`` inverts it on ``[B, T, C]`` batches."""
+    """(x - min) / (max - min) per feature; ``denormalize`` inverts it on ``[B, T, C]`` batches.  The reference applies numpy float64
+    scalars to a float32 tensor, feature by feature (utils/ODE_dataset.py:196-209): the range max - min is formed in float64 and only
+    then rounded to float32 -- reproduced here so that the samples are bit-identical to the reference loader's."""
 
     def __init__(self, params):
-        self.min_val = torch.as_tensor(np.asarray(params["min"]), dtype=torch.float32)
-        self.max_val = torch.as_tensor(np.asarray(params["max"]), dtype=torch.float32)
+        lo, hi = np.asarray(params["min"], dtype=np.float64), np.asarray(params["max"], dtype=np.float64)
+        self.min_val = torch.as_tensor(lo, dtype=torch.float32)
+        self.max_val = torch.as_tensor(hi, dtype=torch.float32)
+        self.range = torch.as_tensor(hi - lo, dtype=torch.float32)
 
     def __call__(self, sample: torch.Tensor) -> torch.Tensor:
         out = sample.to(torch.float32).clone()
         c = self.min_val.shape[0]
-        out[..., :c] = (out[..., :c] - self.min_val) / (self.max_val - self.min_val)
+        out[..., :c] = (out[..., :c] - self.min_val) / self.range
         return out
 
     def denormalize(self, batch: torch.Tensor) -> torch.Tensor:
-        return batch * (self.max_val - self.min_val).to(batch.device) + self.min_val.to(batch.device)
+        return batch * self.range.to(batch.device) + self.min_val.to(batch.device)
 
 
 class NormalizeZScore:
@@ -176,71 +184,74 @@ def build_challenge_datasets(pkl_path: str, seed: int, folds: int, split: int) -
 
 
 # ---- proc (plate-reader CSV) -----------------------------------------------------------------------------------------------------
-def _condition(cond: str) -> "OrderedDict[str, float]":
-    """'C6=0.5' or 'C6=0.5;C12=1' -> ordered {name: value}; a string without '=' is an empty condition."""
-    out: "OrderedDict[str, float]" = OrderedDict()
-    if "=" not in str(cond):
-        return out
-    for part in str(cond).split(";"):
-        k, v = part.split("=")
-        out[k] = float(v)
-    return out
-
-
-def _signal_of(header: str) -> str:
-    """'Raw Data (EYFP) 3 - 0 h 23 min' -> 'EYFP': the text inside the first pair of parentheses, or the header itself."""
-    lo = header.find("(")
-    if lo >= 0:
-        hi = header.find(")")
-        if hi >= 0:
-            return header[lo + 1:hi]
-    return header
+def _parse_conditions(cells: Sequence[str]) -> Tuple[List[str], np.ndarray]:
+    """Condition cells ('C6=0.5', 'C6=0.5;C12=1', '' ...) -> (names in first-seen order, values [N, len(names)], absent = 0)."""
+    names: List[str] = []
+    parsed = []
+    for cell in cells:
+        pairs = []
+        if "=" in cell:
+            for item in cell.split(";"):
+                key, val = item.split("=")
+                if key not in names:
+                    names.append(key)
+                pairs.append((key, float(val)))
+        parsed.append(pairs)
+    vals = np.zeros((len(parsed), len(names)))
+    for i, pairs in enumerate(parsed):
+        for key, val in pairs:
+            vals[i, names.index(key)] = val
+    return names, vals
 
 
 def load_proc_csv(path: str, devices: Sequence[str], device_map: Dict[str, float], conditions: Sequence[str], signals: Sequence[str],
                   dtype=np.float32, time_signal: str = "OD"):
     """One plate-reader CSV -> (device ids [N], treatments [N, len(conditions)], times [T], observations [N, len(signals), T]).
-    Layout: columns 0..4 = Content (device), Colony, Well Col, Well Row, Content (condition, 'C6=<float>' ...); then one column per
-    (signal, reading), header 'Raw Data (<signal>) <k> - <h> h <m> min'; the FIRST data row holds the time of every reading column.
-    Kept rows: device in ``devices`` and zero for every condition that is not in ``conditions``; ``times`` are those of the
-    ``time_signal`` block.  Returns None when the file has no row of the requested devices."""
-    import pandas as pd
-    loaded = pd.read_csv(path, sep=",", na_filter=False)
-    timesall = loaded.iloc[0, 5:]
-    rows = loaded.iloc[1:, :]
-    rows = rows.iloc[np.isin(rows.iloc[:, 0], list(devices)), :]
-    conds = [_condition(c) for c in rows.iloc[:, 4]]
-    if len(conds) == 0:
+    File layout (data/proc/load_proc_data.py:69-83): columns 0..4 = device, colony, well column, well row, condition ('C6=<float>',
+    several joined by ';'); then one column per (signal, reading) whose header carries the signal name in parentheses; the first data
+    row holds the time of every reading column.  Kept rows: device in ``devices`` and zero for every condition outside ``conditions``
+    (the reference derives that list of "other" conditions from the first kept row: load_proc_data.py:18-26; same here).  ``times``
+    are those of the ``time_signal`` block.  Returns None when the file has no row of the requested devices.
+    The numeric block is parsed once into one float array and split by boolean column masks."""
+    import csv
+    with open(path, newline="") as fh:
+        table = list(csv.reader(fh))
+    header, time_row, body = table[0], table[1], [r for r in table[2:] if r]
+    body = [r for r in body if r[0] in set(devices)]
+    if not body:
         return None
-    dev = np.array([device_map[d] for d in rows.iloc[:, 0]], dtype=int)
-    keep = [i for i, c in enumerate(conds) if all(v == 0.0 for k, v in c.items() if k not in conditions)]
-    treatments = np.array([[conds[i].get(k, 0.0) for k in conditions] for i in keep])
-    X = rows.iloc[keep, 5:]
-    header_signal = np.array([_signal_of(str(h).split(".")[0]) for h in X.columns.values])
-    obs = np.array([[row.iloc[header_signal == s].values for s in signals] for _, row in X.iterrows()])
-    times = timesall.iloc[header_signal == time_signal].values
+    col_signal = np.array([h[h.find("(") + 1:h.find(")")] if "(" in h and ")" in h[h.find("("):] else h for h in header[5:]])
+    dev = np.array([device_map[r[0]] for r in body], dtype=int)
+    names, vals = _parse_conditions([r[4] for r in body])
+    first_row_names = [n for n, v in zip(names, vals[0]) if ("%s=" % n) in body[0][4]]
+    others = [names.index(n) for n in first_row_names if n not in conditions]
+    keep = np.all(vals[:, others] == 0.0, axis=1) if others else np.ones(len(body), dtype=bool)
+    treatments = np.stack([vals[:, names.index(c)] if c in names else np.zeros(len(body)) for c in conditions], axis=1)[keep]
+    block = np.array([r[5:] for r, k in zip(body, keep) if k], dtype=np.float64)
+    obs = np.stack([block[:, col_signal == sig] for sig in signals], axis=1)
+    times = np.array(time_row[5:], dtype=np.float64)[col_signal == time_signal]
     return dev[keep], treatments.astype(dtype), times.astype(dtype), obs.astype(dtype)
 
 
 def merge_observations(times_list, observations_list):
-    """Align several files on the time grid of the file with the FEWEST series (nearest reading), then stack the series."""
-    loc = int(np.argmin([len(o) for o in observations_list]))
-    chosen = times_list[loc]
-    aligned = []
+    """Several files -> one array on a common time grid: the grid of the file with the fewest series; every other file contributes, for
+    each grid time, its reading nearest in time (first one on ties)  (utils/proc_dataset.py:11-26)."""
+    grid = np.asarray(times_list[int(np.argmin([len(o) for o in observations_list]))])
+    picked = []
     for t, obs in zip(times_list, observations_list):
-        locs = [int(np.abs(np.asarray(t) - ti).argmin()) for ti in chosen]
-        aligned.append(obs[:, :, locs])
-    return chosen, np.vstack(aligned)
+        nearest = np.abs(np.asarray(t)[None, :] - grid[:, None]).argmin(axis=1)
+        picked.append(obs[:, :, nearest])
+    return grid, np.concatenate(picked, axis=0)
 
 
 def scale_data(X: np.ndarray, normalize=None, subtract_background: bool = False):
-    """Each signal divided by its maximum over the data set (or by ``normalize[i]``); optionally every series shifted to min 0."""
+    """Every signal divided by its maximum over the whole data set (or by ``normalize[i]``), then -- optionally -- every series shifted
+    so that its smallest value is 0  (utils/proc_dataset.py:37-50).  Returns (scaled copy, scales)."""
     X = np.array(X, copy=True)
-    scales = [np.max(X[:, i, :]).astype(np.float32) for i in range(X.shape[1])] if normalize is None else list(normalize)
-    for i, sc in enumerate(scales):
-        X[:, i, :] /= sc
-        if subtract_background:
-            X[:, i, :] -= np.min(X[:, i, :], axis=1)[:, np.newaxis]
+    scales = [m for m in X.max(axis=(0, 2)).astype(np.float32)] if normalize is None else list(normalize)
+    X /= np.asarray(scales, dtype=X.dtype)[None, :, None]
+    if subtract_background:
+        X -= X.min(axis=2, keepdims=True)
     return X, scales
 
 
