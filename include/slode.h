@@ -169,6 +169,22 @@ int slode_ode_solve_bwd(slode_handle h, const slode_shape* s, const slode_layout
 int slode_dynamics_eval(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, float t,
                         const float* state, const float* z, float* out, void* stream);
 
+/* OdeModel.initialize_state (models/blackbox_ode.py:19-22, 32-34): z[B,L] -> x0[B,S] = sigmoid(W2 relu(W1 z + b1) + b2). */
+int slode_initialize_state(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* z, float* x0,
+                           void* stream);
+
+/* The conditional prior nets p(z_g | u_g) (EncoderMLP([u_dim, [z_dim, z_dim]], [None, Exp]).forward; call sites
+ * models/mechanistic_cvs.py:225-237, 304-311 (prior reconstructions)): u[B,n_u] -> loc, scale [B,L]; latent dims outside every group get
+ * loc 0, scale 1 (the N(0,1) prior of z_epsilon). */
+int slode_prior_nets(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* u, float* loc,
+                     float* scale, void* stream);
+
+/* The label heads q(label | z_g) (EncoderMLP([z_dim, U, u_dim]).forward; call sites: classifier / pred_inputs,
+ * models/mechanistic_cvs.py:278-296, mechanistic_proc.py:361-380): z[B,L] -> out[B,n_u], every head writing the label columns it scores:
+ * Bernoulli probabilities (SIGMOID), class probabilities (SOFTMAX) or the Laplace location exp(.) (EXPEXP). */
+int slode_label_heads(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* z, float* out,
+                      void* stream);
+
 /* Decoder.forward / GaussianDecoder.forward heads (models/decoders.py:45-53, 86-89) on a given trajectory:
  * x[B,T,S] -> mu[Q][B,C,T] (Q = 3: mu_50, mu_75, mu_25 in that order; Q = 1: mean) and std[C,T] = softplus(constant_std). */
 int slode_decode_heads(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params,

@@ -120,6 +120,84 @@ __global__ void dynamics_eval_kernel(const float* __restrict__ params, int wh, i
   }
 }
 
+// Eval-side small nets, thread per trajectory (the training path evaluates the same nets inside the fused kernels).
+// x0 = sigmoid(W2 relu(W1 z + b1) + b2): OdeModel.initialize_state (models/blackbox_ode.py:19-22, 32-34).
+__global__ void init_state_kernel(const float* __restrict__ params, int w1, int b1, int w2, int b2, int B, int L, int S, int H,
+                                  const float* __restrict__ z, float* __restrict__ x0) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float h[SLODE_MAX_H];
+  for (int j = 0; j < H; ++j) {
+    float pre = params[b1 + j];
+    for (int l = 0; l < L; ++l) pre = fmaf(params[w1 + j * L + l], z[(long long)b * L + l], pre);
+    h[j] = fmaxf(pre, 0.f);
+  }
+  for (int s = 0; s < S; ++s) {
+    float o = params[b2 + s];
+    for (int j = 0; j < H; ++j) o = fmaf(params[w2 + s * H + j], h[j], o);
+    x0[(long long)b * S + s] = sigmoidf_fast(o);
+  }
+}
+
+// Conditional priors p(z_g | u_g) = N(W_loc u_g + b_loc, exp(W_ls u_g + b_ls)) (EncoderMLP([u_dim, [z_dim, z_dim]], [None, Exp]);
+// models/mechanistic_cvs.py:88-100, 225-237); latent dims outside every group: N(0, 1).  loc, scale [B, L].
+struct PriorK { int n_groups; slode_group grp[SLODE_MAX_GROUPS]; int ploc_w[SLODE_MAX_GROUPS], ploc_b[SLODE_MAX_GROUPS], pls_w[SLODE_MAX_GROUPS], pls_b[SLODE_MAX_GROUPS]; };
+__global__ void prior_nets_kernel(const float* __restrict__ params, const PriorK k, int B, int L, int nu, const float* __restrict__ u,
+                                  float* __restrict__ loc, float* __restrict__ scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * L) return;
+  const int b = i / L, l = i - b * L;
+  float pl = 0.f, sc = 1.f;
+  for (int g = 0; g < k.n_groups; ++g) {
+    const slode_group gr = k.grp[g];
+    if (l >= gr.z_off && l < gr.z_off + gr.z_dim) {
+      const int ll = l - gr.z_off;
+      float a = params[k.ploc_b[g] + ll], c = params[k.pls_b[g] + ll];
+      for (int q = 0; q < gr.u_dim; ++q) {
+        const float uv = u[(long long)b * nu + gr.u_off + q];
+        a = fmaf(params[k.ploc_w[g] + ll * gr.u_dim + q], uv, a);
+        c = fmaf(params[k.pls_w[g] + ll * gr.u_dim + q], uv, c);
+      }
+      pl = a; sc = expf(c);
+    }
+  }
+  loc[i] = pl; scale[i] = sc;
+}
+
+// Label heads q(label | z_g): Linear -> Softplus -> Linear -> Sigmoid | Softmax | Exp (the first of the two Exp heads), written into the
+// label columns they score: out[B, n_u]  (classifier / pred_inputs: models/mechanistic_cvs.py:278-296, mechanistic_proc.py:361-380).
+struct LabelK { int n_aux, U; slode_aux aux[SLODE_MAX_AUX]; int w1[SLODE_MAX_AUX], b1[SLODE_MAX_AUX], w2[SLODE_MAX_AUX], b2[SLODE_MAX_AUX]; };
+__global__ void label_heads_kernel(const float* __restrict__ params, const LabelK k, int B, int L, int nu, const float* __restrict__ z,
+                                   float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * k.n_aux) return;
+  const int b = i / k.n_aux, hd = i - b * k.n_aux;
+  const slode_aux ax = k.aux[hd];
+  float h[32];
+  for (int j = 0; j < k.U; ++j) {
+    float pre = params[k.b1[hd] + j];
+    for (int l = 0; l < ax.z_dim; ++l) pre = fmaf(params[k.w1[hd] + j * ax.z_dim + l], z[(long long)b * L + ax.z_off + l], pre);
+    h[j] = softplusf(pre);
+  }
+  float o[8], mx = -3.0e38f;
+  for (int q = 0; q < ax.u_dim; ++q) {
+    float a = params[k.b2[hd] + q];
+    for (int j = 0; j < k.U; ++j) a = fmaf(params[k.w2[hd] + q * k.U + j], h[j], a);
+    o[q] = a;
+    mx = fmaxf(mx, a);
+  }
+  float se = 0.f;
+  if (ax.kind == SLODE_AUX_SOFTMAX)
+    for (int q = 0; q < ax.u_dim; ++q) se += expf(o[q] - mx);
+  for (int q = 0; q < ax.u_dim; ++q) {
+    float v;
+    if (ax.kind == SLODE_AUX_SIGMOID) v = 1.f / (1.f + expf(-o[q]));
+    else if (ax.kind == SLODE_AUX_SOFTMAX) v = expf(o[q] - mx) / se;
+    else v = expf(o[q]);
+    out[(long long)b * nu + ax.u_off + q] = v;
+  }
+}
+
 // torch.optim.Adam single-tensor update (amsgrad=False, weight_decay=0, maximize=False) as applied per parameter by
 // pyro.optim.Adam (training_cvs.py:226-227): exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v + (1-b2) g*g;
 // denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m/denom.
@@ -205,4 +283,35 @@ hipError_t slode_launch_adam(int64_t n, float* p, const float* g, float* m, floa
                              int64_t step, hipStream_t stream) {
   const AdamHost a{p, m, v, lr, b1, b2, eps, step, n};
   return slode_launch_adam_k(n, g, a, stream);
+}
+
+hipError_t slode_launch_init_state(const slode_shape& s, const slode_layout& lay, const float* params, const float* z, float* x0, hipStream_t stream) {
+  hipLaunchKernelGGL(init_state_kernel, dim3((s.B + 63) / 64), dim3(64), 0, stream, params, lay.init_w1, lay.init_b1, lay.init_w2, lay.init_b2,
+                     s.B, s.L, s.S, s.H, z, x0);
+  return hipGetLastError();
+}
+
+hipError_t slode_launch_prior_nets(const slode_shape& s, const slode_layout& lay, const float* params, const float* u, float* loc, float* scale,
+                                   hipStream_t stream) {
+  PriorK k{};
+  k.n_groups = s.n_groups;
+  for (int g = 0; g < s.n_groups; ++g) {
+    k.grp[g] = s.groups[g];
+    k.ploc_w[g] = lay.ploc_w[g]; k.ploc_b[g] = lay.ploc_b[g]; k.pls_w[g] = lay.pls_w[g]; k.pls_b[g] = lay.pls_b[g];
+  }
+  const int n = s.B * s.L;
+  hipLaunchKernelGGL(prior_nets_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, params, k, s.B, s.L, s.n_u, u, loc, scale);
+  return hipGetLastError();
+}
+
+hipError_t slode_launch_label_heads(const slode_shape& s, const slode_layout& lay, const float* params, const float* z, float* out, hipStream_t stream) {
+  LabelK k{};
+  k.n_aux = s.n_aux; k.U = s.U;
+  for (int a = 0; a < s.n_aux; ++a) {
+    k.aux[a] = s.aux[a];
+    k.w1[a] = lay.aux_w1[a]; k.b1[a] = lay.aux_b1[a]; k.w2[a] = lay.aux_w2[a]; k.b2[a] = lay.aux_b2[a];
+  }
+  const int n = s.B * s.n_aux;
+  hipLaunchKernelGGL(label_heads_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, params, k, s.B, s.L, s.n_u, z, out);
+  return hipGetLastError();
 }

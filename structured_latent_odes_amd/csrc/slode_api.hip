@@ -572,6 +572,34 @@ int slode_dynamics_eval(slode_handle h, const slode_shape* s, const slode_layout
   return SLODE_OK;
 }
 
+int slode_initialize_state(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* z, float* x0,
+                           void* stream) {
+  const char* why = check_common(h, s, lay, params);
+  if (why) return fail(h, SLODE_EINVAL, "%s", why);
+  if (!z || !x0) return fail(h, SLODE_EINVAL, "z / x0 is NULL");
+  HIP_TRY(h, slode_launch_init_state(*s, *lay, params, z, x0, (hipStream_t)stream));
+  return SLODE_OK;
+}
+
+int slode_prior_nets(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* u, float* loc,
+                     float* scale, void* stream) {
+  const char* why = check_common(h, s, lay, params);
+  if (why) return fail(h, SLODE_EINVAL, "%s", why);
+  if (!loc || !scale || (s->n_groups > 0 && !u)) return fail(h, SLODE_EINVAL, "u / loc / scale is NULL");
+  HIP_TRY(h, slode_launch_prior_nets(*s, *lay, params, u, loc, scale, (hipStream_t)stream));
+  return SLODE_OK;
+}
+
+int slode_label_heads(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* z, float* out,
+                      void* stream) {
+  const char* why = check_common(h, s, lay, params);
+  if (why) return fail(h, SLODE_EINVAL, "%s", why);
+  if (!z || !out) return fail(h, SLODE_EINVAL, "z / out is NULL");
+  if (s->n_aux < 1) return fail(h, SLODE_EINVAL, "the shape has no label heads");
+  HIP_TRY(h, slode_launch_label_heads(*s, *lay, params, z, out, (hipStream_t)stream));
+  return SLODE_OK;
+}
+
 int slode_adam_region(slode_handle h, int64_t lo, int64_t hi, int64_t step_delta) {
   if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
   if (lo < 0 || hi < lo || hi > 0x7fffffff) return fail(h, SLODE_EINVAL, "bad Adam region [%lld, %lld)", (long long)lo, (long long)hi);

@@ -352,6 +352,10 @@ hipError_t slode_launch_reduce(const ReduceLaunch& a, hipStream_t stream);
 hipError_t slode_launch_stage_times(const slode_shape& s, const float* times, float* stage_t, hipStream_t stream);
 hipError_t slode_launch_decode_heads(const slode_shape& s, const slode_layout& lay, const float* params,
                                      const float* x, float* mu, float* std_ct, hipStream_t stream);
+hipError_t slode_launch_init_state(const slode_shape& s, const slode_layout& lay, const float* params, const float* z, float* x0, hipStream_t stream);
+hipError_t slode_launch_prior_nets(const slode_shape& s, const slode_layout& lay, const float* params, const float* u, float* loc, float* scale,
+                                   hipStream_t stream);
+hipError_t slode_launch_label_heads(const slode_shape& s, const slode_layout& lay, const float* params, const float* z, float* out, hipStream_t stream);
 hipError_t slode_launch_dynamics_eval(const slode_shape& s, const slode_layout& lay, const float* params, float t,
                                       const float* state, const float* z, float* out, hipStream_t stream);
 // adaptive solve with step records (training): z = loc + scale * eps is formed in the kernel and written to z_out

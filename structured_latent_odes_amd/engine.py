@@ -283,6 +283,32 @@ class Engine:
             self._p(self._f32(z, "z")), self._p(out), self._stream()))
         return out
 
+    def initialize_state(self, params, z):
+        """OdeModel.initialize_state: z [B, L] -> x0 [B, S] (one small HIP kernel, no solve)."""
+        B = z.shape[0]
+        x0 = torch.empty(B, self.spec.ode_state_dim, dtype=torch.float32, device=self.device)
+        _check(self.lib, self.handle, self.lib.slode_initialize_state(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._f32(z, "z")), self._p(x0), self._stream()))
+        return x0
+
+    def prior_nets(self, params, u):
+        """Conditional priors: u [B, n_u] -> (loc, scale) [B, L]; dims outside every conditional group: (0, 1)."""
+        B = u.shape[0]
+        loc = torch.empty(B, self.spec.latent_dim, dtype=torch.float32, device=self.device)
+        scale = torch.empty_like(loc)
+        _check(self.lib, self.handle, self.lib.slode_prior_nets(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._f32(u, "u")), self._p(loc), self._p(scale),
+            self._stream()))
+        return loc, scale
+
+    def label_heads(self, params, z):
+        """Label heads q(label | z_g): z [B, L] -> [B, n_u] probabilities / Laplace locations in the label columns they score."""
+        B = z.shape[0]
+        out = torch.zeros(B, self.spec.n_u, dtype=torch.float32, device=self.device)
+        _check(self.lib, self.handle, self.lib.slode_label_heads(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._f32(z, "z")), self._p(out), self._stream()))
+        return out
+
     def decode_heads(self, params, x):
         B = x.shape[0]
         sp = self.spec

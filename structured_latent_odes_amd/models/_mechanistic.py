@@ -144,13 +144,10 @@ class MechanisticBase(nn.Module):
         return [self.latent_dim - self.z_epsilon_dim, self.z_epsilon_dim]        # z_u, z_epsilon
 
     def _prior_loc_scale(self, labels: Dict[str, torch.Tensor]):
-        locs, scales = [], []
-        for attr, lnames, _ in self.PRIORS:
-            u = torch.cat([labels[l].reshape(labels[l].shape[0], -1) for l in lnames], dim=1)
-            loc, scale = getattr(self, attr)(u)
-            locs.append(loc)
-            scales.append(scale)
-        return torch.cat(locs, 1), torch.cat(scales, 1)
+        """(loc, scale) [B, L] of p(z | labels): the conditional prior nets on the label columns, N(0, 1) for the z_epsilon dims -- one
+        HIP kernel (``slode_prior_nets``), the same nets the fused ELBO kernel evaluates in its P0 phase."""
+        b = self._bind()
+        return b.engine.prior_nets(b.flat, self.labels_to_u(**labels))
 
     def _z_group(self, t: torch.Tensor, g: str) -> torch.Tensor:
         return t[:, self.z_off[g]:self.z_off[g] + self.z_dims[g]]
@@ -179,25 +176,25 @@ class MechanisticBase(nn.Module):
         return None
 
     # ---- eval-side API -------------------------------------------------------------------
-    def _aux_probs(self, z: torch.Tensor):
-        out = {}
-        for attr, group, label, kind in self.AUX:
-            out[label] = (getattr(self, attr)(self._z_group(z, group)), kind)
-        return out
-
     def _predict_labels(self, observations):
-        self._bind()
+        """classifier / pred_inputs of the reference (mechanistic_cvs.py:278-296): encoder -> one posterior draw -> label heads
+        (``slode_label_heads``: every head writes the label columns it scores) -> hard decisions."""
+        b = self._bind()
         with torch.no_grad():
             loc, scale = self.encoder.forward(observations)
             z = torch.normal(loc, scale)
+            probs = b.engine.label_heads(b.flat, z.contiguous())
             res = {}
-            for label, (val, kind) in self._aux_probs(z).items():
+            heads = {h.prefix: h for h in b.engine.spec.aux_heads}
+            for attr, group, label, kind in self.AUX:
+                head = heads[attr]
+                val = probs[:, head.u_off:head.u_off + head.u_dim]
                 if kind == "sigmoid":
                     res[label] = (val > 0.5).float()
                 elif kind == "softmax":
                     res[label] = torch.zeros_like(val).scatter_(1, val.argmax(1, keepdim=True), 1.0)
                 else:
-                    res[label] = val[0]
+                    res[label] = val.clone()
             return res
 
     def recon(self, observations, is_post, **labels):
@@ -208,11 +205,8 @@ class MechanisticBase(nn.Module):
                 loc, scale = self.encoder.forward(observations)
                 z = torch.normal(loc, scale)
             else:
-                B = observations.shape[0]
-                ploc, pscale = self._prior_loc_scale(labels)
-                z_u = torch.normal(ploc, pscale)
-                z_eps = torch.randn(B, self.z_epsilon_dim, device=ploc.device)
-                z = torch.cat((z_u, z_eps), dim=1)
+                ploc, pscale = self._prior_loc_scale(labels)      # [B, L]: conditional groups, then (0, 1) for z_epsilon
+                z = torch.normal(ploc, pscale)
             if self.GAUSS:
                 solution_xt, mean, std = self.decoder.forward(z=z)
                 return {"l1": self.l1_func(mean, observations), "solution_xt": solution_xt, "mean": mean, "std": std, "z": z}
@@ -233,9 +227,7 @@ class MechanisticBase(nn.Module):
             if is_post:
                 loc, scale = self.encoder.forward(observations)
             else:
-                ploc, pscale = self._prior_loc_scale(labels)
-                zeros = torch.zeros(B, self.z_epsilon_dim, device=ploc.device)
-                loc, scale = torch.cat((ploc, zeros), 1), torch.cat((pscale, torch.ones_like(zeros)), 1)
+                loc, scale = self._prior_loc_scale(labels)
             if eps is None:
                 eps = torch.randn(ns, B, loc.shape[1], device=loc.device)
             z = loc.unsqueeze(0) + scale.unsqueeze(0) * eps.to(loc.device)               # [ns, B, L]

@@ -118,7 +118,10 @@ class OdeModel(nn.Module):
 
     def initialize_state(self, z):
         """x0 = sigmoid(W2 relu(W1 z + b1) + b2) (blackbox_ode.py:32-34) = the first grid point of the solve."""
-        return self.solve_ODE(z)[:, 0, :]
+        b = self._binding_or_raise()
+        if torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in self._param_list())):
+            return self.solve_ODE(z)[:, 0, :]           # differentiable route: the first grid point of the (autograd-wrapped) solve
+        return b.engine.initialize_state(b.flat, z.to(torch.float32).contiguous())
 
     def solve_ODE(self, z):
         """[B, L] -> [B, T, S] (blackbox_ode.py:36-47)."""

@@ -1,7 +1,8 @@
 """Shared body of the three entry points (training_cvs.py / training_proc.py / training_challenge.py of the reference):
 ``train(config)`` with the reference's structure -- two SVI objects sharing one Adam (training_cvs.py:226-249), an epoch loop of
-``run_batch`` (:147-157, :256-266), validation with ``evaluate_loss`` + ``recon`` + label prediction (:43-144), best-model copy
-(:325-331) and the per-epoch summary line (:336-352).  Batches come from ``synthetic.synthetic_batch`` unless ``--data-dir`` points at
+``run_batch`` (:147-157, :256-266), the four statistics passes per epoch (validation / training x posterior / prior: ``evaluate_loss`` +
+``recon`` + label prediction, :43-144, :270-315), best-model copy (:325-331), the per-epoch summary line (:336-352) and the final
+test passes on the best model (:355-397).  Batches come from ``synthetic.synthetic_batch`` unless ``--data-dir`` points at
 the reference's data files (cvs: ``processed_data.pkl`` ...; challenge: ``data.pkl``; proc: the plate-reader CSVs), which are then read by ``data.py`` (SURVEY row
 N3) and fed through pinned host buffers, or the caller passes its own list of batch dicts."""
 from __future__ import annotations
@@ -70,7 +71,8 @@ def make_batches(config, family: str, n_batches: int, seed: int):
 
 
 def train(config, family: str, model_cls, model_cls_gauss, batches_per_epoch: int = 7,
-          train_batches: Optional[Sequence[dict]] = None, val_batches: Optional[Sequence[dict]] = None, times: Optional[torch.Tensor] = None):
+          train_batches: Optional[Sequence[dict]] = None, val_batches: Optional[Sequence[dict]] = None, times: Optional[torch.Tensor] = None,
+          test_batches: Optional[Sequence[dict]] = None):
     set_seed(config.seed)
     device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
     if times is not None:
@@ -98,12 +100,17 @@ def train(config, family: str, model_cls, model_cls_gauss, batches_per_epoch: in
     # batch sources may be lists or re-iterable feeders (data.BatchFeeder: a fresh pass, reshuffled, every epoch)
     train_b = train_batches if train_batches is not None else make_batches(config, family, batches_per_epoch, seed=1000)
     val_b = val_batches if val_batches is not None else make_batches(config, family, 1, seed=5000)
+    test_b = test_batches if test_batches is not None else val_b          # cvs ships a test split; challenge / proc test on the validation fold
     best_val_loss, best_epoch = np.inf, 0
     names = FAMILY_LABELS[family][:2]
     for epoch in range(config.num_epochs + 1):
         epoch_loss = [run_batch(batch_to_device(b, device, family), losses) for b in train_b]
+        # the reference's four statistics passes per epoch (training_cvs.py:270-315): validation posterior / prior, training
+        # posterior / prior -- every one a full pass over its loader: evaluate_loss of both SVI objects, recon, label prediction
         val = input_pred_stats(val_b, var_model, losses, True, device, family)
-        trn = input_pred_stats([next(iter(train_b))], var_model, losses, True, device, family)
+        _ = input_pred_stats(val_b, var_model, losses, False, device, family)
+        trn = input_pred_stats(train_b, var_model, losses, True, device, family)
+        trn_prior = input_pred_stats(train_b, var_model, losses, False, device, family)
         val_elbo = torch.sum(val["elbo"]) * len(val["elbo"])
         improved = ""
         if best_val_loss >= val_elbo:
@@ -114,6 +121,16 @@ def train(config, family: str, model_cls, model_cls_gauss, batches_per_epoch: in
             val[names[1]], trn["l1"], val["l1"], improved)
         print(line)
         logging.debug(line)
+    # final test passes on the best model, posterior and prior (training_cvs.py:355-397); the losses stay bound to var_model, as there
+    test_post = input_pred_stats(test_b, best_model, losses, True, device, family)
+    test_prior = input_pred_stats(test_b, best_model, losses, False, device, family)
+    final = "FINAL TEST: %s_acc=(%.4f,%.4f)  %s_acc=(%.4f,%.4f) l1=(%.6f,%.6f)" % (
+        names[0], test_post[names[0]], test_prior[names[0]], names[1], test_post[names[1]], test_prior[names[1]], test_post["l1"], test_prior["l1"])
+    print(final)
+    logging.debug(final)
+    tail = "ELBO: best_epoch: {} post: {} prior: {}".format(best_epoch, test_post["elbo"], test_prior["elbo"])
+    print(tail)
+    logging.debug(tail)
     return var_model, best_model, best_epoch
 
 
@@ -126,6 +143,7 @@ def real_batches(config, family: str, data_dir: str):
         tf = D.create_transforms(config.norm, D._torch_load(os.path.join(data_dir, "data_norm_params.pkl")))
         tr = D.CVSDataset(data_dir, "train", config.seq_len, False, tf)
         va = D.CVSDataset(data_dir, "val", config.seq_len, False, tf)
+        te = D.CVSDataset(data_dir, "test", config.seq_len, False, tf)
     elif family == "challenge":
         pair = D.build_challenge_datasets(os.path.join(data_dir, "data.pkl"), config.seed, config.folds, config.split)
         tf = D.create_transforms(config.norm, pair.data_norm_params)
@@ -149,8 +167,11 @@ def real_batches(config, family: str, data_dir: str):
                 b["observations"] = b["observations"].permute(0, 2, 1)
                 yield b
 
-    return (_AsBCT(D.BatchFeeder(tr, config.mini_batch_size, dev, shuffle=True, seed=config.seed)),
-            _AsBCT(D.BatchFeeder(va, config.mini_batch_size, dev)), None)
+    out = (_AsBCT(D.BatchFeeder(tr, config.mini_batch_size, dev, shuffle=True, seed=config.seed)),
+           _AsBCT(D.BatchFeeder(va, config.mini_batch_size, dev)), None)
+    if family == "cvs":
+        out = out + (_AsBCT(D.BatchFeeder(te, config.mini_batch_size, dev)),)
+    return out
 
 
 def main(family: str, load_config, model_cls, model_cls_gauss):
@@ -166,5 +187,8 @@ def main(family: str, load_config, model_cls, model_cls_gauss):
     logging.basicConfig(filename="results_%s/model.log" % config.model, filemode="w", level=logging.DEBUG)
     kw = {}
     if a.data_dir:
-        kw["train_batches"], kw["val_batches"], kw["times"] = real_batches(config, family, a.data_dir)
+        got = real_batches(config, family, a.data_dir)
+        kw["train_batches"], kw["val_batches"], kw["times"] = got[:3]
+        if len(got) > 3:
+            kw["test_batches"] = got[3]
     train(config, family, model_cls, model_cls_gauss, a.batches_per_epoch, **kw)

@@ -412,3 +412,64 @@ def dopri5_backward(p, z, times, recs, gx, drop_z=False):
          _O + "latent_to_ode_net.0.weight": GW1, _O + "latent_to_ode_net.0.bias": Gb1,
          _O + "latent_to_ode_net.2.weight": GW2, _O + "latent_to_ode_net.2.bias": Gb2}
     return gz, g
+
+
+# ---- round-2 algorithms of csrc/ode_kernel.hip (ALG 0) in numpy fp64 ---------------------------------------------------------------
+def switching_indices(wt, u, ts):
+    """Per hidden unit: (ms, sf).  relu(wt t + u) is on exactly where wt*t + u > 0; along a monotone table that predicate flips at
+    most once:  sf = 1: on for m >= ms (ms = 0 always, ms = nt never);  sf = 0: on for m < ms  (P0b of the kernel)."""
+    nt = ts.shape[0]
+    ms, sf = np.zeros(wt.shape[0], int), np.ones(wt.shape[0], int)
+    for j in range(wt.shape[0]):
+        pred = wt[j] * ts + u[j] > 0
+        assert (np.diff(pred.astype(int)) != 0).sum() <= 1, "predicate must flip at most once along a monotone table"
+        if pred[0] == pred[-1]:
+            ms[j] = 0 if pred[0] else nt
+        else:
+            ms[j], sf[j] = int(np.argmax(pred != pred[0])), int(pred[-1])
+    return ms, sf
+
+
+def pwl_heads(wt, u, W, bias, ts):
+    """Head pre-activations o[m, c] = bias_c + sum_j W[c, j] relu(wt_j ts[m] + u_j) from the piecewise-linear table of P0c / P1:
+    row k = [value at the k-th segment's first stage time | slope], events in (switching index, unit) order."""
+    H, nt = wt.shape[0], ts.shape[0]
+    ms, sf = switching_indices(wt, u, ts)
+    order = sorted(range(H), key=lambda j: (ms[j], j))
+    tau = [ts[0]] + [ts[min(ms[j], nt - 1)] for j in order]
+    on0 = sf == 0
+    al = (W[:, on0] * wt[on0]).sum(1)
+    V = bias + (W[:, on0] * (wt[on0] * ts[0] + u[on0])).sum(1)
+    rows = [(V.copy(), al.copy())]
+    for k, j in enumerate(order):
+        sw = (1.0 if sf[j] else -1.0) * W[:, j]
+        V = V + al * (tau[k + 1] - tau[k]) + sw * (wt[j] * tau[k + 1] + u[j])
+        al = al + sw * wt[j]
+        rows.append((V.copy(), al.copy()))
+    ps = np.array(sorted(ms))
+    out = np.empty((nt, W.shape[0]))
+    for m in range(nt):
+        k = int(np.searchsorted(ps, m, side="right"))
+        out[m] = rows[k][0] + rows[k][1] * (ts[m] - tau[k])
+    return out
+
+
+def contraction_by_switching_sums(wt, u, W, g, ts, n_chunks=25):
+    """P6: from the per-sample head gradients g[m, c] to (dW[c, j], dbias[c], dLoss/du_j, dLoss/dwt_j) through chunk sums and each
+    unit's switching index -- no per-sample x per-unit work."""
+    H, nt, NC = wt.shape[0], ts.shape[0], g.shape[1]
+    ms, sf = switching_indices(wt, u, ts)
+    CL = (nt + n_chunks - 1) // n_chunks
+    cg = np.zeros((n_chunks, NC)); cgt = np.zeros((n_chunks, NC))
+    for q in range(n_chunks):
+        sl = slice(q * CL, min(nt, (q + 1) * CL))
+        cg[q], cgt[q] = g[sl].sum(0), (g[sl] * ts[sl, None]).sum(0)
+    GM, GT = np.zeros((NC, H)), np.zeros((NC, H))
+    for j in range(H):
+        qs = ms[j] // CL
+        whole = range(qs + 1, n_chunks) if sf[j] else range(0, min(qs, n_chunks))
+        cut = range(ms[j], min(nt, (qs + 1) * CL)) if sf[j] else range(qs * CL, ms[j])
+        GM[:, j] = sum(cg[q] for q in whole) + sum(g[m] for m in cut)
+        GT[:, j] = sum(cgt[q] for q in whole) + sum(g[m] * ts[m] for m in cut)
+    dW = wt[None, :] * GT + u[None, :] * GM
+    return dW, cg.sum(0), (W * GM).sum(0), (W * GT).sum(0)

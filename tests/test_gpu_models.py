@@ -246,12 +246,12 @@ def test_training_on_reference_format_files(tmp_path):
     torch.save(find_norm_params(obs["train"]), d + "data_norm_params.pkl")
     cfg = training_cvs.load_config()
     cfg.num_epochs, cfg.mini_batch_size = 1, 24
-    trb, vab, _ = TR.real_batches(cfg, "cvs", d)
-    assert len(trb) == 3 and len(vab) == 1                       # 63 train / 7 val series
+    trb, vab, _, teb = TR.real_batches(cfg, "cvs", d)
+    assert len(trb) == 3 and len(vab) == 1 and len(teb) == 1     # 63 train / 7 val / 9 test series
     b0 = next(iter(trb))
     assert b0["observations"].is_cuda and b0["observations"].shape == (24, 3, 86) and b0["observations"].stride() == (258, 1, 3)   # [B,C,T] view of [B,T,C]
-    assert 0.0 <= float(b0["observations"].min()) and float(b0["observations"].max()) <= 1.0
-    vm, bm, be = training_cvs.train(cfg, train_batches=trb, val_batches=vab)
+    assert -1e-6 <= float(b0["observations"].min()) and float(b0["observations"].max()) <= 1.0 + 1e-6
+    vm, bm, be = training_cvs.train(cfg, train_batches=trb, val_batches=vab, test_batches=teb)   # incl. the final test passes
     assert all(torch.isfinite(p).all() for p in vm.parameters())
     with open(d + "data.pkl", "wb") as fh:
         pickle.dump({"observations": rng.random((35, 142, 4)), "shedding": rng.integers(0, 2, (35, 1)).astype(float),

@@ -103,6 +103,24 @@ def test_decode_heads(ctx):
     assert _rel(std, F.softplus(ctx["p"]["decoder.constant_std"])) < 1e-6
 
 
+def test_eval_side_small_nets(ctx):
+    """slode_initialize_state / slode_prior_nets / slode_label_heads (the eval-side entry points: OdeModel.initialize_state, the prior
+    nets of recon(is_post=False), classifier / pred_inputs) against the oracle's restatement of the same modules: 1e-6 relative."""
+    eng, dev, B, ospec, p = ctx["eng"], ctx["dev"], ctx["B"], ctx["ospec"], ctx["p"]
+    g = torch.Generator().manual_seed(6)
+    z = torch.randn(B, ospec.latent_dim, generator=g)
+    assert _rel(eng.initialize_state(ctx["flat"], z.to(dev)), O.initialize_state(p, z)) < 1e-6
+    loc, scale = eng.prior_nets(ctx["flat"], ctx["u_d"])
+    wl, ws = O.prior_loc_scale(p, ospec, ctx["u"])
+    assert _rel(loc, wl) < 1e-6 and _rel(scale, ws) < 1e-6
+    probs = eng.label_heads(ctx["flat"], z.to(dev)).cpu()
+    for kind, prefix, zo, zd, uo, ud in ospec.aux_heads:
+        zg = z[:, zo:zo + zd]
+        want = {"bernoulli": O.classifier_sigmoid, "onehot": O.classifier_softmax}.get(kind)
+        want = want(p, prefix, zg) if want is not None else O.regressor_exp_exp(p, prefix, zg)[0]
+        assert _rel(probs[:, uo:uo + ud], want) < 2e-6, prefix
+
+
 def test_elbo_loss_and_trajectories(ctx):
     eng, dev = ctx["eng"], ctx["dev"]
     loss = torch.zeros(1, device=dev)

@@ -68,3 +68,36 @@ def test_dopri5_reverse_sweep_matches_oracle_autograd(mode):
     np.testing.assert_allclose(gz, zz.grad.numpy(), rtol=2e-4, atol=1e-5)
     for k, v in kg.items():
         np.testing.assert_allclose(v, q[k].grad.numpy(), rtol=2e-4, atol=1e-5, err_msg=k)
+
+
+def test_piecewise_linear_heads_and_switching_sum_contraction():
+    """The round-2 kernel algorithms (csrc/ode_kernel.hip, ALG 0) against the direct formulas, fp64: the piecewise-linear table of
+    the dynamics heads reproduces bias + W relu(wt t + u) at every stage time, and the chunk-sum / switching-index contraction
+    reproduces the per-sample x per-unit weight-gradient sums, for increasing, decreasing and irregular (jittered) time grids and
+    for units that are always on, never on, or flip exactly at a grid point."""
+    rng = np.random.default_rng(5)
+    H, S = 25, 5
+    for case in range(6):
+        T = [40, 200, 86, 33, 100, 64][case]
+        times = np.cumsum(0.05 + rng.random(T)) if case % 2 else np.arange(T, dtype=np.float64)
+        if case == 3:
+            times = times[::-1].copy()                                   # decreasing grid (torchdiffeq accepts it)
+        ts = KM.stage_times(times, "rk4")
+        wt = rng.normal(size=H) * 0.4
+        u = -wt * rng.choice(ts, size=H) + rng.normal(size=H) * 0.3          # thresholds inside the grid
+        wt[0], u[0] = 0.0, 1.0                                                # always on
+        wt[1], u[1] = 0.0, -1.0                                               # never on
+        wt[2], u[2] = 0.5, -0.5 * ts[7]                                       # pre == 0 exactly at a table entry
+        W, bias = rng.normal(size=(2 * S, H)) * 0.3, rng.normal(size=2 * S)
+        pre = wt[None, :] * ts[:, None] + u[None, :]
+        direct = np.maximum(pre, 0) @ W.T + bias
+        assert np.abs(KM.pwl_heads(wt, u, W, bias, ts) - direct).max() < 1e-11 * max(1.0, np.abs(direct).max())
+        g = rng.normal(size=(ts.shape[0], 2 * S))
+        mask = (pre > 0).astype(np.float64)
+        dW_want = g.T @ (np.maximum(pre, 0))                                  # [2S, H]
+        gh = (g @ W) * mask                                                   # [nt, H]
+        dW, dbias, gu, gwt = KM.contraction_by_switching_sums(wt, u, W, g, ts, n_chunks=[7, 25, 12, 5, 32, 9][case])
+        scale = np.abs(dW_want).max()
+        assert np.abs(dW - dW_want).max() < 1e-10 * scale
+        assert np.abs(dbias - g.sum(0)).max() < 1e-10 * scale
+        assert np.abs(gu - gh.sum(0)).max() < 1e-10 * scale and np.abs(gwt - (gh * ts[:, None]).sum(0)).max() < 1e-9 * scale
