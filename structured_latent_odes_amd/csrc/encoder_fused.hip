@@ -451,8 +451,12 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const Tai
     __syncthreads();
     if (tid == 0) {
       s_last = (__hip_atomic_fetch_add(tl.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(k.Hc - 1)) ? 1 : 0;
-      if (s_last) {   // invalidate only (no L2 write-back): this CU's L1 serves the whole block; the invalidate has completed (vmcnt)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // before this lane reaches the barrier the other waves load behind
+      // fast path: the last block reads the rows with sc1 (L1-bypassing) loads behind the barrier below -- every byte was stored sc1
+      // and drained before its block's counter add, and the add's returned value is what told this block it is last
+      // (MI355X_MICROARCH.md, hand-offs measured with sc1 loads in place of the acquire: 4-byte stores and loads, one counter).  The
+      // generic path (plain strided loads in tail_element) keeps the acquire: an L1 invalidate, completed before the barrier.
+      if (s_last && !fast_conv) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
@@ -490,7 +494,8 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const Tai
         for (int w = 0; w < nrow; w += 16) {
           float v[16];
 #pragma unroll
-          for (int q = 0; q < 16; ++q) v[q] = src[(long long)min(w + q, nrow - 1) * 4 * tl.n_cv];   // 16 loads in flight, behind the acquire above
+          for (int q = 0; q < 16; ++q)   // 16 sc1 loads in flight
+            v[q] = __hip_atomic_load(src + (long long)min(w + q, nrow - 1) * 4 * tl.n_cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
           for (int q = 0; q < 16; q += 4) {
             a0 += (w + q < nrow) ? v[q] : 0.f;

@@ -43,7 +43,12 @@ extern "C" int slode_debug_wg_span(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_span), sizeof(unsigned long long) * 2 * n);
 }
 #else
-#define STAMP(i) do { } while (0)
+// Product build: the phase boundaries rotate the issue priority between the workgroups that share a CU.  The CU arbitrates
+// oldest-first, so of the (up to four) co-resident trajectories the youngest only gets the issue slots the others leave and finishes
+// last (round 1: 27 / 31 / 36 / 41 us); alternating high / low priority by (phase + residency slot) parity evens their progress.  Wave 0
+// (every serial stretch) stays one level above its workgroup's bulk waves.
+#define STAMP(i) do { if (((i) + prio_slot) & 1) { if (threadIdx.x < 64) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); } \
+                      else { if (threadIdx.x < 64) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } } while (0)
 #endif
 
 namespace {
@@ -451,7 +456,8 @@ ode_elbo_kernel(const OdeK k) {
   const cptr wg = (cptr)k.wg, bg = (cptr)k.bg, wd = (cptr)k.wd, bd = (cptr)k.bd;
   // wave 0 carries every serial stretch of a trajectory (latent sample, switching indices, table, both scans): it issues ahead of the
   // bulk waves of the co-resident workgroups
-  if (tid < 64) __builtin_amdgcn_s_setprio(2);
+  const int prio_slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 8));   // residency slot on its CU (dispatch order: 256 CUs per pass)
+  (void)prio_slot;
   STAMP(0);
   const int tid_outer = tid;
   // scoring an externally solved trajectory (dopri5 training, generic instantiation): no solve, nothing flows through a solver here
@@ -1192,8 +1198,8 @@ ode_elbo_kernel(const OdeK k) {
           const int j = e / (2 * S), r = e - j * (2 * S);
           const int ms = s_ms[j], sf = s_sf[j];
           const int qs = ms / CL;          // chunk that holds sample ms (>= NQ: none)
-          const int qa = sf ? qs + 1 : 0, qn = sf ? NQ - qa : qs;            // whole chunks [qa, qa + qn)
-          const int ma = sf ? ms : qs * CL, mn = sf ? (qs + 1) * CL - ms : ms - qs * CL;   // cut chunk: samples [ma, ma + mn)
+          const int qa = sf ? qs + 1 : 0, qn = max(sf ? NQ - qa : qs, 0);    // whole chunks [qa, qa + qn)  (a never-on unit: ms = nt, none)
+          const int ma = sf ? ms : qs * CL, mn = max(sf ? (qs + 1) * CL - ms : ms - qs * CL, 0);   // cut chunk: samples [ma, ma + mn)
           float gmv = 0.f, gtv = 0.f;
           for (int q0 = 0; q0 < NQ; q0 += 8) {
             float v[8], w[8];

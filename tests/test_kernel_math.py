@@ -96,7 +96,8 @@ def test_piecewise_linear_heads_and_switching_sum_contraction():
         mask = (pre > 0).astype(np.float64)
         dW_want = g.T @ (np.maximum(pre, 0))                                  # [2S, H]
         gh = (g @ W) * mask                                                   # [nt, H]
-        dW, dbias, gu, gwt = KM.contraction_by_switching_sums(wt, u, W, g, ts, n_chunks=[7, 25, 12, 5, 32, 9][case])
+        # (case 1: 598 samples in 26 chunks of 23 -- a chunk count that divides the sample count exactly, the shape of the round-2 fuzz find)
+        dW, dbias, gu, gwt = KM.contraction_by_switching_sums(wt, u, W, g, ts, n_chunks=[7, 26, 12, 5, 32, 9][case])
         scale = np.abs(dW_want).max()
         assert np.abs(dW - dW_want).max() < 1e-10 * scale
         assert np.abs(dbias - g.sum(0)).max() < 1e-10 * scale
