@@ -25,7 +25,7 @@ def short(name):
     for k in KERNELS:
         if k in name:
             return k
-    return name.split("(")[0][-60:]
+    return name.split("(")[0].split("<")[0].replace(",", ";")[-60:]
 
 
 def stats(d):
