@@ -15,13 +15,12 @@
 //
 // Training with dopri5 (BASELINE config[2]): the forward kernel also records every accepted step (t, dt, y) and
 // `dopri5_bwd_kernel` walks a trajectory's record backwards -- the exact reverse mode of the accepted Dormand-Prince steps and of
-// the dense-output polynomial, step sizes held fixed (the controller is not differentiated), lane = trajectory (weights as SGPR
-// operands, hidden offsets u in LDS).  The right-hand side is linear in the state with coefficients that depend on time only, so a
-// step's seven stages are re-evaluated from its recorded (t, dt, y) instead of being stored.  All six evaluation times of a step are
-// folded into one pass; the weight gradients come from running sums parked at each hidden unit's switching time (sweep_step).
-// The workgroup's 64 columns are summed in a fixed order into one slab row in the layout of the fixed-grid kernel's slabs (reduced
-// by the same deterministic tail).  (A reverse sweep in the forward kernel's 8-lane mapping was 4x faster but computed the
-// hidden-layer bias gradient of units >= 16 about 1e-2 off -- cause not found -- and is not shipped.)
+// the dense-output polynomial, step sizes held fixed (the controller is not differentiated) -- in the same 8-lane mapping.  The
+// right-hand side is linear in the state with coefficients that depend on time only, so a step's seven stages are re-evaluated from
+// its recorded (t, dt, y) instead of being stored, and the reverse mode is component-wise: one scalar of everything per lane.  The
+// coefficients are re-evaluated incrementally (grp::Incr) and the weight gradients come from running sums parked at each hidden
+// unit's switching time (grp::sweep_sample).  A workgroup's 16 trajectories are summed in a fixed order into one slab row in the
+// layout of the fixed-grid kernel's slabs (reduced by the same deterministic tail).
 #include "slode_common.h"
 
 namespace {
@@ -268,428 +267,444 @@ struct DpBK {
   const float *times, *z, *gx, *rec;
   const int* nrec;
   const float *w1, *b1, *w2, *b2, *wh, *bh, *wg, *bg, *wd, *bd;
-  float *gz, *slabs;           // gz [B][L]; slabs: one row per workgroup, slot 0 = loss (0, or NaN on a failed solve), then the ode segment
-  float* snap;                 // [B][H][4S] running sums parked when a unit's relu flips (see sweep_step)
-  int slab_stride, nseg;
+  float *g_loc, *g_scale, *slabs;   // the latent gradient through the solver is ADDED to the scorer's dLoss/dloc, dLoss/dscale [B][L]
+  const float* eps;                 // (z = loc + scale eps);  slabs: one row per workgroup, slot 0 = loss (0 / NaN on a failed solve), then the ode segment
+  float* snap;                 // [B][H][4S] running sums parked when a unit's relu flips (see grp::sweep_sample)
+  int slab_stride, nseg, stage_gx;
   int o_w1, o_b1, o_w2, o_b2, o_wh, o_bh, o_wg, o_bg, o_wd, o_bd;
 };
 
-namespace lane64 {
-typedef const __attribute__((address_space(4))) float* cptr;
-constexpr int DPW = 64;  // lanes (= trajectories) per workgroup
+namespace grp {
+// Reverse sweep in the forward kernel's mapping: EIGHT LANES PER TRAJECTORY, lane g = state component g.  The reverse mode of a
+// Dormand-Prince step is component-wise (the right-hand side a_g(t) - d_g(t) y_g couples components only through the time-dependent
+// coefficients), so every quantity of the step -- stage states, stage adjoints, dense-output sums, the running sums of the weight
+// gradients -- is ONE scalar per lane: ~80 registers, nothing spilled, nothing staged.
+constexpr int BNT = 128;        // threads per workgroup
+constexpr int BTP = BNT / G;    // trajectories per workgroup (= per slab row)
+constexpr int TS = BTP + 1;     // padded trajectory stride of the column-sum tile
 
-// growth / degradation coefficients at time t: a = sigmoid(Wg h + bg), d = sigmoid(Wd h + bd), h = relu(wt t + u)
-template <int S, int H>
-__device__ __forceinline__ void coef(float t, const float* __restrict__ s_wt, const float* __restrict__ s_ul, cptr wg, cptr bg, cptr wd,
-                                     cptr bd, float (&a)[S], float (&d)[S]) {
-  asm volatile("" : "+s"(wg), "+s"(wd), "+s"(bg), "+s"(bd));
-  float xa[S], xd[S];
-#pragma unroll
-  for (int s = 0; s < S; ++s) { xa[s] = bg[s]; xd[s] = bd[s]; }
-  // hidden-unit-major with a short unroll: the fully unrolled form keeps all 2*S*H weights in SGPRs at once and spills hundreds
-#pragma unroll 5
-  for (int j = 0; j < H; ++j) {
-    const float h = fmaxf(fmaf(s_wt[j], t, s_ul[j * DPW]), 0.f);
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      xa[s] = fmaf(wg[s * H + j], h, xa[s]);
-      xd[s] = fmaf(wd[s * H + j], h, xd[s]);
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < S; ++s) { a[s] = sigmoidf_fast(xa[s]); d[s] = sigmoidf_fast(xd[s]); }
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+// butterflies over the 8 lanes of a trajectory on the DPP crossbar (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror): every
+// lane of the group ends with the same bits (each step adds the same two operands on both sides)
+__device__ __forceinline__ unsigned group_or(unsigned v) {
+  v |= dpp_u<0xB1>(v);
+  v |= dpp_u<0x4E>(v);
+  v |= dpp_u<0x141>(v);
+  return v;
+}
+__device__ __forceinline__ float group_add(float v) {
+  v += __uint_as_float(dpp_u<0xB1>(__float_as_uint(v)));
+  v += __uint_as_float(dpp_u<0x4E>(__float_as_uint(v)));
+  v += __uint_as_float(dpp_u<0x141>(__float_as_uint(v)));
+  return v;
 }
 
-// The same structure makes the coefficients cheap to re-evaluate along the sweep: between two evaluation times only the units whose
-// predicate flips change the head pre-activations o_c(t) = bias_c + sum_{j on} W_cj (w_t,j t + u_j), which are linear in t otherwise.
-// The lane carries (value V_c at the last evaluation time tau, slope AL_c, the units' on/off bits): one evaluation = H predicates +
-// 2S fmas (+ 2 x 2S fmas per flipped unit) + 2S sigmoids instead of the H x 2S product; `coef` re-bases it every 16 steps.
-template <int S, int H>
+// The hidden layer is relu(w_t t + u_j): between two evaluation times only the units whose predicate fma(w_t, t, u_j) > 0 flips change
+// the head pre-activations o_c(t) = bias_c + sum_{j on} W_cj (w_t,j t + u_j), which are linear in t otherwise.  A lane carries, for the
+// growth and the degradation head of its component, the value V at the last evaluation time tau and the slope AL, and the group's
+// on/off bits: one evaluation = 4 predicates per lane + one OR butterfly + 2 fmas (+ 4 per flipped unit) + 2 sigmoids instead of the
+// H x 2S product and two 8-vector butterflies of the forward kernel's eval_ad; re-based every 16 steps (bounds the drift).
 struct Incr {
-  float V[2 * S], AL[2 * S], tau;
+  float Va, Vd, ALa, ALd, tau;
   unsigned mask;
 };
-template <int S, int H>
-__device__ __forceinline__ void incr_init(Incr<S, H>& st, float t, const float* __restrict__ s_wt, const float* __restrict__ s_ul, cptr wg, cptr bg,
-                                          cptr wd, cptr bd) {
-  asm volatile("" : "+s"(wg), "+s"(wd), "+s"(bg), "+s"(bd));
-#pragma unroll
-  for (int s = 0; s < S; ++s) { st.V[s] = bg[s]; st.V[S + s] = bd[s]; st.AL[s] = 0.f; st.AL[S + s] = 0.f; }
+struct Units {
+  float wt[JL], u[JL];   // this lane's hidden units g, g+8, g+16, g+24 (0, 0 beyond H: predicate never true)
+};
+__device__ __forceinline__ unsigned unit_bits(float t, const Units& w, int g) {
   unsigned m = 0u;
+#pragma unroll
+  for (int i = 0; i < JL; ++i) m |= (fmaf(w.wt[i], t, w.u[i]) > 0.f) ? (1u << (g + G * i)) : 0u;
+  return group_or(m);
+}
+template <int H>
+__device__ __forceinline__ void incr_init(Incr& st, float t, const Units& w, int g, const float* __restrict__ s_wt,
+                                          const float* __restrict__ s_us, const float* __restrict__ s_wgd, float bga, float bda) {
+  const unsigned m = unit_bits(t, w, g);
+  float va = bga, vd = bda, ala = 0.f, ald = 0.f;
 #pragma unroll 5
   for (int j = 0; j < H; ++j) {
-    const float wt = s_wt[j], pre = fmaf(wt, t, s_ul[j * DPW]);
-    const bool on = pre > 0.f;
-    m |= on ? (1u << j) : 0u;
+    const float wt = s_wt[j], pre = fmaf(wt, t, s_us[j]);
+    const bool on = (m >> j) & 1u;
     const float h = on ? pre : 0.f, hw = on ? wt : 0.f;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      st.V[s] = fmaf(wg[s * H + j], h, st.V[s]);
-      st.V[S + s] = fmaf(wd[s * H + j], h, st.V[S + s]);
-      st.AL[s] = fmaf(wg[s * H + j], hw, st.AL[s]);
-      st.AL[S + s] = fmaf(wd[s * H + j], hw, st.AL[S + s]);
-    }
+    const float w1 = s_wgd[j * 16 + g], w2 = s_wgd[j * 16 + 8 + g];
+    va = fmaf(w1, h, va); vd = fmaf(w2, h, vd);
+    ala = fmaf(w1, hw, ala); ald = fmaf(w2, hw, ald);
   }
-  st.mask = m;
-  st.tau = t;
+  st.Va = va; st.Vd = vd; st.ALa = ala; st.ALd = ald; st.mask = m; st.tau = t;
 }
-// moves the state to time t; returns the on/off bits at t;  a = sigmoid(V[0..S)), d = sigmoid(V[S..2S))
-template <int S, int H>
-__device__ __forceinline__ unsigned incr_eval(Incr<S, H>& st, float t, const float* __restrict__ s_wt, const float* __restrict__ s_ul, const float* wgp,
-                                              const float* wdp, float (&a)[S], float (&d)[S]) {
-  unsigned now = 0u;
-#pragma unroll 5
-  for (int j = 0; j < H; ++j) now |= (fmaf(s_wt[j], t, s_ul[j * DPW]) > 0.f) ? (1u << j) : 0u;
+// moves the state to time t; returns the on/off bits at t
+template <int H>
+__device__ __forceinline__ unsigned incr_eval(Incr& st, float t, const Units& w, int g, bool own, const float* __restrict__ s_wt,
+                                              const float* __restrict__ s_us, const float* __restrict__ s_wgd, float& a, float& d) {
   const float dtau = t - st.tau;
-#pragma unroll
-  for (int c = 0; c < 2 * S; ++c) st.V[c] = fmaf(st.AL[c], dtau, st.V[c]);
+  st.Va = fmaf(st.ALa, dtau, st.Va);
+  st.Vd = fmaf(st.ALd, dtau, st.Vd);
+  st.tau = t;
+  const unsigned now = unit_bits(t, w, g);
   unsigned flip = now ^ st.mask;
-  while (flip) {   // rare
+  while (flip) {   // the same for the 8 lanes of a trajectory; rare
     const int j = __builtin_ctz(flip);
     flip &= flip - 1u;
     const float wt = s_wt[j], sg = ((now >> j) & 1u) ? 1.f : -1.f;
-    const float pre = sg * fmaf(wt, t, s_ul[j * DPW]), swt = sg * wt;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const float w1 = wgp[s * H + j], w2 = wdp[s * H + j];
-      st.V[s] = fmaf(w1, pre, st.V[s]);     st.AL[s] = fmaf(w1, swt, st.AL[s]);
-      st.V[S + s] = fmaf(w2, pre, st.V[S + s]); st.AL[S + s] = fmaf(w2, swt, st.AL[S + s]);
-    }
+    const float pre = sg * fmaf(wt, t, s_us[j]), swt = sg * wt;
+    const float w1 = s_wgd[j * 16 + g], w2 = s_wgd[j * 16 + 8 + g];
+    st.Va = fmaf(w1, pre, st.Va); st.ALa = fmaf(w1, swt, st.ALa);
+    st.Vd = fmaf(w2, pre, st.Vd); st.ALd = fmaf(w2, swt, st.ALd);
   }
   st.mask = now;
-  st.tau = t;
-#pragma unroll
-  for (int s = 0; s < S; ++s) { a[s] = sigmoidf_fast(st.V[s]); d[s] = sigmoidf_fast(st.V[S + s]); }
+  a = own ? sigmoidf_fast(st.Va) : 0.f;
+  d = own ? sigmoidf_fast(st.Vd) : 0.f;
   return now;
 }
 
-// Weight gradients.  The hidden layer is relu(w_t t + u_j): along the time-ordered sequence of evaluation times (all stages of all
-// accepted steps) unit j is switched on over a prefix or a suffix, so its share of every head-weight gradient is a partial sum of the
-// per-sample head gradients g (and of g t) up to the sample where its predicate fma(w_t, t, u_j) > 0 flips.  The sweep walks the
-// samples backwards in time keeping the running sums RS = sum g, RT = sum g t (2S channels each) and a bit per unit; when a unit's
-// bit flips the running sums are parked in `snap` (global, [trajectory][unit][4S], written once per unit at most).  After the sweep
+// Weight gradients.  Along the time-ordered sequence of evaluation times (all stages of all accepted steps) unit j is switched on over
+// a prefix or a suffix, so its share of every head-weight gradient is a partial sum of the per-sample head gradients g (and of g t) up
+// to the sample where its predicate flips.  The sweep walks the samples backwards in time keeping the running sums RS = sum g,
+// RT = sum g t (this lane's growth and degradation channel) and a bit per unit; when a unit's bit flips the running sums are parked
+// in `snap` (global, [trajectory][unit][4S], written once per unit at most).  After the sweep
 //   GM_j = snapshot (unit on at late times) | total - snapshot (on at early times) | total (always on) | 0 (never on),   GT_j likewise,
-//   dW[r][j] = w_t,j GT_j[r] + u_j GM_j[r],  dLoss/du_j = sum_r W[r][j] GM_j[r],  dLoss/dw_t,j = sum_r W[r][j] GT_j[r]
-// -- per step 6 x H predicates and 6 x 4S adds instead of the 6 x H x 4S multiply-adds (and 2S + 2 LDS read-modify-writes per unit)
-// of a per-unit accumulation.
-template <int S, int H>
-__device__ __forceinline__ void sweep_step(const float (&te)[6], const float* __restrict__ s_wt, const float* __restrict__ s_ul,
-                                           const float (&gxa)[6][S], const float (&gxd)[6][S], float (&RS)[2 * S], float (&RT)[2 * S],
-                                           unsigned& onmask, unsigned& tmask, bool& first, bool act, float* __restrict__ snap,
-                                           const unsigned (&mk)[6]) {
-#pragma unroll
-  for (int e = 5; e >= 0; --e) {   // decreasing time
-    const float t = te[e];
-    const unsigned now = mk[e];
-    unsigned flip = (first || !act) ? 0u : (now ^ onmask);
-    while (flip) {   // rare: at most H flips per trajectory
-      const int j = __builtin_ctz(flip);
-      flip &= flip - 1u;
-      float* d = snap + j * 4 * S;
-#pragma unroll
-      for (int c = 0; c < 2 * S; ++c) { d[c] = RS[c]; d[2 * S + c] = RT[c]; }
-      tmask |= 1u << j;
+//   dW[r][j] = w_t,j GT_j[r] + u_j GM_j[r],  dLoss/du_j = sum_r W[r][j] GM_j[r],  dLoss/dw_t,j = sum_r W[r][j] GT_j[r].
+// one sample of the sweep (decreasing time): park the running sums for every unit whose bit flips at this sample, then add the sample
+template <int S>
+__device__ __forceinline__ void sweep_sample(float t, unsigned now, float ga, float gd, float& RSa, float& RSd, float& RTa, float& RTd,
+                                             unsigned& onmask, unsigned& tmask, bool& first, bool act, bool own, int gs,
+                                             float* __restrict__ snap) {
+  unsigned flip = (first || !act) ? 0u : (now ^ onmask);
+  while (flip) {   // at most H flips per trajectory
+    const int j = __builtin_ctz(flip);
+    flip &= flip - 1u;
+    if (own) {
+      float* d = snap + j * 4 * S + gs;
+      d[0] = RSa; d[S] = RSd; d[2 * S] = RTa; d[3 * S] = RTd;
     }
-    if (act) { onmask = now; first = false; }
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const float ga = act ? gxa[e][s] : 0.f, gd = act ? gxd[e][s] : 0.f;
-      RS[s] += ga; RS[S + s] += gd;
-      RT[s] = fmaf(ga, t, RT[s]); RT[S + s] = fmaf(gd, t, RT[S + s]);
-    }
+    tmask |= 1u << j;
   }
+  if (act) { onmask = now; first = false; }
+  const float a = act ? ga : 0.f, d = act ? gd : 0.f;
+  RSa += a; RSd += d;
+  RTa = fmaf(a, t, RTa); RTd = fmaf(d, t, RTd);
 }
 
 template <int S, int H>
-__global__ void __launch_bounds__(DPW) dopri5_bwd_kernel(const DpBK k) {
+__global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
+  static_assert(S <= G && H <= G * JL && H <= 32, "one state component and JL hidden units per lane; unit bits in one word");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NACC = 2 * S * H + 2 * S + 2 * H;
-  float* s_wt = smem;                 // [32]
-  float* s_u = s_wt + 32;             // [H][DPW] hidden offsets; after the step loop: dL/d(init-net pre-activation)
-  float* s_z = s_u + H * DPW;         // [L][DPW]
-  float* s_acc = s_z + k.L * DPW;     // [NACC][DPW]
-  const int lane = threadIdx.x, b = blockIdx.x * DPW + lane, L = k.L, T = k.T;
-  const bool live = b < k.B;
-  const cptr wg = (cptr)k.wg, bg = (cptr)k.bg, wd = (cptr)k.wd, bd = (cptr)k.bd;
-  const cptr wh = (cptr)k.wh, bh = (cptr)k.bh, w1 = (cptr)k.w1, b1 = (cptr)k.b1, w2 = (cptr)k.w2, b2 = (cptr)k.b2;
-  if (lane < 32) s_wt[lane] = lane < H ? k.wh[lane * (1 + L)] : 0.f;
-  for (int l = 0; l < L; ++l) s_z[l * DPW + lane] = live ? k.z[(long long)b * L + l] : 0.f;
-  for (int i = 0; i < NACC; ++i) s_acc[i * DPW + lane] = 0.f;
-  __syncthreads();
-  for (int j = 0; j < H; ++j) {
-    float uj = bh[j];
-    for (int l = 0; l < L; ++l) uj = fmaf(wh[j * (1 + L) + 1 + l], s_z[l * DPW + lane], uj);
-    s_u[j * DPW + lane] = uj;
+  constexpr int NTMP = 2 * S + 2;
+  const int tid = threadIdx.x, g = tid & (G - 1), slot = tid >> 3, b = blockIdx.x * BTP + slot, L = k.L, T = k.T;
+  float* s_wt = smem;                   // [32] time weights of the hidden units
+  float* s_wgd = s_wt + 32;             // [H][16]: [j][g] growth-head weight of component g, [j][8 + g] degradation-head weight
+  float* s_u = s_wgd + H * 16;          // [BTP][32] hidden offsets u = W_z z + b_h
+  float* s_gu = s_u + BTP * 32;         // [BTP][32] dLoss/du_j
+  float* s_gp = s_gu + BTP * 32;        // [BTP][32] dLoss/d(init-net pre-activation j)
+  float* s_h0 = s_gp + BTP * 32;        // [BTP][32] init-net hidden values
+  float* s_go = s_h0 + BTP * 32;        // [BTP][8]  dLoss/d(init-net output pre-activation)
+  float* s_z = s_go + BTP * 8;          // [BTP][L]
+  float* s_times = s_z + BTP * L;       // [T]
+  float* s_big = s_times + ((T + 3) & ~3);   // dL/dx rows of the workgroup's trajectories | column-sum tile | W1, W_z for the latent gradient
+  const bool live = b < k.B, own = g < S;
+  const long long bb = live ? b : 0;
+  const int gs = own ? g : 0;
+  float* row = k.slabs + (long long)blockIdx.x * k.slab_stride;
+  float* prm = row + 1;
+  for (int i = 1 + tid; i <= k.nseg; i += BNT) row[i] = 0.f;   // (every element is written again below; completes long before)
+  if (tid < 32) s_wt[tid] = tid < H ? k.wh[tid * (1 + L)] : 0.f;
+  for (int i = tid; i < H * 16; i += BNT) {
+    const int j = i >> 4, c = i & 15, gg = c & 7;
+    s_wgd[i] = gg < S ? (c < 8 ? k.wg[gg * H + j] : k.wd[gg * H + j]) : 0.f;
   }
-  const float* s_ul = s_u + lane;
-  float* acc = s_acc + lane;
-  const int nr = live ? k.nrec[b] : 0;
+  for (int l = g; l < L; l += G) s_z[slot * L + l] = live ? k.z[bb * L + l] : 0.f;
+  for (int i = tid; i < T; i += BNT) s_times[i] = k.times[i];
+  if (k.stage_gx) {   // the workgroup's BTP rows of dL/dx are one contiguous block
+    const long long base = (long long)blockIdx.x * BTP * T * S;
+    const int ntr = min(BTP, k.B - blockIdx.x * BTP), n = ntr * T * S;
+    for (int i = tid; i < n; i += BNT) s_big[i] = k.gx[base + i];
+  }
+  __syncthreads();
+  // this lane's hidden units: offsets u (dynamics net) and pre-activations (init net)
+  Units w;
+  float pre0[JL];
+  {
+    const float* zrow = s_z + slot * L;
+#pragma unroll
+    for (int i = 0; i < JL; ++i) {
+      const int j = g + G * i;
+      const bool valid = j < H;
+      const int jj = valid ? j : 0;
+      float uj = k.bh[jj], pj = k.b1[jj];
+      for (int l = 0; l < L; ++l) {
+        const float zl = zrow[l];
+        uj = fmaf(k.wh[jj * (1 + L) + 1 + l], zl, uj);
+        pj = fmaf(k.w1[jj * L + l], zl, pj);
+      }
+      w.wt[i] = valid ? s_wt[jj] : 0.f;
+      w.u[i] = valid ? uj : 0.f;
+      pre0[i] = valid ? pj : 0.f;
+      s_u[slot * 32 + j] = w.u[i];
+    }
+  }
+  __syncthreads();
+  const float* s_us = s_u + slot * 32;
+  const float bga = own ? k.bg[gs] : 0.f, bda = own ? k.bd[gs] : 0.f;
+  const int nr = live ? k.nrec[bb] : 0;
   const bool bad = nr < 0 || nr > k.kmax;
   const int K = bad ? 0 : nr;
-  const float* gxb = k.gx + (long long)(live ? b : 0) * T * S;
-  float lam[S];
-#pragma unroll
-  for (int s = 0; s < S; ++s) lam[s] = 0.f;
-  float RS[2 * S], RT[2 * S];
-#pragma unroll
-  for (int c = 0; c < 2 * S; ++c) { RS[c] = 0.f; RT[c] = 0.f; }
+  const float* gxb = k.gx + bb * T * S + gs;
+  const float* gxs = s_big + slot * T * S + gs;
+  float* snap = k.snap + bb * H * 4 * S;
+  float lam = 0.f, RSa = 0.f, RSd = 0.f, RTa = 0.f, RTd = 0.f;
   unsigned onmask = 0u, tmask = 0u;
   bool first = true;
-  Incr<S, H> inc;
-  float* snap = k.snap + (long long)(live ? b : 0) * H * 4 * S;
+  Incr inc;
+  inc.Va = inc.Vd = inc.ALa = inc.ALd = inc.tau = 0.f; inc.mask = 0u;
   int j = T - 1;
-  // every lane leaves the loop after max(K) <= kmax iterations
+  // the record of step K-1-it, two steps ahead of its use (a step is ~1 us of dependent arithmetic: about one memory latency)
+  float t, dt, y, t_n1, dt_n1, y_n1, t_n2, dt_n2, y_n2;
+#define SLODE_LDREC(IT, T_, DT_, Y_)                                                            \
+  {                                                                                             \
+    const bool a_ = (IT) < K;                                                                   \
+    const float* r_ = k.rec + ((long long)(a_ ? K - 1 - (IT) : 0) * k.B + bb) * (S + 2);         \
+    const float r0_ = r_[0], r1_ = r_[1], r2_ = r_[2 + gs];                                     \
+    T_ = a_ ? r0_ : 0.f; DT_ = a_ ? r1_ : 0.f; Y_ = (a_ && own) ? r2_ : 0.f;                    \
+  }
+  SLODE_LDREC(0, t, dt, y)
+  SLODE_LDREC(1, t_n1, dt_n1, y_n1)
+  // every lane leaves the loop after max(K) <= kmax iterations; the butterflies sit at the top level of the body (all lanes run them)
   for (int it = 0; __any(it < K); ++it) {
     const bool act = it < K;
-    const int kk = act ? K - 1 - it : 0;
-    float t = 0.f, dt = 0.f, y[S];
-    {
-      const float* r = k.rec + ((long long)kk * k.B + (live ? b : 0)) * (S + 2);
-      if (act) { t = r[0]; dt = r[1]; }
-#pragma unroll
-      for (int s = 0; s < S; ++s) y[s] = act ? r[2 + s] : 0.f;
-    }
-    // stage coefficients at the six distinct stage times (stages 6 and 7 share t + dt) and the stage slopes
-    float A[6][S], D[6][S];
-    unsigned mk[6];
-    if ((it & 15) == 0) incr_init<S, H>(inc, t, s_wt, s_ul, wg, bg, wd, bd);   // re-base (bounds the drift of the incremental form)
-    mk[0] = incr_eval<S, H>(inc, t, s_wt, s_ul, k.wg, k.wd, A[0], D[0]);
-    mk[1] = incr_eval<S, H>(inc, t + dt * (1.f / 5), s_wt, s_ul, k.wg, k.wd, A[1], D[1]);
-    mk[2] = incr_eval<S, H>(inc, t + dt * (3.f / 10), s_wt, s_ul, k.wg, k.wd, A[2], D[2]);
-    mk[3] = incr_eval<S, H>(inc, t + dt * (4.f / 5), s_wt, s_ul, k.wg, k.wd, A[3], D[3]);
-    mk[4] = incr_eval<S, H>(inc, t + dt * (8.f / 9), s_wt, s_ul, k.wg, k.wd, A[4], D[4]);
-    mk[5] = incr_eval<S, H>(inc, t + dt, s_wt, s_ul, k.wg, k.wd, A[5], D[5]);
-    float k1[S], k2[S], k3[S], k4[S], k5[S], k6[S], y2[S], y3[S], y4[S], y5[S], y6[S], y1[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      k1[s] = A[0][s] - D[0][s] * y[s];
-      y2[s] = fmaf(dt, (1.f / 5) * k1[s], y[s]);
-      k2[s] = A[1][s] - D[1][s] * y2[s];
-      y3[s] = fmaf(dt, (3.f / 40) * k1[s] + (9.f / 40) * k2[s], y[s]);
-      k3[s] = A[2][s] - D[2][s] * y3[s];
-      y4[s] = fmaf(dt, (44.f / 45) * k1[s] + (-56.f / 15) * k2[s] + (32.f / 9) * k3[s], y[s]);
-      k4[s] = A[3][s] - D[3][s] * y4[s];
-      y5[s] = fmaf(dt, (19372.f / 6561) * k1[s] + (-25360.f / 2187) * k2[s] + (64448.f / 6561) * k3[s] + (-212.f / 729) * k4[s], y[s]);
-      k5[s] = A[4][s] - D[4][s] * y5[s];
-      y6[s] = fmaf(dt, (9017.f / 3168) * k1[s] + (-355.f / 33) * k2[s] + (46732.f / 5247) * k3[s] + (49.f / 176) * k4[s] + (-5103.f / 18656) * k5[s], y[s]);
-      k6[s] = A[5][s] - D[5][s] * y6[s];
-      y1[s] = fmaf(dt, (35.f / 384) * k1[s] + (500.f / 1113) * k3[s] + (125.f / 192) * k4[s] + (-2187.f / 6784) * k5[s] + (11.f / 84) * k6[s], y[s]);
-    }
-    // dense outputs inside (t, t + dt]: x_j = y + q cd + q^2 cc + q^3 cb + q^4 ca with q = (times[j] - t) / dt
-    float Ga[S], Gb[S], Gc[S], Gd[S], gy[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) Ga[s] = Gb[s] = Gc[s] = Gd[s] = gy[s] = 0.f;
-    while (act && j >= 1 && k.times[j] > t) {
-      const float q = (k.times[j] - t) / dt, q2 = q * q, q3 = q2 * q, q4 = q2 * q2;
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        const float g = gxb[j * S + s];
-        gy[s] += g;
-        Gd[s] = fmaf(q, g, Gd[s]); Gc[s] = fmaf(q2, g, Gc[s]); Gb[s] = fmaf(q3, g, Gb[s]); Ga[s] = fmaf(q4, g, Ga[s]);
-      }
+    SLODE_LDREC(it + 2, t_n2, dt_n2, y_n2)
+    const float te0 = t, te1 = t + dt * (1.f / 5), te2 = t + dt * (3.f / 10), te3 = t + dt * (4.f / 5), te4 = t + dt * (8.f / 9), te5 = t + dt;
+    // ---- forward recomputation of the stages from the recorded (t, dt, y) ------------------------------------------------------
+    if ((it & 15) == 0) incr_init<H>(inc, te0, w, g, s_wt, s_us, s_wgd, bga, bda);
+    float a, d;
+    const unsigned mk0 = incr_eval<H>(inc, te0, w, g, own, s_wt, s_us, s_wgd, a, d);
+    const float ap0 = a * (1.f - a), d0 = d, dp0 = d * (1.f - d);
+    const float k1 = a - d * y;
+    const unsigned mk1 = incr_eval<H>(inc, te1, w, g, own, s_wt, s_us, s_wgd, a, d);
+    const float ap1 = a * (1.f - a), d1 = d, dp1 = d * (1.f - d);
+    const float ys2 = fmaf(dt, (1.f / 5) * k1, y);
+    const float k2 = a - d * ys2;
+    const unsigned mk2 = incr_eval<H>(inc, te2, w, g, own, s_wt, s_us, s_wgd, a, d);
+    const float ap2 = a * (1.f - a), d2 = d, dp2 = d * (1.f - d);
+    const float ys3 = fmaf(dt, (3.f / 40) * k1 + (9.f / 40) * k2, y);
+    const float k3 = a - d * ys3;
+    const unsigned mk3 = incr_eval<H>(inc, te3, w, g, own, s_wt, s_us, s_wgd, a, d);
+    const float ap3 = a * (1.f - a), d3 = d, dp3 = d * (1.f - d);
+    const float ys4 = fmaf(dt, (44.f / 45) * k1 + (-56.f / 15) * k2 + (32.f / 9) * k3, y);
+    const float k4 = a - d * ys4;
+    const unsigned mk4 = incr_eval<H>(inc, te4, w, g, own, s_wt, s_us, s_wgd, a, d);
+    const float ap4 = a * (1.f - a), d4 = d, dp4 = d * (1.f - d);
+    const float ys5 = fmaf(dt, (19372.f / 6561) * k1 + (-25360.f / 2187) * k2 + (64448.f / 6561) * k3 + (-212.f / 729) * k4, y);
+    const float k5 = a - d * ys5;
+    const unsigned mk5 = incr_eval<H>(inc, te5, w, g, own, s_wt, s_us, s_wgd, a, d);
+    const float ap5 = a * (1.f - a), d5 = d, dp5 = d * (1.f - d);
+    const float ys6 = fmaf(dt, (9017.f / 3168) * k1 + (-355.f / 33) * k2 + (46732.f / 5247) * k3 + (49.f / 176) * k4 + (-5103.f / 18656) * k5, y);
+    const float k6 = a - d * ys6;
+    const float y1 = fmaf(dt, (35.f / 384) * k1 + (500.f / 1113) * k3 + (125.f / 192) * k4 + (-2187.f / 6784) * k5 + (11.f / 84) * k6, y);
+    // ---- dense outputs inside (t, t + dt]: x_j = y + q cd + q^2 cc + q^3 cb + q^4 ca with q = (times[j] - t) / dt ----------------
+    float Ga = 0.f, Gb = 0.f, Gc = 0.f, Gd = 0.f, gy = 0.f;
+    while (act && j >= 1 && s_times[j] > t) {
+      const float q = (s_times[j] - t) / dt, q2 = q * q, q3 = q2 * q, q4 = q2 * q2;
+      float gq = k.stage_gx ? gxs[j * S] : gxb[j * S];
+      gq = own ? gq : 0.f;
+      gy += gq;
+      Gd = fmaf(q, gq, Gd); Gc = fmaf(q2, gq, Gc); Gb = fmaf(q3, gq, Gb); Ga = fmaf(q4, gq, Ga);
       --j;
     }
-    float g1[S], g2[S], g3[S], g4[S], g5[S], g6[S], gxa[6][S], gxd[6][S], gy1[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const float gf0 = dt * (-2.f * Ga[s] + 5.f * Gb[s] - 4.f * Gc[s] + Gd[s]);
-      const float gf1 = dt * (2.f * Ga[s] - 3.f * Gb[s] + Gc[s]);
-      const float gm = 16.f * Ga[s] - 32.f * Gb[s] + 16.f * Gc[s];          // dL/dy_mid
-      gy[s] += -8.f * Ga[s] + 18.f * Gb[s] - 11.f * Gc[s] + gm;
-      gy1[s] = lam[s] - 8.f * Ga[s] + 14.f * Gb[s] - 5.f * Gc[s];
-      const float dgm = dt * gm;
-      g1[s] = fmaf(dgm, 6025192743.f / 30085553152.f / 2, gf0);
-      g2[s] = 0.f;
-      g3[s] = dgm * (51252292925.f / 65400821598.f / 2);
-      g4[s] = dgm * (-2691868925.f / 45128329728.f / 2);
-      g5[s] = dgm * (187940372067.f / 1594534317056.f / 2);
-      g6[s] = dgm * (-1776094331.f / 19743644256.f / 2);
-      const float g7 = fmaf(dgm, 11237099.f / 235043384.f / 2, gf1);
-      // stage 7: k7 = a5 - d5 * y1
-      gxa[5][s] = g7 * A[5][s] * (1.f - A[5][s]);
-      gxd[5][s] = -g7 * y1[s] * D[5][s] * (1.f - D[5][s]);
-      gy1[s] = fmaf(-D[5][s], g7, gy1[s]);
-      // y1 = y + dt * sum b_i k_i
-      gy[s] += gy1[s];
-      const float dg = dt * gy1[s];
-      g1[s] = fmaf(dg, 35.f / 384, g1[s]); g3[s] = fmaf(dg, 500.f / 1113, g3[s]); g4[s] = fmaf(dg, 125.f / 192, g4[s]);
-      g5[s] = fmaf(dg, -2187.f / 6784, g5[s]); g6[s] = fmaf(dg, 11.f / 84, g6[s]);
-      // stage 6 (same time as stage 7: one weight-gradient accumulation for both)
-      gxa[5][s] = fmaf(g6[s], A[5][s] * (1.f - A[5][s]), gxa[5][s]);
-      gxd[5][s] = fmaf(-g6[s] * y6[s], D[5][s] * (1.f - D[5][s]), gxd[5][s]);
-      const float e6 = -D[5][s] * g6[s];
-      gy[s] += e6;
-      const float d6 = dt * e6;
-      g1[s] = fmaf(d6, 9017.f / 3168, g1[s]); g2[s] = fmaf(d6, -355.f / 33, g2[s]); g3[s] = fmaf(d6, 46732.f / 5247, g3[s]);
-      g4[s] = fmaf(d6, 49.f / 176, g4[s]); g5[s] = fmaf(d6, -5103.f / 18656, g5[s]);
-    }
-#pragma unroll
-    for (int s = 0; s < S; ++s) {   // stage 5
-      gxa[4][s] = g5[s] * A[4][s] * (1.f - A[4][s]);
-      gxd[4][s] = -g5[s] * y5[s] * D[4][s] * (1.f - D[4][s]);
-      const float e = -D[4][s] * g5[s];
-      gy[s] += e;
-      const float de = dt * e;
-      g1[s] = fmaf(de, 19372.f / 6561, g1[s]); g2[s] = fmaf(de, -25360.f / 2187, g2[s]); g3[s] = fmaf(de, 64448.f / 6561, g3[s]);
-      g4[s] = fmaf(de, -212.f / 729, g4[s]);
-    }
-#pragma unroll
-    for (int s = 0; s < S; ++s) {   // stage 4
-      gxa[3][s] = g4[s] * A[3][s] * (1.f - A[3][s]);
-      gxd[3][s] = -g4[s] * y4[s] * D[3][s] * (1.f - D[3][s]);
-      const float e = -D[3][s] * g4[s];
-      gy[s] += e;
-      const float de = dt * e;
-      g1[s] = fmaf(de, 44.f / 45, g1[s]); g2[s] = fmaf(de, -56.f / 15, g2[s]); g3[s] = fmaf(de, 32.f / 9, g3[s]);
-    }
-#pragma unroll
-    for (int s = 0; s < S; ++s) {   // stage 3
-      gxa[2][s] = g3[s] * A[2][s] * (1.f - A[2][s]);
-      gxd[2][s] = -g3[s] * y3[s] * D[2][s] * (1.f - D[2][s]);
-      const float e = -D[2][s] * g3[s];
-      gy[s] += e;
-      const float de = dt * e;
-      g1[s] = fmaf(de, 3.f / 40, g1[s]); g2[s] = fmaf(de, 9.f / 40, g2[s]);
-    }
-#pragma unroll
-    for (int s = 0; s < S; ++s) {   // stage 2
-      gxa[1][s] = g2[s] * A[1][s] * (1.f - A[1][s]);
-      gxd[1][s] = -g2[s] * y2[s] * D[1][s] * (1.f - D[1][s]);
-      const float e = -D[1][s] * g2[s];
-      gy[s] += e;
-      g1[s] = fmaf(dt * e, 1.f / 5, g1[s]);
-    }
-#pragma unroll
-    for (int s = 0; s < S; ++s) {   // stage 1
-      gxa[0][s] = g1[s] * A[0][s] * (1.f - A[0][s]);
-      gxd[0][s] = -g1[s] * y[s] * D[0][s] * (1.f - D[0][s]);
-      gy[s] = fmaf(-D[0][s], g1[s], gy[s]);
-    }
+    // ---- reverse mode of the step ------------------------------------------------------------------------------------------------
+    const float gf0 = dt * (-2.f * Ga + 5.f * Gb - 4.f * Gc + Gd);
+    const float gf1 = dt * (2.f * Ga - 3.f * Gb + Gc);
+    const float gm = 16.f * Ga - 32.f * Gb + 16.f * Gc;          // dL/dy_mid
+    gy += -8.f * Ga + 18.f * Gb - 11.f * Gc + gm;
+    float gy1 = lam - 8.f * Ga + 14.f * Gb - 5.f * Gc;
+    const float dgm = dt * gm;
+    float g1 = fmaf(dgm, 6025192743.f / 30085553152.f / 2, gf0);
+    float g2 = 0.f;
+    float g3 = dgm * (51252292925.f / 65400821598.f / 2);
+    float g4 = dgm * (-2691868925.f / 45128329728.f / 2);
+    float g5 = dgm * (187940372067.f / 1594534317056.f / 2);
+    float g6 = dgm * (-1776094331.f / 19743644256.f / 2);
+    const float g7 = fmaf(dgm, 11237099.f / 235043384.f / 2, gf1);
+    // stage 7: k7 = a5 - d5 * y1
+    float xa = g7 * ap5, xd = -g7 * y1 * dp5;
+    gy1 = fmaf(-d5, g7, gy1);
+    // y1 = y + dt * sum b_i k_i
+    gy += gy1;
+    const float dg = dt * gy1;
+    g1 = fmaf(dg, 35.f / 384, g1); g3 = fmaf(dg, 500.f / 1113, g3); g4 = fmaf(dg, 125.f / 192, g4);
+    g5 = fmaf(dg, -2187.f / 6784, g5); g6 = fmaf(dg, 11.f / 84, g6);
+    // stage 6 (same time as stage 7: one sample for both)
+    xa = fmaf(g6, ap5, xa);
+    xd = fmaf(-g6 * ys6, dp5, xd);
     {
-      const float te[6] = {t, t + dt * (1.f / 5), t + dt * (3.f / 10), t + dt * (4.f / 5), t + dt * (8.f / 9), t + dt};
-      sweep_step<S, H>(te, s_wt, s_ul, gxa, gxd, RS, RT, onmask, tmask, first, act, snap, mk);
+      const float e = -d5 * g6;
+      gy += e;
+      const float de = dt * e;
+      g1 = fmaf(de, 9017.f / 3168, g1); g2 = fmaf(de, -355.f / 33, g2); g3 = fmaf(de, 46732.f / 5247, g3);
+      g4 = fmaf(de, 49.f / 176, g4); g5 = fmaf(de, -5103.f / 18656, g5);
     }
-#pragma unroll
-    for (int s = 0; s < S; ++s) lam[s] = act ? gy[s] : lam[s];
+    sweep_sample<S>(te5, mk5, xa, xd, RSa, RSd, RTa, RTd, onmask, tmask, first, act, own, gs, snap);
+    {   // stage 5
+      xa = g5 * ap4; xd = -g5 * ys5 * dp4;
+      const float e = -d4 * g5;
+      gy += e;
+      const float de = dt * e;
+      g1 = fmaf(de, 19372.f / 6561, g1); g2 = fmaf(de, -25360.f / 2187, g2); g3 = fmaf(de, 64448.f / 6561, g3);
+      g4 = fmaf(de, -212.f / 729, g4);
+    }
+    sweep_sample<S>(te4, mk4, xa, xd, RSa, RSd, RTa, RTd, onmask, tmask, first, act, own, gs, snap);
+    {   // stage 4
+      xa = g4 * ap3; xd = -g4 * ys4 * dp3;
+      const float e = -d3 * g4;
+      gy += e;
+      const float de = dt * e;
+      g1 = fmaf(de, 44.f / 45, g1); g2 = fmaf(de, -56.f / 15, g2); g3 = fmaf(de, 32.f / 9, g3);
+    }
+    sweep_sample<S>(te3, mk3, xa, xd, RSa, RSd, RTa, RTd, onmask, tmask, first, act, own, gs, snap);
+    {   // stage 3
+      xa = g3 * ap2; xd = -g3 * ys3 * dp2;
+      const float e = -d2 * g3;
+      gy += e;
+      const float de = dt * e;
+      g1 = fmaf(de, 3.f / 40, g1); g2 = fmaf(de, 9.f / 40, g2);
+    }
+    sweep_sample<S>(te2, mk2, xa, xd, RSa, RSd, RTa, RTd, onmask, tmask, first, act, own, gs, snap);
+    {   // stage 2
+      xa = g2 * ap1; xd = -g2 * ys2 * dp1;
+      const float e = -d1 * g2;
+      gy += e;
+      g1 = fmaf(dt * e, 1.f / 5, g1);
+    }
+    sweep_sample<S>(te1, mk1, xa, xd, RSa, RSd, RTa, RTd, onmask, tmask, first, act, own, gs, snap);
+    // stage 1
+    xa = g1 * ap0; xd = -g1 * y * dp0;
+    gy = fmaf(-d0, g1, gy);
+    sweep_sample<S>(te0, mk0, xa, xd, RSa, RSd, RTa, RTd, onmask, tmask, first, act, own, gs, snap);
+    lam = act ? gy : lam;
+    t = t_n1; dt = dt_n1; y = y_n1;
+    t_n1 = t_n2; dt_n1 = dt_n2; y_n1 = y_n2;
   }
-  // ---- the units' partial sums -> this trajectory's column of the accumulators (each entry written once) ---------------------------
+#undef SLODE_LDREC
+  const bool any_bad = __syncthreads_or(live && bad) != 0;   // (also: every wave is done with the staged dL/dx rows)
+  if (tid == 0) row[0] = any_bad ? __builtin_nanf("") : 0.f;
+  // ---- the units' partial sums: every trajectory's terms go through one LDS tile [unit][term][trajectory] and are summed over the
+  //      workgroup's trajectories in a fixed order --------------------------------------------------------------------------------
   {
+    float* tile = s_big;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's own snapshot stores are back-readable
-#pragma unroll 1
+#pragma unroll 5
     for (int jj = 0; jj < H; ++jj) {
       const bool flipped = (tmask >> jj) & 1u, on_early = (onmask >> jj) & 1u;
-      const float wt = s_wt[jj], uj = s_ul[jj * DPW];
-      float gu = 0.f, gwt = 0.f;
-#pragma unroll
-      for (int c = 0; c < 2 * S; ++c) {
-        const float sm = flipped ? snap[jj * 4 * S + c] : 0.f, st = flipped ? snap[jj * 4 * S + 2 * S + c] : 0.f;
-        // on at early times: flipped ? total - snapshot : total;   off at early times: flipped ? snapshot : 0
-        const float gm = on_early ? RS[c] - sm : sm, gt = on_early ? RT[c] - st : st;
-        const float w = c < S ? wg[c * H + jj] : wd[(c - S) * H + jj];
-        acc[((c < S ? c * H : S * H + (c - S) * H) + jj) * DPW] = fmaf(wt, gt, uj * gm);
-        gu = fmaf(w, gm, gu);
-        gwt = fmaf(w, gt, gwt);
+      const float* sn = snap + jj * 4 * S + gs;
+      const float s0 = sn[0], s1 = sn[S], s2 = sn[2 * S], s3 = sn[3 * S];
+      const float sma = flipped ? s0 : 0.f, smd = flipped ? s1 : 0.f, sta = flipped ? s2 : 0.f, std_ = flipped ? s3 : 0.f;
+      // on at early times: flipped ? total - snapshot : total;   off at early times: flipped ? snapshot : 0
+      const float gma = on_early ? RSa - sma : sma, gmd = on_early ? RSd - smd : smd;
+      const float gta = on_early ? RTa - sta : sta, gtd = on_early ? RTd - std_ : std_;
+      const float wt = s_wt[jj], uj = s_us[jj];
+      const float w1 = s_wgd[jj * 16 + g], w2 = s_wgd[jj * 16 + 8 + g];   // 0 for lanes without a component
+      const float gu = group_add(fmaf(w1, gma, w2 * gmd)), gwt = group_add(fmaf(w1, gta, w2 * gtd));
+      if (own) {
+        tile[(jj * NTMP + g) * TS + slot] = fmaf(wt, gta, uj * gma);
+        tile[(jj * NTMP + S + g) * TS + slot] = fmaf(wt, gtd, uj * gmd);
       }
-      acc[(2 * S * H + 2 * S + jj) * DPW] = gu;
-      acc[(2 * S * H + 2 * S + H + jj) * DPW] = gwt;
+      if (g == 0) {
+        tile[(jj * NTMP + 2 * S) * TS + slot] = gu;
+        tile[(jj * NTMP + 2 * S + 1) * TS + slot] = gwt;
+        s_gu[slot * 32 + jj] = gu;
+      }
     }
-#pragma unroll
-    for (int c = 0; c < 2 * S; ++c) acc[(2 * S * H + c) * DPW] = RS[c];
+    if (own) {   // the constant-1 unit: head biases
+      tile[(H * NTMP + g) * TS + slot] = RSa;
+      tile[(H * NTMP + S + g) * TS + slot] = RSd;
+    }
+    __syncthreads();
+    for (int col = tid; col < (H + 1) * NTMP; col += BNT) {
+      const int jj = col / NTMP, c = col - jj * NTMP;
+      int o;
+      if (jj < H) o = c < S ? k.o_wg + c * H + jj : (c < 2 * S ? k.o_wd + (c - S) * H + jj : (c == 2 * S ? k.o_bh + jj : k.o_wh + jj * (1 + L)));
+      else o = c < S ? k.o_bg + c : (c < 2 * S ? k.o_bd + (c - S) : -1);
+      float acc = 0.f;
+      for (int r = 0; r < BTP; ++r) acc += tile[col * TS + r];
+      if (o >= 0) prm[o] = acc;
+    }
+    __syncthreads();
   }
-  // ---- init net: x0 = sigmoid(W2 relu(W1 z + b1) + b2); the j = 0 output is x0 itself ---------------------------------
-  float go[S];
+  // ---- init net: x0 = sigmoid(W2 relu(W1 z + b1) + b2); the j = 0 output is x0 itself -------------------------------------------
   {
-    float o[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) o[s] = b2[s];
-    for (int jj = 0; jj < H; ++jj) {
-      float p0 = b1[jj];
-      for (int l = 0; l < L; ++l) p0 = fmaf(w1[jj * L + l], s_z[l * DPW + lane], p0);
-      const float hj = fmaxf(p0, 0.f);
-#pragma unroll
-      for (int s = 0; s < S; ++s) o[s] = fmaf(w2[s * H + jj], hj, o[s]);
+    float* s_w1 = s_big;            // [H][L]
+    float* s_wz = s_big + H * L;    // [H][L]  z-columns of the dynamics net's hidden layer
+    for (int i = tid; i < H * L; i += BNT) {
+      const int jj = i / L, l = i - jj * L;
+      s_w1[i] = k.w1[i];
+      s_wz[i] = k.wh[jj * (1 + L) + 1 + l];
     }
+    const float x0 = init_state<S, H>(k.w2, k.b2, pre0, g, own);
+    const float g0 = (live && !bad && own) ? lam + gxb[0] : 0.f;
+    s_go[slot * 8 + g] = g0 * x0 * (1.f - x0);
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const float x0 = sigmoidf_fast(o[s]);
-      const float g = (live && !bad) ? lam[s] + gxb[s] : 0.f;
-      go[s] = g * x0 * (1.f - x0);
-    }
-  }
-  // zero this workgroup's slab row, then fill in the entries it owns
-  float* row = k.slabs + (long long)blockIdx.x * k.slab_stride;
-  const bool any_bad = __any(live && bad);
-  for (int i = lane; i <= k.nseg; i += DPW) row[i] = (i == 0 && any_bad) ? __builtin_nanf("") : 0.f;
-  __syncthreads();
-  float* prm = row + 1;
-  for (int jj = 0; jj < H; ++jj) {
-    float p0 = b1[jj];
-    for (int l = 0; l < L; ++l) p0 = fmaf(w1[jj * L + l], s_z[l * DPW + lane], p0);
-    const float hj = fmaxf(p0, 0.f);
-    float gh = 0.f;
+    for (int i = 0; i < JL; ++i) s_h0[slot * 32 + g + G * i] = fmaxf(pre0[i], 0.f);
+    __syncthreads();
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      gh = fmaf(w2[s * H + jj], go[s], gh);
-      const float v = wave_sum(go[s] * hj);
-      if (lane == 0) prm[k.o_w2 + s * H + jj] = v;
+    for (int i = 0; i < JL; ++i) {
+      const int jj = g + G * i;
+      float gh = 0.f;
+      if (jj < H)
+        for (int s = 0; s < S; ++s) gh = fmaf(k.w2[s * H + jj], s_go[slot * 8 + s], gh);
+      s_gp[slot * 32 + jj] = pre0[i] > 0.f ? gh : 0.f;
+      if (jj >= H) s_gu[slot * 32 + jj] = 0.f;
     }
-    const float gp = p0 > 0.f ? gh : 0.f;
-    s_u[jj * DPW + lane] = gp;            // u is dead: the column now holds dL/d(init pre-activation j)
-    const float v = wave_sum(gp);
-    if (lane == 0) prm[k.o_b1 + jj] = v;
-  }
-#pragma unroll
-  for (int s = 0; s < S; ++s) {
-    const float v = wave_sum(go[s]);
-    if (lane == 0) prm[k.o_b2 + s] = v;
-  }
-  __syncthreads();
-  // latent gradient of this trajectory: through the init net and (exact mode) through u = W_z z + b_h
-  const float* s_gu = s_acc + (2 * S * H + 2 * S) * DPW;
-  for (int l = 0; l < L; ++l) {
-    float g = 0.f;
-    for (int jj = 0; jj < H; ++jj) {
-      g = fmaf(w1[jj * L + l], s_u[jj * DPW + lane], g);
-      if (!k.drop_z) g = fmaf(wh[jj * (1 + L) + 1 + l], s_gu[jj * DPW + lane], g);
-    }
-    if (live) k.gz[(long long)b * L + l] = g;
-  }
-  // outer products with z over the workgroup's trajectories: lane = latent dim l (rotated column reads: no bank conflicts)
-  for (int l0 = 0; l0 < L; l0 += DPW) {
-    const int l = l0 + lane;
-    if (l < L)
+    __syncthreads();
+    // latent gradient of this trajectory: through the init net and (exact mode) through u = W_z z + b_h
+    for (int l = g; l < L; l += G) {
+      float gl = 0.f;
       for (int jj = 0; jj < H; ++jj) {
-        float a1 = 0.f, a2 = 0.f;
-        for (int r = 0; r < DPW; ++r) {
-          const int c = (r + lane) & (DPW - 1);
-          const float zl = s_z[l * DPW + c];
-          a1 = fmaf(s_u[jj * DPW + c], zl, a1);
-          a2 = fmaf(s_gu[jj * DPW + c], zl, a2);
-        }
-        prm[k.o_w1 + jj * L + l] = a1;
-        prm[k.o_wh + jj * (1 + L) + 1 + l] = a2;
+        gl = fmaf(s_w1[jj * L + l], s_gp[slot * 32 + jj], gl);
+        if (!k.drop_z) gl = fmaf(s_wz[jj * L + l], s_gu[slot * 32 + jj], gl);
       }
-  }
-  // per-lane columns -> sums over the workgroup's trajectories
-  for (int i = lane; i < NACC; i += DPW) {
-    float a = 0.f;
-    for (int r = 0; r < DPW; ++r) a += s_acc[i * DPW + ((r + lane) & (DPW - 1))];
-    int o;
-    if (i < S * H) o = k.o_wg + i;
-    else if (i < 2 * S * H) o = k.o_wd + (i - S * H);
-    else if (i < 2 * S * H + S) o = k.o_bg + (i - 2 * S * H);
-    else if (i < 2 * S * H + 2 * S) o = k.o_bd + (i - 2 * S * H - S);
-    else if (i < 2 * S * H + 2 * S + H) o = k.o_bh + (i - 2 * S * H - 2 * S);
-    else o = k.o_wh + (i - 2 * S * H - 2 * S - H) * (1 + L);
-    prm[o] = a;
+      if (live) {
+        const long long i = bb * L + l;
+        k.g_loc[i] += gl;
+        k.g_scale[i] = fmaf(gl, k.eps[i], k.g_scale[i]);
+      }
+    }
+    // sums over the workgroup's trajectories (fixed order): outer products with z, with the init net's hidden values, bias columns
+    for (int o = tid; o < H * L; o += BNT) {
+      const int jj = o / L, l = o - jj * L;
+      float a1 = 0.f, a2 = 0.f;
+      for (int r = 0; r < BTP; ++r) {
+        const float zl = s_z[r * L + l];
+        a1 = fmaf(s_gp[r * 32 + jj], zl, a1);
+        a2 = fmaf(s_gu[r * 32 + jj], zl, a2);
+      }
+      prm[k.o_w1 + o] = a1;
+      prm[k.o_wh + jj * (1 + L) + 1 + l] = a2;
+    }
+    for (int o = tid; o < S * H + H + S; o += BNT) {
+      float acc = 0.f;
+      if (o < S * H) {
+        const int s = o / H, jj = o - s * H;
+        for (int r = 0; r < BTP; ++r) acc = fmaf(s_go[r * 8 + s], s_h0[r * 32 + jj], acc);
+        prm[k.o_w2 + o] = acc;
+      } else if (o < S * H + H) {
+        const int jj = o - S * H;
+        for (int r = 0; r < BTP; ++r) acc += s_gp[r * 32 + jj];
+        prm[k.o_b1 + jj] = acc;
+      } else {
+        const int s = o - S * H - H;
+        for (int r = 0; r < BTP; ++r) acc += s_go[r * 8 + s];
+        prm[k.o_b2 + s] = acc;
+      }
+    }
   }
 }
 
-}  // namespace lane64
+}  // namespace grp
 
 }  // namespace
 
-int slode_dopri5_rows(const slode_shape& s) { return (s.B + 63) / 64; }   // slab rows of the reverse sweep: one per workgroup of 64 trajectories
+int slode_dopri5_rows(const slode_shape& s) { return (s.B + grp::BTP - 1) / grp::BTP; }   // slab rows of the reverse sweep: one per workgroup
 
 int slode_dopri5_kmax(const slode_shape& s) {
   // record capacity per trajectory: 256 MB of (t, dt, y) records, within [64, 2048] steps
@@ -717,29 +732,35 @@ hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, co
 }
 
 hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay, const float* p, const float* times, const DopriRec& rec,
-                                   const float* gx, float* gz, float* slabs, int slab_stride, int drop_z, float* snap, hipStream_t stream) {
+                                   const float* gx, float* g_loc, float* g_scale, float* slabs, int slab_stride, int drop_z, float* snap,
+                                   hipStream_t stream) {
   DpBK k;
-  k.snap = snap;
+  k.snap = snap; k.g_loc = g_loc; k.g_scale = g_scale; k.eps = rec.eps;
   k.B = s.B; k.T = s.T; k.L = s.L; k.kmax = rec.kmax; k.drop_z = drop_z;
   k.times = times; k.z = rec.z_out; k.gx = gx; k.rec = rec.rec; k.nrec = rec.nrec;
   k.w1 = p + lay.init_w1; k.b1 = p + lay.init_b1; k.w2 = p + lay.init_w2; k.b2 = p + lay.init_b2;
   k.wh = p + lay.dyn_wh; k.bh = p + lay.dyn_bh; k.wg = p + lay.dyn_wg; k.bg = p + lay.dyn_bg; k.wd = p + lay.dyn_wd; k.bd = p + lay.dyn_bd;
-  k.gz = gz; k.slabs = slabs; k.slab_stride = slab_stride; k.nseg = lay.ode_end - lay.ode_begin;
+  k.slabs = slabs; k.slab_stride = slab_stride; k.nseg = lay.ode_end - lay.ode_begin;
   const int ob = lay.ode_begin;
   k.o_w1 = lay.init_w1 - ob; k.o_b1 = lay.init_b1 - ob; k.o_w2 = lay.init_w2 - ob; k.o_b2 = lay.init_b2 - ob;
   k.o_wh = lay.dyn_wh - ob; k.o_bh = lay.dyn_bh - ob; k.o_wg = lay.dyn_wg - ob; k.o_bg = lay.dyn_bg - ob;
   k.o_wd = lay.dyn_wd - ob; k.o_bd = lay.dyn_bd - ob;
   {
-    using namespace lane64;
+    using namespace grp;
     const int grid = slode_dopri5_rows(s);
-    const size_t lds = sizeof(float) * (32 + (size_t)s.H * DPW + (size_t)s.L * DPW + (size_t)(2 * s.S * s.H + 2 * s.S + 2 * s.H) * DPW);
+    const size_t fixed = 32 + (size_t)s.H * 16 + (size_t)BTP * 32 * 4 + BTP * 8 + (size_t)BTP * s.L + (size_t)((s.T + 3) & ~3);
+    const size_t tile = (size_t)(s.H + 1) * (2 * s.S + 2) * TS, wz = 2 * (size_t)s.H * s.L, gxrows = (size_t)BTP * s.T * s.S;
+    size_t big = tile > wz ? tile : wz;
+    k.stage_gx = sizeof(float) * (fixed + (gxrows > big ? gxrows : big)) <= 80 * 1024 ? 1 : 0;   // dL/dx rows in LDS when two workgroups still fit a CU
+    if (k.stage_gx && gxrows > big) big = gxrows;
+    const size_t lds = sizeof(float) * (fixed + big);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (s.H == 25 && s.S == 5) {
-      (void)hipFuncSetAttribute((const void*)lane64::dopri5_bwd_kernel<5, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((lane64::dopri5_bwd_kernel<5, 25>), dim3(grid), dim3(DPW), lds, stream, k);
+      (void)hipFuncSetAttribute((const void*)grp::dopri5_bwd_kernel<5, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((grp::dopri5_bwd_kernel<5, 25>), dim3(grid), dim3(BNT), lds, stream, k);
     } else if (s.H == 25 && s.S == 8) {
-      (void)hipFuncSetAttribute((const void*)lane64::dopri5_bwd_kernel<8, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((lane64::dopri5_bwd_kernel<8, 25>), dim3(grid), dim3(DPW), lds, stream, k);
+      (void)hipFuncSetAttribute((const void*)grp::dopri5_bwd_kernel<8, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((grp::dopri5_bwd_kernel<8, 25>), dim3(grid), dim3(BNT), lds, stream, k);
     } else return hipErrorInvalidValue;
   }
   return hipGetLastError();

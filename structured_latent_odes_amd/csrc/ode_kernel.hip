@@ -81,7 +81,7 @@ struct OdeK {
   const float *enc_hid, *enc_zloc_w, *enc_zls_w;
   float *g_pre, *glat;   // g_pre [B][64]; glat [B][128], row = [g_loc (L) | pad to 64 | g_scale * scale (L) | pad]
   // externally solved trajectories (dopri5 training, generic instantiation only; see OdeLaunch)
-  const float *x_ext, *gz_ext;
+  const float* x_ext;
   float* gx_out;
   int Hc;
   // gradient-segment elements no phase of this launch owns (zero gradient: written as zeros once per workgroup), relative to ode_begin
@@ -997,8 +997,6 @@ ode_elbo_kernel(const OdeK k) {
       const float* gi = k.gx_in + (long long)b * T * S;
       for (int i = tid; i < T * S; i += NT) s_lam[i] = gi[i];
     }
-    // scorer pass 1 of dopri5 training only produces dLoss/dx: the workgroup is done (uniform exit; pass 2 rewrites every other output)
-    if (BWD && ONE && ext && k.gx_out) return;
 
     if (BWD) {
       if (RA && !ext) {
@@ -1336,7 +1334,6 @@ ode_elbo_kernel(const OdeK k) {
         for (int off = Lp; off < 64; off <<= 1) gz += __shfl_xor(gz, off, 64);
         if (tid < L) {
           gz += s_gzl[l];
-          if (T_ == 0 && k.gz_ext) gz += k.gz_ext[(long long)b * L + l];
           for (int hd = 0; hd < k.n_aux; ++hd) {
             const slode_aux ax = k.aux[hd];
             if (l >= ax.z_off && l < ax.z_off + ax.z_dim)
@@ -1566,7 +1563,7 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   k.x_out = a.x_out; k.z_out = a.z_out; k.g_loc = a.g_loc; k.g_scale = a.g_scale; k.slabs = a.slabs;
   k.slab_stride = a.slab_stride; k.backward = a.backward; k.with_ll = a.with_ll;
   k.enc_hid = a.enc_hid; k.g_pre = a.g_pre; k.glat = a.glat; k.Hc = s.Hc;
-  k.x_ext = a.x_ext; k.gx_out = a.gx_out; k.gz_ext = a.gz_ext;
+  k.x_ext = a.x_ext; k.gx_out = a.gx_out;
   k.enc_zloc_w = p + lay.zloc_w; k.enc_zls_w = p + lay.zls_w;
 
   const int nthreads = slode_ode_threads(s);

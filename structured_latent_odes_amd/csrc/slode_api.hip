@@ -443,21 +443,16 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     a.force_loop = h->ode_loop; a.force_generic = h->ode_generic; a.alg = h->ode_alg;
     if (bwd && folded) { a.enc_hid = w.hid; a.g_pre = w.g_pre; a.glat = w.glat; a.g_loc = nullptr; a.g_scale = nullptr; }
     if (dp5) {
-      // adaptive solve (per-trajectory controller, accepted steps recorded) -> scorer pass 1: loss terms, dLoss/dx -> reverse mode
-      // over the records: solver-side gradients as extra slab rows + the latent gradient -> scorer pass 2 (below) folds that in
+      // adaptive solve (per-trajectory controller, accepted steps recorded) -> ONE scorer pass (loss terms, dLoss/dx, every gradient
+      // that does not flow through the solver, its own share of the latent gradient into g_loc / g_scale) -> reverse mode over the
+      // records: solver-side gradients as extra slab rows, the latent gradient through the solver added to g_loc / g_scale -> the
+      // unfused encoder tail below
       DopriRec rc{w.loc, w.scale, eps, w.dp_z, bwd ? w.dp_rec : nullptr, w.dp_nrec, w.dp_kmax};
       HIP_TRY(h, slode_launch_dopri5(*s, *lay, params, times, nullptr, w.dp_x, st, &rc));
       a.x_ext = w.dp_x;
       if (bwd) {
         a.gx_out = w.dp_gx;
-        e = slode_launch_ode(a, st, h->err, sizeof(h->err));
-        if (e == hipErrorInvalidValue) return SLODE_EINVAL;
-        HIP_TRY(h, e);
-        rc.rec = w.dp_rec;
-        HIP_TRY(h, slode_launch_dopri5_bwd(*s, *lay, params, times, rc, w.dp_gx, w.dp_gz, w.ode_slabs + (size_t)w.ode_grid * w.ode_stride,
-                                           w.ode_stride, s->grad_mode == SLODE_GRAD_REFERENCE_ADJOINT ? 1 : 0, w.dp_snap, st));
-        a.gx_out = nullptr;
-        a.gz_ext = w.dp_gz;
+        a.enc_hid = nullptr; a.g_pre = nullptr; a.glat = nullptr; a.g_loc = w.g_loc; a.g_scale = w.g_scale;
         n_slabs = w.ode_grid + w.dp_rows;
       }
     }
@@ -466,10 +461,15 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
       if (e == hipErrorInvalidValue) return SLODE_EINVAL;
       HIP_TRY(h, e);
     }
+    if (dp5 && bwd) {
+      DopriRec rc{w.loc, w.scale, eps, w.dp_z, w.dp_rec, w.dp_nrec, w.dp_kmax};
+      HIP_TRY(h, slode_launch_dopri5_bwd(*s, *lay, params, times, rc, w.dp_gx, w.g_loc, w.g_scale, w.ode_slabs + (size_t)w.ode_grid * w.ode_stride,
+                                         w.ode_stride, s->grad_mode == SLODE_GRAD_REFERENCE_ADJOINT ? 1 : 0, w.dp_snap, st));
+    }
   }
   SLODE_MARK(3);
 
-  if (bwd && folded && !aux_mode) {
+  if (bwd && folded && !aux_mode && !dp5) {
     // Fused tail.  The ODE kernel has already run the encoder heads + tanh backward (g_pre, glat): three launches remain --
     // split-K MFMA GEMMs (+ rider blocks: stage 1 of the ODE-slab reduction), chain rule, one final reduction (+ Adam).
     AdamHost ah{};

@@ -241,10 +241,10 @@ struct OdeLaunch {
   float* g_pre = nullptr;
   float* glat = nullptr;   // [B][128] = [g_loc (L) | pad to 64 | g_scale * scale (L) | pad]
   // externally solved trajectories (dopri5 training; generic instantiation only): the kernel scores x_ext instead of its own solve,
-  // writes dLoss/dx to gx_out, back-propagates nothing through its solver and adds gz_ext to the latent gradient
+  // writes dLoss/dx to gx_out and back-propagates nothing through a solver of its own (the adaptive solver's reverse sweep adds its
+  // share of the latent gradient to g_loc / g_scale afterwards)
   const float* x_ext = nullptr;   // [B][T][S]
   float* gx_out = nullptr;        // [B][T][S]
-  const float* gz_ext = nullptr;  // [B][L]
   int force_loop = 0, force_generic = 0, alg = 0;   // handle flags (slode_ctx)
 };
 hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, size_t errlen);
@@ -365,7 +365,7 @@ int slode_dopri5_rows(const slode_shape& s);
 hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const float* z,
                                float* x, hipStream_t stream, const DopriRec* rec = nullptr);
 hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const DopriRec& rec,
-                                   const float* gx, float* gz, float* slabs, int slab_stride, int drop_z, float* snap, hipStream_t stream);
+                                   const float* gx, float* g_loc, float* g_scale, float* slabs, int slab_stride, int drop_z, float* snap, hipStream_t stream);
 hipError_t slode_launch_adam_k(int64_t n, const float* g, const AdamHost& a, hipStream_t stream);
 hipError_t slode_launch_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2,
                              float eps, int64_t step, hipStream_t stream);
