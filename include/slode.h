@@ -244,6 +244,11 @@ int slode_adam_step(slode_handle h, int64_t n, float* params, const float* grads
  * slode_elbo_adam_step, slode_aux_step).  Default: empty region. */
 int slode_adam_region(slode_handle h, int64_t lo, int64_t hi, int64_t step_delta);
 
+/* Diagnostic (no reference counterpart; torchdiffeq does not report it): accepted steps per trajectory of the last dopri5 training
+ * step run on this workspace -> counts[B] (int32, device).  -1: 20,000 attempted steps exhausted; > capacity: record overflow. */
+int slode_dopri5_step_counts(slode_handle h, const slode_shape* s, const slode_layout* lay, const void* workspace,
+                             size_t workspace_bytes, int* counts, void* stream);
+
 /* Measurement aid for bench.py's roofline block (no reference counterpart): when enabled, slode_elbo_step records HIP
  * events on `stream` around each of its kernels; slode_profile_read waits for the last one and returns the durations in
  * milliseconds of [fold (W_eff), encoder_fwd, ode_elbo (fused solve + ELBO fwd/bwd), encoder_bwd (heads),

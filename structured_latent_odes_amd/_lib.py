@@ -44,7 +44,7 @@ EXPORTS = ["slode_version", "slode_create", "slode_destroy", "slode_last_error",
            "slode_num_stage_times", "slode_workspace_bytes", "slode_stage_times", "slode_encoder_conv_fwd",
            "slode_encoder_conv_bwd", "slode_ode_solve_fwd", "slode_ode_solve_bwd", "slode_decode_heads",
            "slode_elbo_step", "slode_adam_step", "slode_profile_enable", "slode_profile_read", "slode_dynamics_eval", "slode_elbo_adam_step", "slode_aux_step", "slode_adam_region",
-           "slode_initialize_state", "slode_prior_nets", "slode_label_heads"]
+           "slode_initialize_state", "slode_prior_nets", "slode_label_heads", "slode_dopri5_step_counts"]
 
 _lib = None
 
@@ -93,6 +93,7 @@ def load():
     lib.slode_initialize_state.argtypes = [VP, P(Shape), P(Layout), VP, VP, VP, VP]
     lib.slode_prior_nets.argtypes = [VP, P(Shape), P(Layout), VP, VP, VP, VP, VP]
     lib.slode_label_heads.argtypes = [VP, P(Shape), P(Layout), VP, VP, VP, VP]
+    lib.slode_dopri5_step_counts.argtypes = [VP, P(Shape), P(Layout), VP, C.c_size_t, VP, VP]
     lib.slode_profile_enable.argtypes = [VP, C.c_int]
     lib.slode_profile_read.argtypes = [VP, P(C.c_float)]
     for name in EXPORTS:

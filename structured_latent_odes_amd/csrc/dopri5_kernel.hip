@@ -7,26 +7,28 @@
 // rtol*max(|y0|,|y1|))), factor clamp [0.2, 10] with safety 0.9, quartic dense output through (y0, y_mid, y1, f0, f1)) --
 // validated at solution level against the oracle's per-trajectory restatement and scipy RK45.
 //
-// Mapping: EIGHT LANES PER TRAJECTORY (8 trajectories per wave).  An adaptive solve is one long dependent chain per trajectory,
-// so its latency -- not the FLOPs -- sets the kernel time; the chain is shortened by spreading the hidden layer over the group:
-// lane g owns hidden units {g, g+8, g+16, g+24} (weights in its registers) and state component g.  One evaluation of the
-// dynamics coefficients is 4 relu + 8*S partial FMAs per lane and a halving butterfly over the group (7 shuffles per 8-vector)
-// that leaves lane g with pre-activation g: one sigmoid pair per lane, and all the Runge-Kutta arithmetic is scalar per lane.
+// Mapping: EIGHT LANES PER TRAJECTORY (8 trajectories per wave), lane g = state component g.  An adaptive solve is one long
+// dependent chain per trajectory, so its latency -- not the FLOPs -- sets the kernel time.  The chain is kept short by the structure
+// of the dynamics net: its hidden layer is relu(w_t t + u_j), so the head pre-activations are piecewise linear in t and a lane
+// reads value and slope of its two heads from a per-trajectory table of the H + 1 linear segments (load_units / eval_ad): one
+// evaluation of the coefficients is 4 compares per lane, an OR butterfly over the group on the DPP crossbar, a popcount, one LDS row,
+// 2 fmas and one sigmoid pair -- branch-free, the evaluations of a step independent of each other; all the Runge-Kutta arithmetic is
+// scalar per lane.
 //
 // Training with dopri5 (BASELINE config[2]): the forward kernel also records every accepted step (t, dt, y) and
 // `dopri5_bwd_kernel` walks a trajectory's record backwards -- the exact reverse mode of the accepted Dormand-Prince steps and of
 // the dense-output polynomial, step sizes held fixed (the controller is not differentiated) -- in the same 8-lane mapping.  The
 // right-hand side is linear in the state with coefficients that depend on time only, so a step's seven stages are re-evaluated from
 // its recorded (t, dt, y) instead of being stored, and the reverse mode is component-wise: one scalar of everything per lane.  The
-// coefficients are re-evaluated incrementally (grp::Incr) and the weight gradients come from running sums parked at each hidden
-// unit's switching time (grp::sweep_sample).  A workgroup's 16 trajectories are summed in a fixed order into one slab row in the
+// coefficients come from the same segment table and the weight gradients from running sums parked at each hidden unit's switching
+// time (grp::sweep_sample).  A workgroup's 16 trajectories are summed in a fixed order into one slab row in the
 // layout of the fixed-grid kernel's slabs (reduced by the same deterministic tail).
 #include "slode_common.h"
 
 namespace {
 
 constexpr int G = 8;            // lanes per trajectory
-constexpr int DNT = 256;        // threads per workgroup
+constexpr int DNT = 128;        // threads per workgroup (B = 4096: 256 workgroups, one per CU)
 constexpr int TPB = DNT / G;    // trajectories per workgroup
 constexpr int JL = 4;           // hidden units per lane (H <= 32)
 
@@ -65,70 +67,58 @@ __device__ __forceinline__ float group_scatter8(float (&v)[8], int g) {
   const float keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1];
   return keep + __shfl_xor(send, 1, 64);
 }
-__device__ __forceinline__ float group_sum(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+// butterflies over the 8 lanes of a trajectory on the DPP crossbar (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror): every
+// lane of the group ends with the same bits (each step adds the same two operands on both sides)
+__device__ __forceinline__ unsigned group_or(unsigned v) {
+  v |= dpp_u<0xB1>(v);
+  v |= dpp_u<0x4E>(v);
+  v |= dpp_u<0x141>(v);
+  return v;
+}
+__device__ __forceinline__ float group_add(float v) {
+  v += __uint_as_float(dpp_u<0xB1>(__float_as_uint(v)));
+  v += __uint_as_float(dpp_u<0x4E>(__float_as_uint(v)));
+  v += __uint_as_float(dpp_u<0x141>(__float_as_uint(v)));
   return v;
 }
 
-// a lane's share of the dynamics net: its hidden units (time weight, offset u = W_z z + b, rows of the two heads) and the head
-// biases of its state component
-template <int S>
-struct Unit {
-  float wt[JL], u[JL], wg[JL][S], wd[JL][S];
-  float bg, bd;
+// The hidden layer is relu(w_t t + u_j): unit j switches at th_j = -u_j / w_t,j, so between two consecutive switching times the head
+// pre-activations o_c(t) = bias_c + sum_{j on} W_cj (w_t,j t + u_j) are LINEAR in t.  Per trajectory the H + 1 segments are tabulated
+// once (load_units): row r = (value of the growth / degradation head of component g at the segment's centre, their slopes), the
+// segments ordered by switching time.  The segment of a time t is the NUMBER of switching times <= t -- a popcount of the group's
+// "t >= th_j" bits, no search -- so one evaluation of the coefficients is 4 compares per lane, an OR butterfly over the group on the
+// DPP crossbar, one 16-byte LDS read, 2 fmas and a sigmoid pair: branch-free, and the evaluations of one step are independent.
+// (The switch is placed at the rounded th_j instead of at the exact sign change of fma(w_t, t, u_j): the heads are continuous there,
+// the difference is a few ulp of o_c.)
+constexpr float BIGT = 3.0e38f;
+struct Units {
+  float wt[JL], u[JL];   // this lane's hidden units g, g+8, g+16, g+24
+  float th[JL];          // their switching times (+BIGT beyond H: never passed)
 };
-
-// growth / degradation coefficient of this lane's state component at time t: a = sigmoid(Wg h + bg), d = sigmoid(Wd h + bd),
-// h = relu(wt t + u)   (blackbox_ode.py:97-109)
-template <int S>
-__device__ __forceinline__ void eval_ad(float t, const Unit<S>& w, int g, bool own, float& a, float& d) {
-  float xa[8], xd[8];
+// bit j: t >= th_j (the same word in the 8 lanes of a trajectory)
+__device__ __forceinline__ unsigned ge_bits(float t, const Units& w, int g) {
+  unsigned m = 0u;
 #pragma unroll
-  for (int s = 0; s < 8; ++s) xa[s] = xd[s] = 0.f;
-#pragma unroll
-  for (int i = 0; i < JL; ++i) {
-    const float h = fmaxf(fmaf(w.wt[i], t, w.u[i]), 0.f);
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      xa[s] = fmaf(w.wg[i][s], h, xa[s]);
-      xd[s] = fmaf(w.wd[i][s], h, xd[s]);
-    }
-  }
-  const float pa = group_scatter8(xa, g) + w.bg, pd = group_scatter8(xd, g) + w.bd;
-  a = own ? sigmoidf_fast(pa) : 0.f;
-  d = own ? sigmoidf_fast(pd) : 0.f;
+  for (int i = 0; i < JL; ++i) m |= (t >= w.th[i]) ? (1u << (g + G * i)) : 0u;
+  return group_or(m);
 }
-
-// latent sample of the workgroup's trajectories -> LDS; this lane's units; returns the init-net hidden values of its units
-template <int S, int H>
-__device__ __forceinline__ void load_units(const float* wh, const float* bh, const float* wg, const float* bg, const float* wd, const float* bd,
-                                           const float* w1, const float* b1, const float* zrow, int L, int g, bool own, Unit<S>& w,
-                                           float (&pre0)[JL]) {
-#pragma unroll
-  for (int i = 0; i < JL; ++i) {
-    const int j = g + G * i;
-    const bool valid = j < H;
-    const int jj = valid ? j : 0;
-    float uj = bh[jj], pj = b1[jj];
-    for (int l = 0; l < L; ++l) {
-      const float zl = zrow[l];
-      uj = fmaf(wh[jj * (1 + L) + 1 + l], zl, uj);
-      pj = fmaf(w1[jj * L + l], zl, pj);
-    }
-    w.wt[i] = valid ? wh[jj * (1 + L)] : 0.f;
-    w.u[i] = valid ? uj : 0.f;
-    pre0[i] = valid ? pj : 0.f;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      w.wg[i][s] = valid ? wg[s * H + jj] : 0.f;
-      w.wd[i][s] = valid ? wd[s * H + jj] : 0.f;
-    }
-  }
-  w.bg = own ? bg[g] : 0.f;
-  w.bd = own ? bd[g] : 0.f;
+// growth / degradation coefficient of this lane's state component at time t (blackbox_ode.py:97-109); returns the bits
+template <int H>
+__device__ __forceinline__ unsigned eval_ad(float t, const Units& w, int g, bool own, const float4* __restrict__ tab,
+                                            const float* __restrict__ ctr, float& a, float& d) {
+  const unsigned ge = ge_bits(t, w, g);
+  const int r = __builtin_popcount(ge);
+  const float4 row = tab[r * G + g];
+  const float dtau = t - ctr[r];
+  a = own ? sigmoidf_fast(fmaf(row.z, dtau, row.x)) : 0.f;
+  d = own ? sigmoidf_fast(fmaf(row.w, dtau, row.y)) : 0.f;
+  return ge;
 }
+// bit j: unit j on, given the ge bits (dir bit 1: w_t >= 0, on from th_j upwards; 0: on below th_j)
+__device__ __forceinline__ unsigned on_bits(unsigned ge, unsigned dirmask) { return ~(ge ^ dirmask); }
 
 // x0 = sigmoid(W2 relu(W1 z + b1) + b2), this lane's component (blackbox_ode.py:19-22)
 template <int S, int H>
@@ -147,15 +137,129 @@ __device__ __forceinline__ float init_state(const float* w2, const float* b2, co
   return own ? sigmoidf_fast(v + b2[g]) : 0.f;
 }
 
+// LDS of one trajectory group: the shared tables (time weights, head weights by unit) and per trajectory the hidden offsets, the
+// switching times, their order, the segment centres and the segment table
+template <int H>
+struct GroupLds {
+  float *wt, *wgd, *u, *th, *ctr;
+  int* ord;
+  float4* tab;
+  static constexpr int floats(int ntraj) { return 32 + H * 16 + ntraj * 32 * 4 + ntraj * (H + 1) * G * 4; }
+  __device__ __forceinline__ float* carve(float* base, int ntraj) {   // base 16-byte aligned; returns the first float behind
+    tab = reinterpret_cast<float4*>(base);
+    wt = base + ntraj * (H + 1) * G * 4;
+    wgd = wt + 32;
+    u = wgd + H * 16;
+    th = u + ntraj * 32;
+    ctr = th + ntraj * 32;
+    ord = reinterpret_cast<int*>(ctr + ntraj * 32);
+    return ctr + ntraj * 64;
+  }
+};
+
+// Fills the shared tables, this lane's hidden units (offsets u = W_z z + b_h of the dynamics net -> registers + LDS, pre-activations of
+// the init net -> pre0) and the trajectory's segment table.  [tlo, thi]: the integration range (segment centres are clamped to it).
+// Returns the dir bits.  Contains barriers: every thread of the workgroup calls it.
+template <int S, int H>
+__device__ __forceinline__ unsigned load_units(const float* wh, const float* bh, const float* wg, const float* bg, const float* wd,
+                                               const float* bd, const float* w1, const float* b1, const float* zrow, int L, int tid,
+                                               int nthreads, float tlo, float thi, const GroupLds<H>& m, Units& w, float (&pre0)[JL]) {
+  const int g = tid & (G - 1), slot = tid >> 3;
+  const bool own = g < S;
+  if (tid < 32) m.wt[tid] = tid < H ? wh[tid * (1 + L)] : 0.f;
+  for (int i = tid; i < H * 16; i += nthreads) {
+    const int j = i >> 4, c = i & 15, gg = c & 7;
+    m.wgd[i] = gg < S ? (c < 8 ? wg[gg * H + j] : wd[gg * H + j]) : 0.f;
+  }
+  float* s_us = m.u + slot * 32;
+  float* s_th = m.th + slot * 32;
+  unsigned dm = 0u;
+#pragma unroll
+  for (int i = 0; i < JL; ++i) {
+    const int j = g + G * i;
+    const bool valid = j < H;
+    const int jj = valid ? j : 0;
+    float uj = bh[jj], pj = b1[jj];
+    for (int l = 0; l < L; ++l) {
+      const float zl = zrow[l];
+      uj = fmaf(wh[jj * (1 + L) + 1 + l], zl, uj);
+      pj = fmaf(w1[jj * L + l], zl, pj);
+    }
+    const float wt = valid ? wh[jj * (1 + L)] : 0.f;
+    w.wt[i] = wt;
+    w.u[i] = valid ? uj : 0.f;
+    pre0[i] = valid ? pj : 0.f;
+    // switching time; w_t == 0: the predicate is the sign of u (always / never on)
+    float th = wt != 0.f ? -uj / wt : (uj > 0.f ? -BIGT : BIGT);
+    th = fminf(fmaxf(th, -BIGT), BIGT);
+    if (!valid) th = BIGT;
+    w.th[i] = th;
+    dm |= (wt >= 0.f || !valid) ? (1u << j) : 0u;
+    s_us[j] = w.u[i];
+    s_th[j] = th;
+  }
+  const unsigned dirmask = group_or(dm);
+  __syncthreads();
+  // order of the switching times: rank by counting (ties by unit index)
+  {
+    int rank[JL];
+#pragma unroll
+    for (int i = 0; i < JL; ++i) rank[i] = 0;
+    for (int kk = 0; kk < H; ++kk) {
+      const float thk = s_th[kk];
+#pragma unroll
+      for (int i = 0; i < JL; ++i) rank[i] += (thk < w.th[i] || (thk == w.th[i] && kk < g + G * i)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < JL; ++i)
+      if (g + G * i < H) m.ord[slot * 32 + rank[i]] = g + G * i;
+  }
+  __syncthreads();
+  // segment table, event by event in the centred form: V(c') = V(c) + slope (c' - c) +- W pre(c'), slope +- W w_t
+  {
+    float4* tab = m.tab + slot * (H + 1) * G;
+    float* ctr = m.ctr + slot * 32;
+    float c = tlo;
+    float va = own ? bg[g] : 0.f, vd = own ? bd[g] : 0.f, ala = 0.f, ald = 0.f;
+    for (int j = 0; j < H; ++j) {   // below every switching time the units with w_t < 0 are on
+      const bool on = !((dirmask >> j) & 1u);
+      const float wt = m.wt[j], pre = fmaf(wt, c, s_us[j]);
+      const float h = on ? pre : 0.f, hw = on ? wt : 0.f;
+      const float w1_ = m.wgd[j * 16 + g], w2_ = m.wgd[j * 16 + 8 + g];
+      va = fmaf(w1_, h, va); vd = fmaf(w2_, h, vd);
+      ala = fmaf(w1_, hw, ala); ald = fmaf(w2_, hw, ald);
+    }
+    tab[g] = make_float4(va, vd, ala, ald);
+    if (g == 0) ctr[0] = c;
+    for (int r = 0; r < H; ++r) {
+      const int j = m.ord[slot * 32 + r];
+      const float c1 = fminf(fmaxf(s_th[j], tlo), thi);
+      const float wt = m.wt[j], sg = ((dirmask >> j) & 1u) ? 1.f : -1.f;
+      const float pre = sg * fmaf(wt, c1, s_us[j]), swt = sg * wt;
+      const float w1_ = m.wgd[j * 16 + g], w2_ = m.wgd[j * 16 + 8 + g];
+      const float dc = c1 - c;
+      va = fmaf(w1_, pre, fmaf(ala, dc, va)); vd = fmaf(w2_, pre, fmaf(ald, dc, vd));
+      ala = fmaf(w1_, swt, ala); ald = fmaf(w2_, swt, ald);
+      c = c1;
+      tab[(r + 1) * G + g] = make_float4(va, vd, ala, ald);
+      if (g == 0) ctr[r + 1] = c;
+    }
+  }
+  __syncthreads();
+  return dirmask;
+}
+
 template <int S>
-__device__ __forceinline__ float group_rms(float v, bool own) { return sqrtf(group_sum(own ? v * v : 0.f) * (1.0f / S)); }
+__device__ __forceinline__ float group_rms(float v, bool own) { return sqrtf(group_add(own ? v * v : 0.f) * (1.0f / S)); }
 
 template <int S, int H>
 __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
-  static_assert(S <= G && H <= G * JL, "one state component and JL hidden units per lane");
+  static_assert(S <= G && H <= G * JL && H <= 32, "one state component and JL hidden units per lane; unit bits in one word");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_z = smem;                  // [TPB][L]
   const int tid = threadIdx.x, g = tid & (G - 1), slot = tid >> 3, b = blockIdx.x * TPB + slot, L = k.L, T = k.T;
+  GroupLds<H> m;
+  float* s_z = m.carve(smem, TPB);      // [TPB][L]
+  float* s_times = s_z + TPB * L;       // [T]
   const bool live = b < k.B, own = g < S;
   const long long bb = live ? b : 0;
   for (int l = g; l < L; l += G) {
@@ -167,18 +271,23 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
     }
     s_z[slot * L + l] = zl;
   }
+  for (int i = tid; i < T; i += DNT) s_times[i] = k.times[i];
   __syncthreads();
-  Unit<S> w;
+  Units w;
   float pre0[JL];
-  load_units<S, H>(k.wh, k.bh, k.wg, k.bg, k.wd, k.bd, k.w1, k.b1, s_z + slot * L, L, g, own, w, pre0);
+  const float t_first = s_times[0], t_last = s_times[T - 1];
+  load_units<S, H>(k.wh, k.bh, k.wg, k.bg, k.wd, k.bd, k.w1, k.b1, s_z + slot * L, L, tid, DNT, fminf(t_first, t_last), fmaxf(t_first, t_last),
+                   m, w, pre0);
+  const float4* tab = m.tab + slot * (H + 1) * G;
+  const float* ctr = m.ctr + slot * 32;
   float y = init_state<S, H>(k.w2, k.b2, pre0, g, own);
   const int gs = own ? g : 0;
   float* xo = k.x + bb * T * S;
   if (live && own) xo[gs] = y;
   const float rtol = k.rtol, atol = k.atol;
-  float t = k.times[0];
+  float t = t_first;
   float a, d;
-  eval_ad<S>(t, w, g, own, a, d);
+  eval_ad<H>(t, w, g, own, tab, ctr, a, d);
   float fcur = a - d * y;
   // Hairer's initial step (torchdiffeq _select_initial_step, order 4)
   float dt;
@@ -187,7 +296,7 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
     const float d0 = group_rms<S>(y / sc, own), d1 = group_rms<S>(fcur / sc, own);
     const float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
     const float y1 = fmaf(h0, fcur, y);
-    eval_ad<S>(t + h0, w, g, own, a, d);
+    eval_ad<H>(t + h0, w, g, own, tab, ctr, a, d);
     const float f1 = a - d * y1;
     const float d2 = group_rms<S>((f1 - fcur) / sc, own) / h0;
     const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
@@ -195,23 +304,26 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
   }
   int j = 1;
   int steps = 0, nacc = 0;
-  // every lane leaves the loop: either all outputs written or max_steps reached (outputs then hold the last state).  The shuffles
+  float tj = s_times[j < T ? j : T - 1];   // the next output time, read ahead of its use
+  // every lane leaves the loop: either all outputs written or max_steps reached (outputs then hold the last state).  The butterflies
   // inside eval_ad / group_rms sit at the top level of the loop body: all 64 lanes execute them.
   while (__any(live && j < T && steps < k.max_steps)) {
     const bool act = live && j < T && steps < k.max_steps;
     ++steps;
-    eval_ad<S>(t + dt * (1.f / 5), w, g, own, a, d);
-    const float k2 = a - d * fmaf(dt, (1.f / 5) * fcur, y);
-    eval_ad<S>(t + dt * (3.f / 10), w, g, own, a, d);
-    const float k3 = a - d * fmaf(dt, (3.f / 40) * fcur + (9.f / 40) * k2, y);
-    eval_ad<S>(t + dt * (4.f / 5), w, g, own, a, d);
-    const float k4 = a - d * fmaf(dt, (44.f / 45) * fcur + (-56.f / 15) * k2 + (32.f / 9) * k3, y);
-    eval_ad<S>(t + dt * (8.f / 9), w, g, own, a, d);
-    const float k5 = a - d * fmaf(dt, (19372.f / 6561) * fcur + (-25360.f / 2187) * k2 + (64448.f / 6561) * k3 + (-212.f / 729) * k4, y);
-    eval_ad<S>(t + dt, w, g, own, a, d);   // stages 6 and 7 share t + dt
-    const float k6 = a - d * fmaf(dt, (9017.f / 3168) * fcur + (-355.f / 33) * k2 + (46732.f / 5247) * k3 + (49.f / 176) * k4 + (-5103.f / 18656) * k5, y);
+    // the five evaluation times of the step are known up front: five independent table look-ups
+    float a2, d2, a3, d3, a4, d4, a5, d5, a6, d6;
+    eval_ad<H>(t + dt * (1.f / 5), w, g, own, tab, ctr, a2, d2);
+    eval_ad<H>(t + dt * (3.f / 10), w, g, own, tab, ctr, a3, d3);
+    eval_ad<H>(t + dt * (4.f / 5), w, g, own, tab, ctr, a4, d4);
+    eval_ad<H>(t + dt * (8.f / 9), w, g, own, tab, ctr, a5, d5);
+    eval_ad<H>(t + dt, w, g, own, tab, ctr, a6, d6);   // stages 6 and 7 share t + dt
+    const float k2 = a2 - d2 * fmaf(dt, (1.f / 5) * fcur, y);
+    const float k3 = a3 - d3 * fmaf(dt, (3.f / 40) * fcur + (9.f / 40) * k2, y);
+    const float k4 = a4 - d4 * fmaf(dt, (44.f / 45) * fcur + (-56.f / 15) * k2 + (32.f / 9) * k3, y);
+    const float k5 = a5 - d5 * fmaf(dt, (19372.f / 6561) * fcur + (-25360.f / 2187) * k2 + (64448.f / 6561) * k3 + (-212.f / 729) * k4, y);
+    const float k6 = a6 - d6 * fmaf(dt, (9017.f / 3168) * fcur + (-355.f / 33) * k2 + (46732.f / 5247) * k3 + (49.f / 176) * k4 + (-5103.f / 18656) * k5, y);
     const float y1 = fmaf(dt, (35.f / 384) * fcur + (500.f / 1113) * k3 + (125.f / 192) * k4 + (-2187.f / 6784) * k5 + (11.f / 84) * k6, y);
-    const float k7 = a - d * y1;
+    const float k7 = a6 - d6 * y1;
     const float e = dt * ((35.f / 384 - 1951.f / 21600) * fcur + (500.f / 1113 - 22642.f / 50085) * k3 + (125.f / 192 - 451.f / 720) * k4 +
                           (-2187.f / 6784 + 12231.f / 42400) * k5 + (11.f / 84 - 649.f / 6300) * k6 + (-1.f / 60) * k7);
     const float ratio = group_rms<S>(e / (atol + rtol * fmaxf(fabsf(y), fabsf(y1))), own);
@@ -225,7 +337,7 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
         if (own) r[2 + gs] = y;
       }
       ++nacc;
-      if (j < T && k.times[j] <= t1) {
+      if (j < T && tj <= t1) {
         const float ymid = fmaf(dt, (6025192743.f / 30085553152.f / 2) * fcur + (51252292925.f / 65400821598.f / 2) * k3 +
                                         (-2691868925.f / 45128329728.f / 2) * k4 + (187940372067.f / 1594534317056.f / 2) * k5 +
                                         (-1776094331.f / 19743644256.f / 2) * k6 + (11237099.f / 235043384.f / 2) * k7, y);
@@ -233,10 +345,11 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
         const float cb = dt * (5.f * fcur - 3.f * k7) + 18.f * y + 14.f * y1 - 32.f * ymid;
         const float cc = dt * (k7 - 4.f * fcur) - 11.f * y - 5.f * y1 + 16.f * ymid;
         const float cd = dt * fcur;
-        while (j < T && k.times[j] <= t1) {
-          const float xq = (k.times[j] - t) / dt;
+        while (j < T && tj <= t1) {
+          const float xq = (tj - t) / dt;
           if (own) xo[j * S + gs] = y + xq * (cd + xq * (cc + xq * (cb + xq * ca)));
           ++j;
+          tj = s_times[j < T ? j : T - 1];
         }
       }
       t = t1;
@@ -247,7 +360,7 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
       float factor;
       if (ratio == 0.f) factor = 10.f;
       else {
-        const float safe = 0.9f * powf(ratio, -0.2f);
+        const float safe = 0.9f * __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf(ratio));   // 0.9 ratio^(-1/5) (v_log_f32 is log2)
         factor = fminf(10.f, fmaxf(safe, ratio < 1.f ? 1.f : 0.2f));
       }
       dt *= factor;
@@ -283,82 +396,6 @@ constexpr int BNT = 128;        // threads per workgroup
 constexpr int BTP = BNT / G;    // trajectories per workgroup (= per slab row)
 constexpr int TS = BTP + 1;     // padded trajectory stride of the column-sum tile
 
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_u(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
-// butterflies over the 8 lanes of a trajectory on the DPP crossbar (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror): every
-// lane of the group ends with the same bits (each step adds the same two operands on both sides)
-__device__ __forceinline__ unsigned group_or(unsigned v) {
-  v |= dpp_u<0xB1>(v);
-  v |= dpp_u<0x4E>(v);
-  v |= dpp_u<0x141>(v);
-  return v;
-}
-__device__ __forceinline__ float group_add(float v) {
-  v += __uint_as_float(dpp_u<0xB1>(__float_as_uint(v)));
-  v += __uint_as_float(dpp_u<0x4E>(__float_as_uint(v)));
-  v += __uint_as_float(dpp_u<0x141>(__float_as_uint(v)));
-  return v;
-}
-
-// The hidden layer is relu(w_t t + u_j): between two evaluation times only the units whose predicate fma(w_t, t, u_j) > 0 flips change
-// the head pre-activations o_c(t) = bias_c + sum_{j on} W_cj (w_t,j t + u_j), which are linear in t otherwise.  A lane carries, for the
-// growth and the degradation head of its component, the value V at the last evaluation time tau and the slope AL, and the group's
-// on/off bits: one evaluation = 4 predicates per lane + one OR butterfly + 2 fmas (+ 4 per flipped unit) + 2 sigmoids instead of the
-// H x 2S product and two 8-vector butterflies of the forward kernel's eval_ad; re-based every 16 steps (bounds the drift).
-struct Incr {
-  float Va, Vd, ALa, ALd, tau;
-  unsigned mask;
-};
-struct Units {
-  float wt[JL], u[JL];   // this lane's hidden units g, g+8, g+16, g+24 (0, 0 beyond H: predicate never true)
-};
-__device__ __forceinline__ unsigned unit_bits(float t, const Units& w, int g) {
-  unsigned m = 0u;
-#pragma unroll
-  for (int i = 0; i < JL; ++i) m |= (fmaf(w.wt[i], t, w.u[i]) > 0.f) ? (1u << (g + G * i)) : 0u;
-  return group_or(m);
-}
-template <int H>
-__device__ __forceinline__ void incr_init(Incr& st, float t, const Units& w, int g, const float* __restrict__ s_wt,
-                                          const float* __restrict__ s_us, const float* __restrict__ s_wgd, float bga, float bda) {
-  const unsigned m = unit_bits(t, w, g);
-  float va = bga, vd = bda, ala = 0.f, ald = 0.f;
-#pragma unroll 5
-  for (int j = 0; j < H; ++j) {
-    const float wt = s_wt[j], pre = fmaf(wt, t, s_us[j]);
-    const bool on = (m >> j) & 1u;
-    const float h = on ? pre : 0.f, hw = on ? wt : 0.f;
-    const float w1 = s_wgd[j * 16 + g], w2 = s_wgd[j * 16 + 8 + g];
-    va = fmaf(w1, h, va); vd = fmaf(w2, h, vd);
-    ala = fmaf(w1, hw, ala); ald = fmaf(w2, hw, ald);
-  }
-  st.Va = va; st.Vd = vd; st.ALa = ala; st.ALd = ald; st.mask = m; st.tau = t;
-}
-// moves the state to time t; returns the on/off bits at t
-template <int H>
-__device__ __forceinline__ unsigned incr_eval(Incr& st, float t, const Units& w, int g, bool own, const float* __restrict__ s_wt,
-                                              const float* __restrict__ s_us, const float* __restrict__ s_wgd, float& a, float& d) {
-  const float dtau = t - st.tau;
-  st.Va = fmaf(st.ALa, dtau, st.Va);
-  st.Vd = fmaf(st.ALd, dtau, st.Vd);
-  st.tau = t;
-  const unsigned now = unit_bits(t, w, g);
-  unsigned flip = now ^ st.mask;
-  while (flip) {   // the same for the 8 lanes of a trajectory; rare
-    const int j = __builtin_ctz(flip);
-    flip &= flip - 1u;
-    const float wt = s_wt[j], sg = ((now >> j) & 1u) ? 1.f : -1.f;
-    const float pre = sg * fmaf(wt, t, s_us[j]), swt = sg * wt;
-    const float w1 = s_wgd[j * 16 + g], w2 = s_wgd[j * 16 + 8 + g];
-    st.Va = fmaf(w1, pre, st.Va); st.ALa = fmaf(w1, swt, st.ALa);
-    st.Vd = fmaf(w2, pre, st.Vd); st.ALd = fmaf(w2, swt, st.ALd);
-  }
-  st.mask = now;
-  a = own ? sigmoidf_fast(st.Va) : 0.f;
-  d = own ? sigmoidf_fast(st.Vd) : 0.f;
-  return now;
-}
-
 // Weight gradients.  Along the time-ordered sequence of evaluation times (all stages of all accepted steps) unit j is switched on over
 // a prefix or a suffix, so its share of every head-weight gradient is a partial sum of the per-sample head gradients g (and of g t) up
 // to the sample where its predicate flips.  The sweep walks the samples backwards in time keeping the running sums RS = sum g,
@@ -393,27 +430,21 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NTMP = 2 * S + 2;
   const int tid = threadIdx.x, g = tid & (G - 1), slot = tid >> 3, b = blockIdx.x * BTP + slot, L = k.L, T = k.T;
-  float* s_wt = smem;                   // [32] time weights of the hidden units
-  float* s_wgd = s_wt + 32;             // [H][16]: [j][g] growth-head weight of component g, [j][8 + g] degradation-head weight
-  float* s_u = s_wgd + H * 16;          // [BTP][32] hidden offsets u = W_z z + b_h
-  float* s_gu = s_u + BTP * 32;         // [BTP][32] dLoss/du_j
+  GroupLds<H> m;
+  float* s_gu = m.carve(smem, BTP);     // [BTP][32] dLoss/du_j
   float* s_gp = s_gu + BTP * 32;        // [BTP][32] dLoss/d(init-net pre-activation j)
   float* s_h0 = s_gp + BTP * 32;        // [BTP][32] init-net hidden values
   float* s_go = s_h0 + BTP * 32;        // [BTP][8]  dLoss/d(init-net output pre-activation)
   float* s_z = s_go + BTP * 8;          // [BTP][L]
   float* s_times = s_z + BTP * L;       // [T]
   float* s_big = s_times + ((T + 3) & ~3);   // dL/dx rows of the workgroup's trajectories | column-sum tile | W1, W_z for the latent gradient
+  const float *s_wt = m.wt, *s_wgd = m.wgd;
   const bool live = b < k.B, own = g < S;
   const long long bb = live ? b : 0;
   const int gs = own ? g : 0;
   float* row = k.slabs + (long long)blockIdx.x * k.slab_stride;
   float* prm = row + 1;
   for (int i = 1 + tid; i <= k.nseg; i += BNT) row[i] = 0.f;   // (every element is written again below; completes long before)
-  if (tid < 32) s_wt[tid] = tid < H ? k.wh[tid * (1 + L)] : 0.f;
-  for (int i = tid; i < H * 16; i += BNT) {
-    const int j = i >> 4, c = i & 15, gg = c & 7;
-    s_wgd[i] = gg < S ? (c < 8 ? k.wg[gg * H + j] : k.wd[gg * H + j]) : 0.f;
-  }
   for (int l = g; l < L; l += G) s_z[slot * L + l] = live ? k.z[bb * L + l] : 0.f;
   for (int i = tid; i < T; i += BNT) s_times[i] = k.times[i];
   if (k.stage_gx) {   // the workgroup's BTP rows of dL/dx are one contiguous block
@@ -422,31 +453,14 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
     for (int i = tid; i < n; i += BNT) s_big[i] = k.gx[base + i];
   }
   __syncthreads();
-  // this lane's hidden units: offsets u (dynamics net) and pre-activations (init net)
   Units w;
   float pre0[JL];
-  {
-    const float* zrow = s_z + slot * L;
-#pragma unroll
-    for (int i = 0; i < JL; ++i) {
-      const int j = g + G * i;
-      const bool valid = j < H;
-      const int jj = valid ? j : 0;
-      float uj = k.bh[jj], pj = k.b1[jj];
-      for (int l = 0; l < L; ++l) {
-        const float zl = zrow[l];
-        uj = fmaf(k.wh[jj * (1 + L) + 1 + l], zl, uj);
-        pj = fmaf(k.w1[jj * L + l], zl, pj);
-      }
-      w.wt[i] = valid ? s_wt[jj] : 0.f;
-      w.u[i] = valid ? uj : 0.f;
-      pre0[i] = valid ? pj : 0.f;
-      s_u[slot * 32 + j] = w.u[i];
-    }
-  }
-  __syncthreads();
-  const float* s_us = s_u + slot * 32;
-  const float bga = own ? k.bg[gs] : 0.f, bda = own ? k.bd[gs] : 0.f;
+  const float t_first = s_times[0], t_last = s_times[T - 1];
+  const unsigned dirmask = load_units<S, H>(k.wh, k.bh, k.wg, k.bg, k.wd, k.bd, k.w1, k.b1, s_z + slot * L, L, tid, BNT, fminf(t_first, t_last),
+                                            fmaxf(t_first, t_last), m, w, pre0);
+  const float* s_us = m.u + slot * 32;
+  const float4* tab = m.tab + slot * (H + 1) * G;
+  const float* ctr = m.ctr + slot * 32;
   const int nr = live ? k.nrec[bb] : 0;
   const bool bad = nr < 0 || nr > k.kmax;
   const int K = bad ? 0 : nr;
@@ -454,11 +468,11 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   const float* gxs = s_big + slot * T * S + gs;
   float* snap = k.snap + bb * H * 4 * S;
   float lam = 0.f, RSa = 0.f, RSd = 0.f, RTa = 0.f, RTd = 0.f;
-  unsigned onmask = 0u, tmask = 0u;
+  unsigned onmask = 0u, tmask = 0u;   // onmask: the ge bits of the latest sample of the sweep
   bool first = true;
-  Incr inc;
-  inc.Va = inc.Vd = inc.ALa = inc.ALd = inc.tau = 0.f; inc.mask = 0u;
   int j = T - 1;
+  float tj = s_times[j], gj = k.stage_gx ? gxs[j * S] : gxb[j * S];   // the next output sample of the sweep
+  gj = own ? gj : 0.f;
   // the record of step K-1-it, two steps ahead of its use (a step is ~1 us of dependent arithmetic: about one memory latency)
   float t, dt, y, t_n1, dt_n1, y_n1, t_n2, dt_n2, y_n2;
 #define SLODE_LDREC(IT, T_, DT_, Y_)                                                            \
@@ -476,41 +490,40 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
     SLODE_LDREC(it + 2, t_n2, dt_n2, y_n2)
     const float te0 = t, te1 = t + dt * (1.f / 5), te2 = t + dt * (3.f / 10), te3 = t + dt * (4.f / 5), te4 = t + dt * (8.f / 9), te5 = t + dt;
     // ---- forward recomputation of the stages from the recorded (t, dt, y) ------------------------------------------------------
-    if ((it & 15) == 0) incr_init<H>(inc, te0, w, g, s_wt, s_us, s_wgd, bga, bda);
-    float a, d;
-    const unsigned mk0 = incr_eval<H>(inc, te0, w, g, own, s_wt, s_us, s_wgd, a, d);
-    const float ap0 = a * (1.f - a), d0 = d, dp0 = d * (1.f - d);
-    const float k1 = a - d * y;
-    const unsigned mk1 = incr_eval<H>(inc, te1, w, g, own, s_wt, s_us, s_wgd, a, d);
-    const float ap1 = a * (1.f - a), d1 = d, dp1 = d * (1.f - d);
+    float a0, a1, a2, a3, a4, a5, d0, d1, d2, d3, d4, d5;   // six independent table look-ups
+    const unsigned mk0 = eval_ad<H>(te0, w, g, own, tab, ctr, a0, d0);
+    const unsigned mk1 = eval_ad<H>(te1, w, g, own, tab, ctr, a1, d1);
+    const unsigned mk2 = eval_ad<H>(te2, w, g, own, tab, ctr, a2, d2);
+    const unsigned mk3 = eval_ad<H>(te3, w, g, own, tab, ctr, a3, d3);
+    const unsigned mk4 = eval_ad<H>(te4, w, g, own, tab, ctr, a4, d4);
+    const unsigned mk5 = eval_ad<H>(te5, w, g, own, tab, ctr, a5, d5);
+    const float ap0 = a0 * (1.f - a0), dp0 = d0 * (1.f - d0), ap1 = a1 * (1.f - a1), dp1 = d1 * (1.f - d1);
+    const float ap2 = a2 * (1.f - a2), dp2 = d2 * (1.f - d2), ap3 = a3 * (1.f - a3), dp3 = d3 * (1.f - d3);
+    const float ap4 = a4 * (1.f - a4), dp4 = d4 * (1.f - d4), ap5 = a5 * (1.f - a5), dp5 = d5 * (1.f - d5);
+    const float k1 = a0 - d0 * y;
     const float ys2 = fmaf(dt, (1.f / 5) * k1, y);
-    const float k2 = a - d * ys2;
-    const unsigned mk2 = incr_eval<H>(inc, te2, w, g, own, s_wt, s_us, s_wgd, a, d);
-    const float ap2 = a * (1.f - a), d2 = d, dp2 = d * (1.f - d);
+    const float k2 = a1 - d1 * ys2;
     const float ys3 = fmaf(dt, (3.f / 40) * k1 + (9.f / 40) * k2, y);
-    const float k3 = a - d * ys3;
-    const unsigned mk3 = incr_eval<H>(inc, te3, w, g, own, s_wt, s_us, s_wgd, a, d);
-    const float ap3 = a * (1.f - a), d3 = d, dp3 = d * (1.f - d);
+    const float k3 = a2 - d2 * ys3;
     const float ys4 = fmaf(dt, (44.f / 45) * k1 + (-56.f / 15) * k2 + (32.f / 9) * k3, y);
-    const float k4 = a - d * ys4;
-    const unsigned mk4 = incr_eval<H>(inc, te4, w, g, own, s_wt, s_us, s_wgd, a, d);
-    const float ap4 = a * (1.f - a), d4 = d, dp4 = d * (1.f - d);
+    const float k4 = a3 - d3 * ys4;
     const float ys5 = fmaf(dt, (19372.f / 6561) * k1 + (-25360.f / 2187) * k2 + (64448.f / 6561) * k3 + (-212.f / 729) * k4, y);
-    const float k5 = a - d * ys5;
-    const unsigned mk5 = incr_eval<H>(inc, te5, w, g, own, s_wt, s_us, s_wgd, a, d);
-    const float ap5 = a * (1.f - a), d5 = d, dp5 = d * (1.f - d);
+    const float k5 = a4 - d4 * ys5;
     const float ys6 = fmaf(dt, (9017.f / 3168) * k1 + (-355.f / 33) * k2 + (46732.f / 5247) * k3 + (49.f / 176) * k4 + (-5103.f / 18656) * k5, y);
-    const float k6 = a - d * ys6;
+    const float k6 = a5 - d5 * ys6;
     const float y1 = fmaf(dt, (35.f / 384) * k1 + (500.f / 1113) * k3 + (125.f / 192) * k4 + (-2187.f / 6784) * k5 + (11.f / 84) * k6, y);
     // ---- dense outputs inside (t, t + dt]: x_j = y + q cd + q^2 cc + q^3 cb + q^4 ca with q = (times[j] - t) / dt ----------------
     float Ga = 0.f, Gb = 0.f, Gc = 0.f, Gd = 0.f, gy = 0.f;
-    while (act && j >= 1 && s_times[j] > t) {
-      const float q = (s_times[j] - t) / dt, q2 = q * q, q3 = q2 * q, q4 = q2 * q2;
-      float gq = k.stage_gx ? gxs[j * S] : gxb[j * S];
-      gq = own ? gq : 0.f;
+    const float rdt = 1.f / dt;
+    while (act && j >= 1 && tj > t) {
+      const float q = (tj - t) * rdt, q2 = q * q, q3 = q2 * q, q4 = q2 * q2;
+      const float gq = gj;
+      --j;
+      tj = s_times[j];                                  // read ahead of their use (j >= 0)
+      gj = k.stage_gx ? gxs[j * S] : gxb[j * S];
+      gj = own ? gj : 0.f;
       gy += gq;
       Gd = fmaf(q, gq, Gd); Gc = fmaf(q2, gq, Gc); Gb = fmaf(q3, gq, Gb); Ga = fmaf(q4, gq, Ga);
-      --j;
     }
     // ---- reverse mode of the step ------------------------------------------------------------------------------------------------
     const float gf0 = dt * (-2.f * Ga + 5.f * Gb - 4.f * Gc + Gd);
@@ -595,7 +608,7 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's own snapshot stores are back-readable
 #pragma unroll 5
     for (int jj = 0; jj < H; ++jj) {
-      const bool flipped = (tmask >> jj) & 1u, on_early = (onmask >> jj) & 1u;
+      const bool flipped = (tmask >> jj) & 1u, on_early = (on_bits(onmask, dirmask) >> jj) & 1u;
       const float* sn = snap + jj * 4 * S + gs;
       const float s0 = sn[0], s1 = sn[S], s2 = sn[2 * S], s3 = sn[3 * S];
       const float sma = flipped ? s0 : 0.f, smd = flipped ? s1 : 0.f, sta = flipped ? s2 : 0.f, std_ = flipped ? s3 : 0.f;
@@ -724,7 +737,7 @@ hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, co
   k.atol = s.atol > 0.f ? s.atol : 1e-9f;
   k.max_steps = 20000;
   const int grid = (s.B + TPB - 1) / TPB;
-  const size_t lds = sizeof(float) * ((size_t)TPB * s.L);
+  const size_t lds = sizeof(float) * ((size_t)GroupLds<25>::floats(TPB) + (size_t)TPB * s.L + (size_t)s.T);
   if (s.H == 25 && s.S == 5) hipLaunchKernelGGL((dopri5_kernel<5, 25>), dim3(grid), dim3(DNT), lds, stream, k);
   else if (s.H == 25 && s.S == 8) hipLaunchKernelGGL((dopri5_kernel<8, 25>), dim3(grid), dim3(DNT), lds, stream, k);
   else return hipErrorInvalidValue;
@@ -748,10 +761,10 @@ hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay
   {
     using namespace grp;
     const int grid = slode_dopri5_rows(s);
-    const size_t fixed = 32 + (size_t)s.H * 16 + (size_t)BTP * 32 * 4 + BTP * 8 + (size_t)BTP * s.L + (size_t)((s.T + 3) & ~3);
+    const size_t fixed = (size_t)GroupLds<25>::floats(BTP) + (size_t)BTP * 32 * 3 + BTP * 8 + (size_t)BTP * s.L + (size_t)((s.T + 3) & ~3);
     const size_t tile = (size_t)(s.H + 1) * (2 * s.S + 2) * TS, wz = 2 * (size_t)s.H * s.L, gxrows = (size_t)BTP * s.T * s.S;
     size_t big = tile > wz ? tile : wz;
-    k.stage_gx = sizeof(float) * (fixed + (gxrows > big ? gxrows : big)) <= 80 * 1024 ? 1 : 0;   // dL/dx rows in LDS when two workgroups still fit a CU
+    k.stage_gx = sizeof(float) * (fixed + (gxrows > big ? gxrows : big)) <= 160 * 1024 ? 1 : 0;   // dL/dx rows in LDS when they fit
     if (k.stage_gx && gxrows > big) big = gxrows;
     const size_t lds = sizeof(float) * (fixed + big);
     if (lds > 160 * 1024) return hipErrorInvalidValue;

@@ -600,6 +600,16 @@ int slode_label_heads(slode_handle h, const slode_shape* s, const slode_layout* 
   return SLODE_OK;
 }
 
+int slode_dopri5_step_counts(slode_handle h, const slode_shape* s, const slode_layout* lay, const void* workspace, size_t workspace_bytes,
+                             int* counts, void* stream) {
+  if (!h) return SLODE_EINVAL;
+  if (!s || !lay || !workspace || !counts || s->method != SLODE_DOPRI5) return fail(h, SLODE_EINVAL, "slode_dopri5_step_counts: dopri5 shape, workspace and output required");
+  if (workspace_bytes < slode_workspace_bytes(h, s)) return fail(h, SLODE_EINVAL, "slode_dopri5_step_counts: workspace too small");
+  const Workspace w = carve(h, *s, *lay, const_cast<void*>(workspace));
+  HIP_TRY(h, hipMemcpyAsync(counts, w.dp_nrec, sizeof(int) * (size_t)s->B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return SLODE_OK;
+}
+
 int slode_adam_region(slode_handle h, int64_t lo, int64_t hi, int64_t step_delta) {
   if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
   if (lo < 0 || hi < lo || hi > 0x7fffffff) return fail(h, SLODE_EINVAL, "bad Adam region [%lld, %lld)", (long long)lo, (long long)hi);

@@ -309,6 +309,14 @@ class Engine:
             self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._f32(z, "z")), self._p(out), self._stream()))
         return out
 
+    def dopri5_step_counts(self, B: int) -> torch.Tensor:
+        """Accepted steps per trajectory of the last dopri5 training step at batch size B (diagnostic; int32 [B])."""
+        out = torch.empty(B, dtype=torch.int32, device=self.device)
+        w = self.workspace(B)
+        _check(self.lib, self.handle, self.lib.slode_dopri5_step_counts(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(w), w.numel() * 4, self._p(out), self._stream()))
+        return out
+
     def decode_heads(self, params, x):
         B = x.shape[0]
         sp = self.spec

@@ -20,3 +20,5 @@ for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
     t0 = time.perf_counter()
     loss = svi.step(obs_d, eps=eps_d, u=u_d)
     print("step %d  -ELBO/B %.4f  %.2f ms" % (i, loss / B, 1e3 * (time.perf_counter() - t0)), flush=True)
+n = eng.dopri5_step_counts(B).float()
+print("accepted steps per trajectory: min %d  mean %.1f  max %d;  mean over groups-of-64 maxima %.1f" % (n.min(), n.mean(), n.max(), n.view(-1, 64).max(1).values.mean()))
