@@ -205,10 +205,11 @@ __device__ __forceinline__ unsigned load_units(const float* wh, const float* bh,
     int rank[JL];
 #pragma unroll
     for (int i = 0; i < JL; ++i) rank[i] = 0;
+#pragma unroll 5
     for (int kk = 0; kk < H; ++kk) {
       const float thk = s_th[kk];
 #pragma unroll
-      for (int i = 0; i < JL; ++i) rank[i] += (thk < w.th[i] || (thk == w.th[i] && kk < g + G * i)) ? 1 : 0;
+      for (int i = 0; i < JL; ++i) rank[i] += (int)((thk < w.th[i]) | ((thk == w.th[i]) & (kk < g + G * i)));   // (bitwise: no branches)
     }
 #pragma unroll
     for (int i = 0; i < JL; ++i)
@@ -475,12 +476,14 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   gj = own ? gj : 0.f;
   // the record of step K-1-it, two steps ahead of its use (a step is ~1 us of dependent arithmetic: about one memory latency)
   float t, dt, y, t_n1, dt_n1, y_n1, t_n2, dt_n2, y_n2;
+  const long long rstride = (long long)k.B * (S + 2);   // records of consecutive steps are B (S + 2) floats apart
+  const float* rp = k.rec + (long long)(K > 0 ? K - 1 : 0) * rstride + bb * (S + 2);   // step K-1 first
 #define SLODE_LDREC(IT, T_, DT_, Y_)                                                            \
   {                                                                                             \
     const bool a_ = (IT) < K;                                                                   \
-    const float* r_ = k.rec + ((long long)(a_ ? K - 1 - (IT) : 0) * k.B + bb) * (S + 2);         \
-    const float r0_ = r_[0], r1_ = r_[1], r2_ = r_[2 + gs];                                     \
+    const float r0_ = rp[0], r1_ = rp[1], r2_ = rp[2 + gs];                                     \
     T_ = a_ ? r0_ : 0.f; DT_ = a_ ? r1_ : 0.f; Y_ = (a_ && own) ? r2_ : 0.f;                    \
+    rp -= ((IT) + 1 < K) ? rstride : 0;                                                         \
   }
   SLODE_LDREC(0, t, dt, y)
   SLODE_LDREC(1, t_n1, dt_n1, y_n1)

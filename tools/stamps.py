@@ -11,14 +11,20 @@ from oracle import slode_oracle as O
 from structured_latent_odes_amd import _lib, engine as E
 
 dev = torch.device("cuda:0")
-ospec = O.cvs_spec(3, 3, 2, solver="rk4")
-B, T = int(os.environ.get("STAMPS_B", "1024")), 200
-p = O.init_params(ospec, T=T)
+CFG = os.environ.get("STAMPS_CFG", "c1")   # c1: the metric shape; c2 / c2dp5: BASELINE config[2] with rk4 / dopri5
+if CFG == "c1":
+    ospec, espec, T, S = O.cvs_spec(3, 3, 2, solver="rk4"), E.cvs_spec(3, 3, 2, solver="rk4"), 200, 5
+    B = int(os.environ.get("STAMPS_B", "1024"))
+else:
+    sol = "dopri5" if CFG == "c2dp5" else "rk4"
+    ospec, espec, T, S = O.proc_spec(z_g=10, z_eps=10, solver=sol), E.proc_spec(z_g=10, z_eps=10, solver=sol), 100, 8
+    B = int(os.environ.get("STAMPS_B", "4096"))
+p = O.init_params(ospec, T=T, S=S)
 obs, u, eps, times = O.synthetic_batch(ospec, B, T)
-eng = E.Engine(E.cvs_spec(3, 3, 2, solver="rk4"), T, dev)
+eng = E.Engine(espec, T, dev)
 eng.set_times(times)
 flat = eng.pack(p)
-obs_d = obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)
+obs_d = obs.contiguous().to(dev) if CFG != "c1" else obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)
 loss, grads = torch.zeros(1, device=dev), torch.zeros(eng.n_params, device=dev)
 m_, v_ = torch.zeros_like(flat), torch.zeros_like(flat)
 u_d, eps_d = u.to(dev), eps.to(dev)
