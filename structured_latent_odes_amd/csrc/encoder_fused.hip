@@ -48,6 +48,7 @@ struct FoldK {
   float* g_lin_w;                          // final lin.weight gradient (written directly)
   float* conv_slabs;                       // [Hc][F*C*K + F]
   unsigned int* counter;
+  const float* cstd; float* sigtab; int gauss;   // likelihood-scale table of this step: [4][CT] (sigtab == nullptr: none)
 };
 
 __device__ __forceinline__ int kappa_of(const FoldK& k, int c, int t) { return k.t_major ? t * k.C + c : c * k.T + t; }
@@ -124,6 +125,17 @@ __global__ void __launch_bounds__(256) weff_kernel(const FoldK k, const int stag
     __syncthreads();
     if (fh == 0 && (int)blockIdx.x * WPB + el < n_w) k.weff[e] = (acc0 + acc1) + s_half[el];
     STAMP(2);
+  } else if ((int)blockIdx.x >= nb_w + (k.Hc + 3) / 4) {
+    // likelihood scales of this step (decoders.py:52-53: softplus(constant_std)) and what the likelihood and its gradient need of them:
+    // parameter-only, so once per step here instead of once per trajectory in the ODE/ELBO kernel (same functions: same bits)
+    const int i = ((int)blockIdx.x - nb_w - (k.Hc + 3) / 4) * 256 + tid;
+    if (i < k.CT) {
+      const float sig = softplusf(k.cstd[i]);
+      k.sigtab[i] = sig;
+      k.sigtab[k.CT + i] = 1.0f / sig;
+      k.sigtab[2 * k.CT + i] = k.gauss ? logf(sig) : logf(2.f * sig);
+      k.sigtab[3 * k.CT + i] = 1.f - expf(-sig);
+    }
   } else {
     // one wave per hidden unit m: rowsum[m][f] for every f, then b_eff[m]
     const int m = ((int)blockIdx.x - nb_w) * 4 + (tid >> 6), lane = tid & 63;
@@ -542,6 +554,7 @@ FoldK make_foldk(const FoldLaunch& a) {
   k.scale_in = a.scale; k.hid_in = a.hid; k.g_loc = a.g_loc; k.g_scale = a.g_scale;
   k.g_pre = a.g_pre; k.slabs = a.small_slabs; k.small_stride = a.small_stride;
   k.gslabs = a.gslabs; k.n_gslabs = a.n_gslabs; k.g_lin_w = a.g_lin_w; k.conv_slabs = a.conv_slabs; k.counter = a.counter;
+  k.cstd = p + lay.cstd; k.sigtab = a.sigtab; k.gauss = s.likelihood == SLODE_GAUSS ? 1 : 0;
   return k;
 }
 
@@ -551,7 +564,7 @@ int slode_fold_small_count(const slode_shape& s) { return s.Hc + 2 * (s.L * s.Hc
 
 hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream, hipEvent_t mid) {
   FoldK k = make_foldk(a);
-  const int nb_w = (k.Hc * k.CT + WPB - 1) / WPB, nb_r = (k.Hc + 3) / 4;
+  const int nb_w = (k.Hc * k.CT + WPB - 1) / WPB, nb_r = (k.Hc + 3) / 4 + (k.sigtab ? (k.CT + 255) / 256 : 0);
   // dynamic LDS: conv taps + (when they fit) the lin.weight rows a block's WPB consecutive outputs can touch
   const size_t cw = ((size_t)k.F * k.C * k.K + 3) & ~(size_t)3;
   const size_t max_rows = (size_t)(WPB - 1) / k.CT + 2;   // WPB outputs starting anywhere inside a row of CT

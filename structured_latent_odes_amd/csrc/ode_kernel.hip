@@ -61,6 +61,7 @@ struct OdeK {
   float tau[SLODE_MAX_HEADS];
   const float *ploc_w[SLODE_MAX_GROUPS], *ploc_b[SLODE_MAX_GROUPS], *pls_w[SLODE_MAX_GROUPS], *pls_b[SLODE_MAX_GROUPS];
   const float *w1, *b1, *w2, *b2, *wh, *bh, *wg, *bg, *wd, *bd, *head[SLODE_MAX_HEADS], *cstd;
+  const float* sigtab;   // optional [4][C*T]: softplus(constant_std) | 1/scale | log(scale) or log(2 scale) | softplus' (OdeLaunch::sigtab)
   // offsets relative to lay.ode_begin (accumulator / slab index = 1 + offset)
   int o_ploc_w[SLODE_MAX_GROUPS], o_ploc_b[SLODE_MAX_GROUPS], o_pls_w[SLODE_MAX_GROUPS], o_pls_b[SLODE_MAX_GROUPS];
   int o_w1, o_b1, o_w2, o_b2, o_wh, o_bh, o_wg, o_bg, o_wd, o_bd, o_head[SLODE_MAX_HEADS], o_cstd;
@@ -495,9 +496,10 @@ ode_elbo_kernel(const OdeK k) {
       }
       if (k.u != nullptr) v_u = k.u[(long long)b_first * k.nu + min(tid, k.nu - 1)];
     }
-    if (ONE && k.with_ll) {
+    if (ONE && k.with_ll) {   // (with the per-step table: the scale itself instead of its parameter)
+      const float* src = k.sigtab ? k.sigtab : k.cstd;
 #pragma unroll
-      for (int c = 0; c < SLODE_MAX_C; ++c) v_c[c] = k.cstd[min(c, C - 1) * T + min(tid, T - 1)];
+      for (int c = 0; c < SLODE_MAX_C; ++c) v_c[c] = src[min(c, C - 1) * T + min(tid, T - 1)];
     }
     if (tid < L) {
       // prior-net lookup table for latent dim l (mechanistic_cvs.py:225-237): resolved once per workgroup, while the loads fly
@@ -516,14 +518,14 @@ ode_elbo_kernel(const OdeK k) {
       for (int q = 0; q < 8; ++q) s_meta[l * 8 + q] = me[q];
     }
     if (!ONE) {   // persistent-loop form: softplus(constant_std) once per workgroup, kept in LDS
-      for (int i = tid; i < n_sig; i += NT) s_sig[i] = softplusf(k.cstd[i]);
+      for (int i = tid; i < n_sig; i += NT) s_sig[i] = k.sigtab ? k.sigtab[i] : softplusf(k.cstd[i]);
     }
     if (tid < L) { s_pf[tid] = v_l0; s_pf[pad4(L) + tid] = v_l1; s_pf[2 * pad4(L) + tid] = v_l2; }
     if (tid < k.nu) s_uu[tid] = v_u;
     if (ONE && k.with_ll) {
 #pragma unroll
       for (int c = 0; c < SLODE_MAX_C; ++c)
-        if (c < C) sigr[c] = softplusf(v_c[c]);
+        if (c < C) sigr[c] = k.sigtab ? v_c[c] : softplusf(v_c[c]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA has landed (the barrier below covers the other waves')
   }
@@ -1545,6 +1547,7 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   k.wd = p + lay.dyn_wd; k.bd = p + lay.dyn_bd;
   for (int q = 0; q < SLODE_MAX_HEADS; ++q) { k.head[q] = p + lay.head_w[q]; k.o_head[q] = lay.head_w[q] - ob; }
   k.cstd = p + lay.cstd;
+  k.sigtab = a.sigtab;
   k.o_w1 = lay.init_w1 - ob; k.o_b1 = lay.init_b1 - ob; k.o_w2 = lay.init_w2 - ob; k.o_b2 = lay.init_b2 - ob;
   k.o_wh = lay.dyn_wh - ob; k.o_bh = lay.dyn_bh - ob; k.o_wg = lay.dyn_wg - ob; k.o_bg = lay.dyn_bg - ob;
   k.o_wd = lay.dyn_wd - ob; k.o_bd = lay.dyn_bd - ob; k.o_cstd = lay.cstd - ob;

@@ -177,6 +177,7 @@ struct Workspace {
   unsigned int* counter;
   // dopri5 training: solution, dLoss/dx, external latent gradient, latent sample, step records
   float *dp_x, *dp_gx, *dp_gz, *dp_z, *dp_rec, *dp_snap;
+  float* sigtab;   // [4][C*T] likelihood-scale table of the step (OdeLaunch::sigtab)
   int* dp_nrec;
   int dp_kmax, dp_rows;
   int gsplit;
@@ -249,6 +250,7 @@ static Workspace carve(slode_handle h, const slode_shape& s_in, const slode_layo
   w.gslabs2 = take((size_t)w.gsplit * s.L * (s.Hc + 1));
   w.gslabs3 = take((size_t)w.gsplit * s.L * (s.Hc + 1));
   w.counter = reinterpret_cast<unsigned int*>(take(64));
+  w.sigtab = take(4 * (size_t)s.C * s.T);
   if (dp5) {
     w.dp_kmax = slode_dopri5_kmax(s);
     w.dp_x = take((size_t)s.B * s.T * s.S);
@@ -416,6 +418,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     fl.g_loc = w.g_loc; fl.g_scale = w.g_scale; fl.g_pre = w.g_pre; fl.small_slabs = w.small_slabs; fl.small_stride = w.small_stride;
     fl.gslabs = w.gslabs; fl.n_gslabs = w.gsplit; fl.g_lin_w = grads ? grads + lay->lin_w : nullptr; fl.conv_slabs = w.conv_slabs;
     fl.counter = w.counter;
+    fl.sigtab = aux_mode ? nullptr : w.sigtab;
     e = slode_launch_fold_fwd(fl, st, prof ? h->ev[1] : nullptr);
     HIP_TRY(h, e);
   } else {
@@ -440,6 +443,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     a.u = u; a.eps = eps; a.loc = w.loc; a.scale = w.scale; a.x_out = x_out; a.z_out = z_out;
     a.g_loc = w.g_loc; a.g_scale = w.g_scale; a.slabs = w.ode_slabs; a.slab_stride = w.ode_stride; a.grid = w.ode_grid;
     a.backward = bwd ? 1 : 0; a.with_ll = 1;
+    a.sigtab = folded ? w.sigtab : nullptr;   // written by the fold launch above
     a.force_loop = h->ode_loop; a.force_generic = h->ode_generic; a.alg = h->ode_alg;
     if (bwd && folded) { a.enc_hid = w.hid; a.g_pre = w.g_pre; a.glat = w.glat; a.g_loc = nullptr; a.g_scale = nullptr; }
     if (dp5) {

@@ -236,6 +236,8 @@ struct OdeLaunch {
   int grid;
   int backward;          // 0: forward only
   int with_ll;           // 1: likelihood + latent terms (ELBO); 0: pure ODE solve
+  const float* sigtab = nullptr;   // optional [4][C*T]: softplus(constant_std) | its reciprocal | log(scale) (Gauss) or log(2 scale) (ALD) |
+                                   // 1 - exp(-scale) = softplus'; parameter-only, computed once per step instead of once per trajectory
   // folded-encoder ELBO step: the kernel also runs the encoder heads + tanh backward and writes g_pre / glat ([B][64] each)
   const float* enc_hid = nullptr;
   float* g_pre = nullptr;
@@ -301,6 +303,7 @@ struct FoldLaunch {
   const float* gslabs; int n_gslabs;
   float *g_lin_w, *conv_slabs;
   unsigned int* counter = nullptr;   // zeroed by the fold kernel; arrivals of the chain blocks
+  float* sigtab = nullptr;           // [4][C*T] likelihood-scale table of this step (see OdeLaunch::sigtab), written by extra fold blocks
   const TailK* tail = nullptr;       // chain launch also finishes the whole flat gradient (+ loss, + optional Adam)
 };
 hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream, hipEvent_t mid = nullptr);

@@ -73,6 +73,10 @@ if hasattr(lib, "slode_debug_wg_hw"):
         print("   per-CU max duration: min/median/max", per_cu.min(), np.median(per_cu), per_cu.max())
         order = np.argsort(dur)[-8:]
         print("   slowest workgroups:", [(int(i), round(float(dur[i]), 1), int(xcc[i]), int(se[i]), int(cu[i]), int(cnt[list(np.unique(key)).index(key[i])])) for i in order])
+        simd, wave = (hw[:, 0] >> 4) & 3, hw[:, 0] & 15
+        print("   wave 0 of a workgroup sits on SIMD:", {int(x): int(np.sum(simd == x)) for x in np.unique(simd)}, " wave slot:", {int(x): int(np.sum(wave == x)) for x in np.unique(wave)})
+        same = [len(set(simd[key == kk])) for kk in np.unique(key)]
+        print("   distinct SIMDs hosting the wave 0s of a CU's co-resident workgroups: min/median/max", min(same), int(np.median(same)), max(same))
         print("   start-time by blockIdx>>8 (median):", {int(x): round(float(np.median(a[(np.arange(n) >> 8) == x, 0] - t0)), 2) for x in range(4)})
 
 if hasattr(lib, "slode_debug_stamps_fold"):
