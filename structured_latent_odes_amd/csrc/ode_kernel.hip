@@ -94,7 +94,16 @@ struct LdsMap {  // offsets in floats
       hid0, x0, go, gp0, gu, red, pf, meta, total;
 };
 
-__host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
+__host__ __device__ constexpr int pad4(int n) { return (n + 3) & ~3; }
+// samples by which NQ = nthreads / 2S chunks of ceil(nt / NQ) samples overhang the stage-time table; 0 when that is more than 8 rows
+__host__ __device__ constexpr int ode_pad_rows(int nt, int nthreads, int S) {
+  const int nq = nthreads / (2 * S), cl = (nt + nq - 1) / nq, over = nq * cl - nt;
+  return over <= 8 ? over : 0;
+}
+__host__ __device__ constexpr bool ode_full_chunks(int nt, int nthreads, int S) {
+  const int nq = nthreads / (2 * S), cl = (nt + nq - 1) / nq;
+  return nq * cl - nt <= 8;
+}
 __host__ __device__ inline int imax2(int a, int b) { return a > b ? a : b; }
 
 // `one`: loop-free form (one workgroup per trajectory): softplus(constant_std) stays in registers, no s_sig.
@@ -104,7 +113,10 @@ __host__ __device__ inline int imax2(int a, int b) { return a > b ? a : b; }
 __host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int Q, int nt, int npar, int nthreads, int naux, bool one) {
   LdsMap m;
   int o = 0;
-  m.ts = o; o += pad4(nt);
+  // P6 reads the sample rows in chunks of CL = ceil(nt / NQ) samples: when the last chunk overhangs the table by a few samples, zero
+  // pad rows (and pad stage times) make every chunk full, and the contraction needs no bounds at all (ode_pad_rows)
+  const int padr = ode_pad_rows(nt, nthreads, S);
+  m.ts = o; o += pad4(nt + padr);
   m.sig = o; o += one ? 0 : pad4(C * T);
   const int tabn = (H + 1) * 4 * S;   // table rows [H+1][V (2S) | slope (2S)]
   m.ax = imax2(pad4(T * S), pad4((tabn + 2) / 3));
@@ -112,7 +124,7 @@ __host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int
   m.x = o; o += m.ax;
   m.lam = o; o += m.ax;
   int stn = imax2(((2 * S + 4) & ~3) * T, Q * C * T);   // stage-0 exchange rows [T][SP]; dLoss/dmu [Q*C][T]
-  stn = imax2(stn, nt * 2 * S - 3 * m.ax);              // G rows overlay the whole block
+  stn = imax2(stn, (nt + padr) * 2 * S - 3 * m.ax);     // G rows (+ pad rows) overlay the whole block
   m.st = o; m.stn = pad4(stn); o += m.stn;
   m.ct = o; o += pad4((nthreads / (2 * S)) * 4 * S);    // chunk sums [NQ][sum g (2S) | sum g t (2S)]
   m.gm = o; o += 2 * 2 * S * 32;                        // GM | GT: [2][2S][32] (unit H = the constant-1 unit)
@@ -527,6 +539,7 @@ ode_elbo_kernel(const OdeK k) {
       for (int c = 0; c < SLODE_MAX_C; ++c)
         if (c < C) sigr[c] = k.sigtab ? v_c[c] : softplusf(v_c[c]);
     }
+    if (tid < ode_pad_rows(n_stage_t, NT, S)) s_ts[n_stage_t + tid] = 0.f;   // pad stage times (P6: full chunks)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA has landed (the barrier below covers the other waves')
   }
   STAMP(13);
@@ -929,6 +942,18 @@ ode_elbo_kernel(const OdeK k) {
       const float* xe = k.x_ext + (long long)b * T * S;
       for (int i = tid; i < T * S; i += NT) s_x[i] = xe[i];
     }
+    // what P3 needs of the likelihood scales besides the scale itself comes from the per-step table when there is one: issued ahead of
+    // the barrier so that the loads fly while the scan finishes
+    float t_inv[SLODE_MAX_C] = {0.f, 0.f, 0.f, 0.f}, t_lg[SLODE_MAX_C] = {0.f, 0.f, 0.f, 0.f}, t_ds[SLODE_MAX_C] = {0.f, 0.f, 0.f, 0.f};
+    const bool use_tab = k.with_ll && k.sigtab != nullptr;
+    if (use_tab) {
+      const int tt = min(tid, T - 1), CTn = C * T;
+#pragma unroll
+      for (int c = 0; c < SLODE_MAX_C; ++c) {
+        const int i = min(c, C - 1) * T + tt;
+        t_inv[c] = k.sigtab[CTn + i]; t_lg[c] = k.sigtab[2 * CTn + i]; t_ds[c] = k.sigtab[3 * CTn + i];
+      }
+    }
     __syncthreads();
     STAMP(5);
     if (k.x_out) {
@@ -948,7 +973,8 @@ ode_elbo_kernel(const OdeK k) {
         for (int c = 0; c < SLODE_MAX_C; ++c) {
           if (c >= C) continue;
           const float sig = ONE ? sigr[c] : s_sig[c * T + t];
-          const float inv = 1.0f / sig;
+          const float inv = use_tab ? t_inv[c] : 1.0f / sig;
+          const float lg = use_tab ? t_lg[c] : (gauss ? logf(sig) : logf(2.f * sig));
           const float obv = (c == 0) ? pf_ob0 : ((c == 1) ? pf_ob1 : ((c == 2) ? pf_ob2 : pf_ob3));
           float gsig = 0.f;
           for (int q = 0; q < Q; ++q) {
@@ -959,13 +985,13 @@ ode_elbo_kernel(const OdeK k) {
             const float r = obv - mu;
             float gmu;
             if (gauss) {
-              ll += -logf(sig) - 0.91893853320467274178f - 0.5f * r * r * inv * inv;
+              ll += -lg - 0.91893853320467274178f - 0.5f * r * r * inv * inv;
               gmu = -r * inv * inv;
               gsig += inv - r * r * inv * inv * inv;
             } else {
               const float w = (obv >= mu) ? k.tau[q] : 1.f - k.tau[q];
               const float ar = fabsf(r);
-              ll += w * (-logf(2.f * sig) - ar * inv);
+              ll += w * (-lg - ar * inv);
               const float sg = (r > 0.f) ? 1.f : ((r < 0.f) ? -1.f : 0.f);
               gmu = -w * sg * inv;
               gsig += w * (inv - ar * inv * inv);
@@ -978,7 +1004,7 @@ ode_elbo_kernel(const OdeK k) {
           }
           if (BWD) {  // constant_std gradient: thread t owns slab entry (c, t); softplus'(x) = 1 - exp(-softplus(x))
             float* dst = k.slabs + (long long)blockIdx.x * k.slab_stride + 1 + k.o_cstd + c * T + t;
-            const float val = gsig * (1.f - expf(-sig));
+            const float val = gsig * (use_tab ? t_ds[c] : 1.f - expf(-sig));
             *dst = (ONE || b == (int)blockIdx.x) ? val : (*dst + val);
           }
         }
@@ -1131,6 +1157,7 @@ ode_elbo_kernel(const OdeK k) {
         }
       }
       __syncthreads();   // every read of A | x | lam | st is done: the block becomes the sample rows G[nt][2S]
+      if (tid < ode_pad_rows(n_stage_t, NT, S) * 2 * S) s_G[n_stage_t * GP + tid] = 0.f;   // zero pad rows: every P6 chunk is full
       if (need_next && own_step) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -1170,7 +1197,32 @@ ode_elbo_kernel(const OdeK k) {
         // (A) chunk sums: lane (chunk q, channel r) adds up CL consecutive samples.  Loads go in batches of 8 samples with a
         // scheduling barrier behind them (left alone, the scheduler waits for each LDS read in turn); a 0/1 mask keeps them
         // unconditional (a select on a loaded value is turned into a branch + wait).
-        if (tid < NQ * 2 * S) {
+        // Shape-specialised instantiations whose chunks are full (pad rows): compile-time chunk length, immediate offsets, no bounds --
+        // the same additions in the same order as the general form below.
+        constexpr bool STATIC_SHAPE = T_ > 0 && M_ >= 0;
+        const bool fullc = STATIC_SHAPE && ode_full_chunks(n_stage_t, NT, S);
+        if (fullc && tid < NQ * 2 * S) {
+          const int q = tid / (2 * S), r = tid - q * (2 * S);
+          const float* gp = s_G + q * CL * GP + r;
+          const float* tp = s_ts + q * CL;
+          float cg = 0.f, cgt = 0.f;
+#pragma unroll
+          for (int i0 = 0; i0 < CL; i0 += 8) {
+            float gv[8], tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              gv[u] = (i0 + u < CL) ? gp[(i0 + u) * GP] : 0.f;
+              tv[u] = (i0 + u < CL) ? tp[i0 + u] : 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              if (i0 + u < CL) { cg += gv[u]; cgt = fmaf(gv[u], tv[u], cgt); }
+            }
+          }
+          s_ct[q * 4 * S + r] = cg;
+          s_ct[q * 4 * S + 2 * S + r] = cgt;
+        } else if (tid < NQ * 2 * S) {
           const int q = tid / (2 * S), r = tid - q * (2 * S);
           float cg = 0.f, cgt = 0.f;
           for (int i0 = 0; i0 < CL; i0 += 8) {
@@ -1216,6 +1268,29 @@ ode_elbo_kernel(const OdeK k) {
               gtv = fmaf(on, w[u], gtv);
             }
           }
+          if (fullc) {
+            const int qc = min(qs, NQ - 1), rel = ma - qc * CL;   // first selected sample, relative to the chunk
+            const float* gp = s_G + qc * CL * GP + r;
+            const float* tp = s_ts + qc * CL;
+#pragma unroll
+            for (int i0 = 0; i0 < CL; i0 += 8) {
+              float gv[8], tv[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                gv[u] = (i0 + u < CL) ? gp[(i0 + u) * GP] : 0.f;
+                tv[u] = (i0 + u < CL) ? tp[i0 + u] : 0.f;
+              }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                if (i0 + u < CL) {
+                  const float g = gv[u] * (((unsigned)(i0 + u - rel) < (unsigned)mn) ? 1.f : 0.f);
+                  gmv += g;
+                  gtv = fmaf(g, tv[u], gtv);
+                }
+              }
+            }
+          } else
           for (int i0 = 0; i0 < CL; i0 += 8) {
             float gv[8], tv[8];
 #pragma unroll
