@@ -377,6 +377,66 @@ __device__ __forceinline__ void wave_affine_scan(const float* __restrict__ s_A, 
   }
 }
 
+// The same recurrence on ALL waves of the workgroup (forward scan: nothing else runs beside it).  NW * NC chunks of <= 8 steps (the block
+// has at least roundup64(T) threads), lanes (chunk, s): compose the chunk's maps, Kogge-Stone over the wave's chunks, the waves' total
+// maps through LDS (s_xw[NW][2][S]) and one barrier, then every lane applies the totals of the waves before its own and replays its
+// chunk.  Contains a barrier: every thread of the workgroup calls it.  The caller's next barrier publishes the results.
+template <int S, bool REV>
+__device__ __forceinline__ void block_affine_scan(const float* __restrict__ s_A, float* __restrict__ s_v, int T, int tid, int NT,
+                                                  float* __restrict__ s_xw) {
+  constexpr int NC = 64 / S, CLMAX = 8;
+  const int NW = NT >> 6, wave = tid >> 6, lane = tid & 63;
+  const int nsteps = T - 1, nch = NW * NC;
+  const int CL = (nsteps + nch - 1) / nch;   // <= 64 / NC <= CLMAX
+  const int c = lane / S, s = min(lane - c * S, S - 1);
+  const bool lane_on = c < NC;
+  const int k0 = (wave * NC + c) * CL;
+  const float y0 = s_v[(REV ? (T - 1) : 0) * S + s];
+  float Ar[CLMAX], vr[CLMAX];
+#pragma unroll
+  for (int q = 0; q < CLMAX; ++q) {
+    const int kk = k0 + q;
+    const bool on = lane_on && q < CL && kk < nsteps;
+    const int kc = min(kk, nsteps - 1), i = REV ? (T - 2 - kc) : kc;  // unconditional LDS reads (clamped), then selects
+    const float Aq = s_A[i * S + s], vq = s_v[(REV ? i : i + 1) * S + s];
+    Ar[q] = on ? Aq : 1.f;
+    vr[q] = on ? vq : 0.f;
+  }
+  float P = 1.f, Q = 0.f;   // this chunk's composed map y -> P y + Q
+#pragma unroll
+  for (int q = 0; q < CLMAX; ++q) {
+    Q = fmaf(Ar[q], Q, vr[q]);
+    P *= Ar[q];
+  }
+#pragma unroll
+  for (int d = 1; d < NC; d <<= 1) {   // inclusive scan over the wave's chunks
+    const float Pp = __shfl_up(P, d * S, 64), Qp = __shfl_up(Q, d * S, 64);
+    if (c >= d) {
+      Q = fmaf(P, Qp, Q);
+      P *= Pp;
+    }
+  }
+  if (c == NC - 1) {   // the wave's total map
+    s_xw[(wave * 2 + 0) * S + s] = P;
+    s_xw[(wave * 2 + 1) * S + s] = Q;
+  }
+  const float Pe = __shfl_up(P, S, 64), Qe = __shfl_up(Q, S, 64);
+  __syncthreads();
+  float y = y0;   // state at the start of this wave's stretch
+  for (int w = 0; w < wave; ++w) y = fmaf(s_xw[(w * 2 + 0) * S + s], y, s_xw[(w * 2 + 1) * S + s]);
+  y = (c == 0) ? y : fmaf(Pe, y, Qe);   // state at the start of this lane's chunk
+#pragma unroll
+  for (int q = 0; q < CLMAX; ++q) {
+    const int kk = k0 + q;
+    const bool on = lane_on && q < CL && kk < nsteps;
+    y = fmaf(Ar[q], y, vr[q]);  // masked entries are the identity map
+    if (on) {
+      const int i = REV ? (T - 2 - kk) : kk;
+      s_v[(REV ? i : i + 1) * S + s] = y;
+    }
+  }
+}
+
 __host__ __device__ constexpr int ode_threads_for(int T, int Q, int C, int S) {
   // waves >= 1 carry the head-gradient role (one (q,c,s) entry per thread) next to the adjoint scan on wave 0
   const int nt = ((T + 63) / 64) * 64, need = 64 + ((Q * C * S + 63) / 64) * 64;
@@ -937,7 +997,7 @@ ode_elbo_kernel(const OdeK k) {
     }
     // ---- P2: forward scan x_{n+1} = A_n x_n + b_n (the only serial part of the solve) -------------------
     if (!ext) {
-      if (tid < 64) wave_affine_scan<S, false>(s_A, s_x, T, tid);
+      block_affine_scan<S, false>(s_A, s_x, T, tid, NT, s_ct);   // (the chunk-sum buffer of P6 carries the waves' total maps)
     } else {   // score the adaptive solver's trajectory instead
       const float* xe = k.x_ext + (long long)b * T * S;
       for (int i = tid; i < T * S; i += NT) s_x[i] = xe[i];
