@@ -692,11 +692,15 @@ ode_elbo_kernel(const OdeK k) {
         uj = s_par[k.o_bh + j];
         const float* whr = s_par + k.o_wh + j * (1 + L) + 1;
         const float* w1r = s_par + k.o_w1 + j * L;
+        if (!ext) {   // (the scorer of an external solution has no use for either: zeros keep the shared gradient code finite)
 #pragma unroll 4
-        for (int l = 0; l < L; ++l) {
-          const float zl = s_z[l];
-          uj = fmaf(whr[l], zl, uj);
-          p0 = fmaf(w1r[l], zl, p0);
+          for (int l = 0; l < L; ++l) {
+            const float zl = s_z[l];
+            uj = fmaf(whr[l], zl, uj);
+            p0 = fmaf(w1r[l], zl, p0);
+          }
+        } else {
+          uj = 0.f; p0 = 0.f;
         }
         s_pre0[j] = p0;
         s_hid0[j] = fmaxf(p0, 0.f);
