@@ -324,7 +324,7 @@ def test_dopri5_elbo_step_solution_level(fam, mode):
         fam, kw = "proc", dict(z_g=10, z_eps=10)
     else:
         kw = dict(z_g=3, z_eps=2) if fam == "proc" else dict(z_iext=3, z_rtpr=3, z_eps=2)
-    S, T, B = (8, 100, 70) if fam == "proc" else (5, 60, 70)       # two 64-lane workgroups, ragged tail
+    S, T, B = (8, 100, 70) if fam == "proc" else (5, 60, 70)       # five 16-trajectory workgroups of the solver kernels, ragged tail
     mk_o, mk_e = (O.proc_spec, E.proc_spec) if fam == "proc" else (O.cvs_spec, E.cvs_spec)
     ospec = mk_o(solver="dopri5", **kw)
     ospec.solver_kw = dict(rtol=1e-8, atol=1e-10, per_trajectory=True)
@@ -343,8 +343,11 @@ def test_dopri5_elbo_step_solution_level(fam, mode):
     loss = torch.zeros(1, device=dev)
     grads = torch.full((eng.n_params,), float("nan"), device=dev)
     x = torch.empty(B, T, S, device=dev)
+    eng.workspace(B).fill_(float("nan"))          # nothing may survive from an earlier launch: every slab element has an owner
     eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss, grads=grads, x_out=x)
     assert torch.isfinite(loss).all() and torch.isfinite(grads).all()
+    steps = eng.dopri5_step_counts(B)
+    assert steps.shape == (B,) and int(steps.min()) >= 1 and int(steps.max()) < 2048
     p64 = {k: v.double() for k, v in p.items()}
     ospec.grad_mode = mode
     q = {k: v.clone().requires_grad_(True) for k, v in p64.items()}
