@@ -110,9 +110,23 @@ __host__ __device__ inline int imax2(int a, int b) { return a > b ? a : b; }
 // The block A | x | lam | st is one work region: besides the scan operands it holds, at different times, the piecewise-linear table of
 // the dynamics heads (P1), the stage-0 exchange rows / dLoss/dmu (P1, P3), the per-sample gradient rows G[nt][2S] (P5 -> P6) and the
 // staged encoder head weights (P7).
-__host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int Q, int nt, int npar, int nthreads, int naux, bool one) {
+// `scorer`: the shape-specialised solver-free scorer (ALG 3) touches neither the scan operands A / lam, nor the sample rows, the chunk
+// sums, GM | GT or the event arrays: they get no space (their offsets alias what follows; nothing reads or writes them).
+__host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int Q, int nt, int npar, int nthreads, int naux, bool one,
+                                          bool scorer = false) {
   LdsMap m;
   int o = 0;
+  if (scorer) {
+    m.ts = o; o += pad4(nt);
+    m.sig = o; o += one ? 0 : pad4(C * T);
+    m.ax = pad4(T * S);
+    m.A = o; m.lam = o;                 // (unused)
+    m.x = o; o += m.ax;
+    m.st = o; m.stn = pad4(Q * C * T); o += m.stn;   // dLoss/dmu [Q*C][T]
+    m.ct = o; m.gm = o;                 // (unused)
+    m.hp = o; o += pad4(4 * Q * C * S);
+    m.tau = m.ps = m.ord = m.sgs = m.ewt = m.epre = m.epre0 = m.esw = m.ms = m.sf = o;   // (unused)
+  } else {
   // P6 reads the sample rows in chunks of CL = ceil(nt / NQ) samples: when the last chunk overhangs the table by a few samples, zero
   // pad rows (and pad stage times) make every chunk full, and the contraction needs no bounds at all (ode_pad_rows)
   const int padr = ode_pad_rows(nt, nthreads, S);
@@ -139,6 +153,7 @@ __host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int
   m.esw = o; o += 32 * 2 * S;                           // events in table order: sign * W[c][unit], [32][2S]
   m.ms = o; o += 32;
   m.sf = o; o += 32;
+  }
   m.uu = o; o += SLODE_MAX_NU;
   m.z = o; o += pad4(L);
   m.gzl = o; o += pad4(L);
@@ -461,6 +476,7 @@ __host__ __device__ constexpr int ode_max_threads(int S, int T_, int C_, int Q_,
 //   ALG 2: forward direct, backward contraction as two f32 MFMA GEMMs [g | g t]^T x mask (v_mfma_f32_16x16x4_f32): the measured
 //          A/B arm SURVEY hard part 8 / DESIGN 5 ask for.
 // ALG 1 / 2 are instantiated for the metric shape only (handle flag `ode_alg`, tests + bench A/B), never dispatched otherwise.
+//   ALG 3: the solver-free scorer of an externally solved trajectory (dopri5 training) with compile-time shape: BASELINE config[2].
 //
 // S = 8 carries 60% more live state per thread: its instantiations trade one wave/SIMD for a 168-VGPR budget (T <= 768).
 // T_, C_, L_, Q_, M_ (time points, channels, latent dim, decoder heads, solver): 0 / -1 = read from the launch struct; the
@@ -482,7 +498,7 @@ ode_elbo_kernel(const OdeK k) {
   // RA (grad_mode = reference_adjoint): the backward pass also needs a, d at node n+1 for euler / midpoint
   const int need_next = RA ? 1 : uses_next;
   const int NT = T_ ? ode_threads_for(T_, Q_, C_, S) : (int)blockDim.x;
-  const LdsMap m = lds_map(T, S, H, C, L, Q, n_stage_t, k.npar, NT, k.n_aux_lds, ONE);
+  const LdsMap m = lds_map(T, S, H, C, L, Q, n_stage_t, k.npar, NT, k.n_aux_lds, ONE, ALG == 3);
   float* s_ts = smem + m.ts;
   float* s_sig = smem + m.sig;
   float* s_A = smem + m.A;
@@ -534,7 +550,7 @@ ode_elbo_kernel(const OdeK k) {
   STAMP(0);
   const int tid_outer = tid;
   // scoring an externally solved trajectory (dopri5 training, generic instantiation): no solve, nothing flows through a solver here
-  const bool ext = (T_ == 0) && k.x_ext != nullptr;
+  const bool ext = (ALG == 3) || ((T_ == 0) && k.x_ext != nullptr);   // ALG 3: shape-specialised scorer (every solver phase is dead code)
 
   // ---- per-workgroup setup (shared by all trajectories this workgroup integrates) ----------------------
   // The stage-time table and the parameter segment go global -> LDS by LDS-DMA (global_load_lds: 64 consecutive floats per wave
@@ -599,7 +615,7 @@ ode_elbo_kernel(const OdeK k) {
       for (int c = 0; c < SLODE_MAX_C; ++c)
         if (c < C) sigr[c] = k.sigtab ? v_c[c] : softplusf(v_c[c]);
     }
-    if (tid < ode_pad_rows(n_stage_t, NT, S)) s_ts[n_stage_t + tid] = 0.f;   // pad stage times (P6: full chunks)
+    if (!ext && tid < ode_pad_rows(n_stage_t, NT, S)) s_ts[n_stage_t + tid] = 0.f;   // pad stage times (P6: full chunks)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA has landed (the barrier below covers the other waves')
   }
   STAMP(13);
@@ -1774,6 +1790,13 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
     if (a.alg == 2) return launch_one<5, 25, true, 200, 3, 8, 3, SLODE_RK4, false, true, 2>(k, a.grid, nthreads, lds, stream);
     snprintf(err, errlen, "unknown ode kernel variant %d", a.alg);
     return hipErrorInvalidValue;
+  }
+  // the scorer of BASELINE config[2] as written (proc, dopri5): shape-specialised, solver phases compiled out
+  if (a.x_ext && !a.force_generic && a.alg == 0 && !ra && s.H == 25 && s.S == 8 && s.T == 100 && s.C == 4 && s.L == 50 && k.Q == 3 &&
+      s.method == SLODE_EULER) {
+    const size_t lds_sc = sizeof(float) * (size_t)lds_map(s.T, s.S, s.H, s.C, s.L, k.Q, k.nt, k.npar, nthreads, k.n_aux_lds, one, true).total;
+    if (!bwd) return launch_one<8, 25, false, 100, 4, 50, 3, SLODE_EULER, false, false, 3>(k, a.grid, nthreads, lds_sc, stream);
+    if (one) return launch_one<8, 25, true, 100, 4, 50, 3, SLODE_EULER, false, true, 3>(k, a.grid, nthreads, lds_sc, stream);
   }
   // shape-specialised instantiations (compile-time LDS offsets, loop bounds, solver): the BASELINE.json shapes and the reference default
   if (s.H == 25 && !a.x_ext && !a.force_generic) {
