@@ -473,3 +473,62 @@ def contraction_by_switching_sums(wt, u, W, g, ts, n_chunks=25):
         GT[:, j] = sum(cgt[q] for q in whole) + sum(g[m] * ts[m] for m in cut)
     dW = wt[None, :] * GT + u[None, :] * GM
     return dW, cg.sum(0), (W * GM).sum(0), (W * GT).sum(0)
+
+
+# ---- round-2 algorithms of csrc/dopri5_kernel.hip in numpy fp64 --------------------------------------------------------------------
+def segment_table(wt, u, W, bias, tlo, thi, big=3.0e38):
+    """load_units: switching times th_j = -u_j / wt_j (wt_j == 0: the sign of u_j decides, always / never on), dir bit (on from th_j
+    upwards), their order by counting, and the H + 1 rows [value at the segment centre | slope] built event by event in the centred
+    form.  Returns (th, dirs, centres, V[H+1, NC], AL[H+1, NC])."""
+    H = wt.shape[0]
+    th = np.where(wt != 0, -u / np.where(wt != 0, wt, 1.0), np.where(u > 0, -big, big))
+    th = np.clip(th, -big, big)
+    dirs = wt >= 0
+    rank = np.array([sum((th[k] < th[j]) or (th[k] == th[j] and k < j) for k in range(H)) for j in range(H)])
+    order = np.argsort(rank)
+    c = tlo
+    on0 = ~dirs                                     # below every switching time the units with wt < 0 are on
+    V = bias + (W[:, on0] * (wt[on0] * c + u[on0])).sum(1)
+    AL = (W[:, on0] * wt[on0]).sum(1)
+    rows_V, rows_AL, centres = [V.copy()], [AL.copy()], [c]
+    for j in order:
+        c1 = min(max(th[j], tlo), thi)
+        sg = 1.0 if dirs[j] else -1.0
+        V = V + AL * (c1 - c) + sg * W[:, j] * (wt[j] * c1 + u[j])
+        AL = AL + sg * W[:, j] * wt[j]
+        c = c1
+        rows_V.append(V.copy()); rows_AL.append(AL.copy()); centres.append(c)
+    return th, dirs, np.array(centres), np.array(rows_V), np.array(rows_AL)
+
+
+def eval_segment(t, th, centres, V, AL):
+    """eval_ad: the segment of t is the NUMBER of switching times <= t (a popcount of the t >= th_j bits)."""
+    r = int((t >= th).sum())
+    return V[r] + AL[r] * (t - centres[r])
+
+
+def sweep_by_switching_times(wt, u, W, th, dirs, ts_desc, g):
+    """grp::sweep_sample + the end phase of dopri5_bwd_kernel: samples visited in DEcreasing time, running sums RS = sum g, RT = sum g t,
+    parked when a unit's `t >= th_j` bit flips (at most once per unit); then GM_j = snapshot | total - snapshot | total | 0.
+    ts_desc[m], g[m, c]: the samples in the order of the sweep.  Returns (dW[c, j], dbias[c], dLoss/du_j, dLoss/dwt_j)."""
+    H, NC = wt.shape[0], g.shape[1]
+    RS, RT = np.zeros(NC), np.zeros(NC)
+    snapS, snapT, flipped = np.zeros((H, NC)), np.zeros((H, NC)), np.zeros(H, bool)
+    ge_prev = None
+    for m in range(ts_desc.shape[0]):
+        ge = ts_desc[m] >= th
+        if ge_prev is not None:
+            for j in np.nonzero(ge != ge_prev)[0]:
+                assert not flipped[j], "a unit's bit flips at most once along a monotone sweep"
+                snapS[j], snapT[j], flipped[j] = RS, RT, True
+        ge_prev = ge
+        RS = RS + g[m]
+        RT = RT + g[m] * ts_desc[m]
+    on_early = ~(ge_prev ^ dirs)                    # on at the earliest (last visited) sample
+    GM, GT = np.zeros((NC, H)), np.zeros((NC, H))
+    for j in range(H):
+        sm, st = (snapS[j], snapT[j]) if flipped[j] else (0.0, 0.0)
+        GM[:, j] = RS - sm if on_early[j] else sm
+        GT[:, j] = RT - st if on_early[j] else st
+    dW = wt[None, :] * GT + u[None, :] * GM
+    return dW, RS, (W * GM).sum(0), (W * GT).sum(0)

@@ -102,3 +102,49 @@ def test_piecewise_linear_heads_and_switching_sum_contraction():
         assert np.abs(dW - dW_want).max() < 1e-10 * scale
         assert np.abs(dbias - g.sum(0)).max() < 1e-10 * scale
         assert np.abs(gu - gh.sum(0)).max() < 1e-10 * scale and np.abs(gwt - (gh * ts[:, None]).sum(0)).max() < 1e-9 * scale
+
+
+def test_dopri5_segment_table_and_switching_time_sweep():
+    """The round-2 algorithms of csrc/dopri5_kernel.hip against the direct formulas, fp64: the per-trajectory segment table
+    (switching times, rank by counting, centred rows, segment = popcount of `t >= th_j`) reproduces bias + W relu(wt t + u) at arbitrary
+    evaluation times -- also outside the integration range and for always-on / never-on units -- and the sweep over the samples in
+    decreasing time (running sums parked at each unit's switching time) reproduces the per-sample x per-unit weight-gradient sums.
+    Away from a switching time the table is exact; AT one the kernel's predicate is `t >= th_j` with the rounded th_j where the
+    reference's relu switches at `wt t + u > 0`: the heads are continuous there, so the two differ by O(ulp) of the pre-activation."""
+    rng = np.random.default_rng(11)
+    H, S = 25, 8
+    for case in range(4):
+        tlo, thi = (0.0, 99.0) if case < 3 else (2.0, 40.0)
+        wt = rng.normal(size=H) * 0.4
+        u = -wt * rng.uniform(tlo - 10, thi + 10, size=H)                    # switching times inside and outside the range
+        wt[0], u[0] = 0.0, 1.0                                                # always on
+        wt[1], u[1] = 0.0, -1.0                                               # never on
+        wt[2], u[2] = wt[3], u[3]                                             # two units switching at the same time
+        W, bias = rng.normal(size=(2 * S, H)) * 0.3, rng.normal(size=2 * S)
+        th, dirs, centres, V, AL = KM.segment_table(wt, u, W, bias, tlo, thi)
+        assert np.all(np.diff(centres) >= 0) and centres[0] == tlo and centres[-1] <= thi
+        # evaluation times of an adaptive solve: arbitrary, not on any grid; a few outside the range (Hairer's probe step, dense output)
+        ts = np.concatenate([rng.uniform(tlo, thi, size=400), [tlo - 3.0, thi + 5.0, tlo, thi]])
+        for t in ts:
+            direct = np.maximum(wt * t + u, 0) @ W.T + bias
+            got = KM.eval_segment(t, th, centres, V, AL)
+            assert np.abs(got - direct).max() < 1e-11 * max(1.0, np.abs(direct).max()), (case, t)
+        # the reverse sweep visits its samples in decreasing time: 6 stage times per accepted step, steps from last to first
+        edges = np.sort(rng.uniform(tlo, thi, size=45))
+        edges[0], edges[-1] = tlo, thi
+        samples = []
+        for k in range(len(edges) - 2, -1, -1):
+            t0, dt = edges[k], edges[k + 1] - edges[k]
+            samples += [t0 + dt, t0 + dt * 8 / 9, t0 + dt * 4 / 5, t0 + dt * 3 / 10, t0 + dt / 5, t0]
+        tsd = np.array(samples)
+        g = rng.normal(size=(tsd.shape[0], 2 * S))
+        pre = wt[None, :] * tsd[:, None] + u[None, :]
+        mask = (tsd[:, None] >= th[None, :]) == dirs[None, :]                 # the kernel's on/off bits
+        assert np.all(mask == (pre > 0)) or np.abs(pre[mask != (pre > 0)]).max() < 1e-12   # they are relu's, up to rounding at a switch
+        dW_want = g.T @ (pre * mask)
+        gh = (g @ W) * mask
+        dW, dbias, gu, gwt = KM.sweep_by_switching_times(wt, u, W, th, dirs, tsd, g)
+        scale = np.abs(dW_want).max()
+        assert np.abs(dW - dW_want).max() < 1e-10 * scale
+        assert np.abs(dbias - g.sum(0)).max() < 1e-10 * scale
+        assert np.abs(gu - gh.sum(0)).max() < 1e-10 * scale and np.abs(gwt - (gh * tsd[:, None]).sum(0)).max() < 1e-9 * scale
