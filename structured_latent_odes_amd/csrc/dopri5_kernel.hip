@@ -78,6 +78,12 @@ __device__ __forceinline__ unsigned group_or(unsigned v) {
   v |= dpp_u<0x141>(v);
   return v;
 }
+__device__ __forceinline__ unsigned group_add_u(unsigned v) {
+  v += dpp_u<0xB1>(v);
+  v += dpp_u<0x4E>(v);
+  v += dpp_u<0x141>(v);
+  return v;
+}
 __device__ __forceinline__ float group_add(float v) {
   v += __uint_as_float(dpp_u<0xB1>(__float_as_uint(v)));
   v += __uint_as_float(dpp_u<0x4E>(__float_as_uint(v)));
@@ -88,9 +94,10 @@ __device__ __forceinline__ float group_add(float v) {
 // The hidden layer is relu(w_t t + u_j): unit j switches at th_j = -u_j / w_t,j, so between two consecutive switching times the head
 // pre-activations o_c(t) = bias_c + sum_{j on} W_cj (w_t,j t + u_j) are LINEAR in t.  Per trajectory the H + 1 segments are tabulated
 // once (load_units): row r = (value of the growth / degradation head of component g at the segment's centre, their slopes), the
-// segments ordered by switching time.  The segment of a time t is the NUMBER of switching times <= t -- a popcount of the group's
-// "t >= th_j" bits, no search -- so one evaluation of the coefficients is 4 compares per lane, an OR butterfly over the group on the
-// DPP crossbar, one 16-byte LDS read, 2 fmas and a sigmoid pair: branch-free, and the evaluations of one step are independent.
+// segments ordered by switching time.  The segment of a time t is the NUMBER of switching times <= t -- no search: each lane counts
+// its 4 units, an add butterfly over the group on the DPP crossbar sums the counts -- so one evaluation of the coefficients is 4
+// compares per lane, 3 DPP adds, one 16-byte LDS read, 2 fmas and a sigmoid pair: branch-free, and the evaluations of one step are
+// independent.
 // (The switch is placed at the rounded th_j instead of at the exact sign change of fma(w_t, t, u_j): the heads are continuous there,
 // the difference is a few ulp of o_c.)
 constexpr float BIGT = 3.0e38f;
@@ -98,27 +105,24 @@ struct Units {
   float wt[JL], u[JL];   // this lane's hidden units g, g+8, g+16, g+24
   float th[JL];          // their switching times (+BIGT beyond H: never passed)
 };
-// bit j: t >= th_j (the same word in the 8 lanes of a trajectory)
-__device__ __forceinline__ unsigned ge_bits(float t, const Units& w, int g) {
-  unsigned m = 0u;
+// number of switching times <= t: 4 compares per lane, summed over the group (the same count in the 8 lanes of a trajectory)
+__device__ __forceinline__ int count_passed(float t, const Units& w) {
+  int c = 0;
 #pragma unroll
-  for (int i = 0; i < JL; ++i) m |= (t >= w.th[i]) ? (1u << (g + G * i)) : 0u;
-  return group_or(m);
+  for (int i = 0; i < JL; ++i) c += (t >= w.th[i]) ? 1 : 0;
+  return (int)group_add_u(static_cast<unsigned>(c));
 }
-// growth / degradation coefficient of this lane's state component at time t (blackbox_ode.py:97-109); returns the bits
+// growth / degradation coefficient of this lane's state component at time t (blackbox_ode.py:97-109); returns the segment index
 template <int H>
-__device__ __forceinline__ unsigned eval_ad(float t, const Units& w, int g, bool own, const float4* __restrict__ tab,
-                                            const float* __restrict__ ctr, float& a, float& d) {
-  const unsigned ge = ge_bits(t, w, g);
-  const int r = __builtin_popcount(ge);
+__device__ __forceinline__ int eval_ad(float t, const Units& w, int g, bool own, const float4* __restrict__ tab,
+                                       const float* __restrict__ ctr, float& a, float& d) {
+  const int r = count_passed(t, w);
   const float4 row = tab[r * G + g];
   const float dtau = t - ctr[r];
   a = own ? sigmoidf_fast(fmaf(row.z, dtau, row.x)) : 0.f;
   d = own ? sigmoidf_fast(fmaf(row.w, dtau, row.y)) : 0.f;
-  return ge;
+  return r;
 }
-// bit j: unit j on, given the ge bits (dir bit 1: w_t >= 0, on from th_j upwards; 0: on below th_j)
-__device__ __forceinline__ unsigned on_bits(unsigned ge, unsigned dirmask) { return ~(ge ^ dirmask); }
 
 // x0 = sigmoid(W2 relu(W1 z + b1) + b2), this lane's component (blackbox_ode.py:19-22)
 template <int S, int H>
@@ -142,9 +146,9 @@ __device__ __forceinline__ float init_state(const float* w2, const float* b2, co
 template <int H>
 struct GroupLds {
   float *wt, *wgd, *u, *th, *ctr;
-  int* ord;
+  int *ord, *rnk;   // unit of a rank, rank of a unit
   float4* tab;
-  static constexpr int floats(int ntraj) { return 32 + H * 16 + ntraj * 32 * 4 + ntraj * (H + 1) * G * 4; }
+  static constexpr int floats(int ntraj) { return 32 + H * 16 + ntraj * 32 * 5 + ntraj * (H + 1) * G * 4; }
   __device__ __forceinline__ float* carve(float* base, int ntraj) {   // base 16-byte aligned; returns the first float behind
     tab = reinterpret_cast<float4*>(base);
     wt = base + ntraj * (H + 1) * G * 4;
@@ -153,7 +157,8 @@ struct GroupLds {
     th = u + ntraj * 32;
     ctr = th + ntraj * 32;
     ord = reinterpret_cast<int*>(ctr + ntraj * 32);
-    return ctr + ntraj * 64;
+    rnk = ord + ntraj * 32;
+    return ctr + ntraj * 96;
   }
 };
 
@@ -213,7 +218,7 @@ __device__ __forceinline__ unsigned load_units(const float* wh, const float* bh,
     }
 #pragma unroll
     for (int i = 0; i < JL; ++i)
-      if (g + G * i < H) m.ord[slot * 32 + rank[i]] = g + G * i;
+      if (g + G * i < H) { m.ord[slot * 32 + rank[i]] = g + G * i; m.rnk[slot * 32 + g + G * i] = rank[i]; }
   }
   __syncthreads();
   // segment table, event by event in the centred form: V(c') = V(c) + slope (c' - c) +- W pre(c'), slope +- W w_t
@@ -252,6 +257,9 @@ __device__ __forceinline__ unsigned load_units(const float* wh, const float* bh,
 
 template <int S>
 __device__ __forceinline__ float group_rms(float v, bool own) { return sqrtf(group_add(own ? v * v : 0.f) * (1.0f / S)); }
+// the controller's copy: v_sqrt_f32 (1 ulp) -- the ratio only steers the step size
+template <int S>
+__device__ __forceinline__ float group_rms_fast(float v, bool own) { return __builtin_amdgcn_sqrtf(group_add(own ? v * v : 0.f) * (1.0f / S)); }
 
 template <int S, int H>
 __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
@@ -327,7 +335,7 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
     const float k7 = a6 - d6 * y1;
     const float e = dt * ((35.f / 384 - 1951.f / 21600) * fcur + (500.f / 1113 - 22642.f / 50085) * k3 + (125.f / 192 - 451.f / 720) * k4 +
                           (-2187.f / 6784 + 12231.f / 42400) * k5 + (11.f / 84 - 649.f / 6300) * k6 + (-1.f / 60) * k7);
-    const float ratio = group_rms<S>(e / (atol + rtol * fmaxf(fabsf(y), fabsf(y1))), own);
+    const float ratio = group_rms_fast<S>(e * __builtin_amdgcn_rcpf(atol + rtol * fmaxf(fabsf(y), fabsf(y1))), own);
     // a step at the resolution floor of fp32 time is accepted regardless (torchdiffeq would raise 'underflow in dt')
     const bool accept = act && (ratio <= 1.f || dt <= 16.f * 1.1920929e-7f * fmaxf(fabsf(t), 1.f));
     if (accept) {
@@ -346,8 +354,9 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
         const float cb = dt * (5.f * fcur - 3.f * k7) + 18.f * y + 14.f * y1 - 32.f * ymid;
         const float cc = dt * (k7 - 4.f * fcur) - 11.f * y - 5.f * y1 + 16.f * ymid;
         const float cd = dt * fcur;
+        const float rdt = __builtin_amdgcn_rcpf(dt);
         while (j < T && tj <= t1) {
-          const float xq = (tj - t) / dt;
+          const float xq = (tj - t) * rdt;
           if (own) xo[j * S + gs] = y + xq * (cd + xq * (cc + xq * (cb + xq * ca)));
           ++j;
           tj = s_times[j < T ? j : T - 1];
@@ -383,7 +392,7 @@ struct DpBK {
   const float *w1, *b1, *w2, *b2, *wh, *bh, *wg, *bg, *wd, *bd;
   float *g_loc, *g_scale, *slabs;   // the latent gradient through the solver is ADDED to the scorer's dLoss/dloc, dLoss/dscale [B][L]
   const float* eps;                 // (z = loc + scale eps);  slabs: one row per workgroup, slot 0 = loss (0 / NaN on a failed solve), then the ode segment
-  float* snap;                 // [B][H][4S] running sums parked when a unit's relu flips (see grp::sweep_sample)
+  float* snap;                 // [B][H][4S] running sums parked when the sweep passes a switching time, by RANK (see grp::sweep_sample)
   int slab_stride, nseg, stage_gx;
   int o_w1, o_b1, o_w2, o_b2, o_wh, o_bh, o_wg, o_bg, o_wd, o_bd;
 };
@@ -399,27 +408,27 @@ constexpr int TS = BTP + 1;     // padded trajectory stride of the column-sum ti
 
 // Weight gradients.  Along the time-ordered sequence of evaluation times (all stages of all accepted steps) unit j is switched on over
 // a prefix or a suffix, so its share of every head-weight gradient is a partial sum of the per-sample head gradients g (and of g t) up
-// to the sample where its predicate flips.  The sweep walks the samples backwards in time keeping the running sums RS = sum g,
-// RT = sum g t (this lane's growth and degradation channel) and a bit per unit; when a unit's bit flips the running sums are parked
-// in `snap` (global, [trajectory][unit][4S], written once per unit at most).  After the sweep
+// to the sample where the sweep passes its switching time.  The sweep walks the samples backwards in time keeping the running sums
+// RS = sum g, RT = sum g t (this lane's growth and degradation channel) and the segment index of the last sample; when the index
+// falls, the running sums are parked in `snap` for every switching time passed (global, [trajectory][rank][4S], written once per
+// rank at most).  After the sweep
 //   GM_j = snapshot (unit on at late times) | total - snapshot (on at early times) | total (always on) | 0 (never on),   GT_j likewise,
 //   dW[r][j] = w_t,j GT_j[r] + u_j GM_j[r],  dLoss/du_j = sum_r W[r][j] GM_j[r],  dLoss/dw_t,j = sum_r W[r][j] GT_j[r].
-// one sample of the sweep (decreasing time): park the running sums for every unit whose bit flips at this sample, then add the sample
+// one sample of the sweep (decreasing time): its segment index `now` can only fall; every switching time passed since the previous
+// sample -- ranks [now, prev) -- parks the running sums (snap is indexed by RANK), then the sample is added
 template <int S>
-__device__ __forceinline__ void sweep_sample(float t, unsigned now, float ga, float gd, float& RSa, float& RSd, float& RTa, float& RTd,
-                                             unsigned& onmask, unsigned& tmask, bool& first, bool act, bool own, int gs,
-                                             float* __restrict__ snap) {
-  unsigned flip = (first || !act) ? 0u : (now ^ onmask);
-  while (flip) {   // at most H flips per trajectory
-    const int j = __builtin_ctz(flip);
-    flip &= flip - 1u;
+__device__ __forceinline__ void sweep_sample(float t, int now, float ga, float gd, float& RSa, float& RSd, float& RTa, float& RTd,
+                                             int& prev, int& cnt_first, bool act, bool own, int gs, float* __restrict__ snap) {
+  // (prev starts at 0: the first sample parks nothing; cnt_first = the largest index seen = the first sample's)
+  while (act && prev > now) {   // at most H parkings per trajectory
+    --prev;
     if (own) {
-      float* d = snap + j * 4 * S + gs;
+      float* d = snap + prev * 4 * S + gs;
       d[0] = RSa; d[S] = RSd; d[2 * S] = RTa; d[3 * S] = RTd;
     }
-    tmask |= 1u << j;
   }
-  if (act) { onmask = now; first = false; }
+  prev = act ? now : prev;
+  cnt_first = act ? max(cnt_first, now) : cnt_first;
   const float a = act ? ga : 0.f, d = act ? gd : 0.f;
   RSa += a; RSd += d;
   RTa = fmaf(a, t, RTa); RTd = fmaf(d, t, RTd);
@@ -460,6 +469,7 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   const unsigned dirmask = load_units<S, H>(k.wh, k.bh, k.wg, k.bg, k.wd, k.bd, k.w1, k.b1, s_z + slot * L, L, tid, BNT, fminf(t_first, t_last),
                                             fmaxf(t_first, t_last), m, w, pre0);
   const float* s_us = m.u + slot * 32;
+  const int* s_rnk = m.rnk + slot * 32;
   const float4* tab = m.tab + slot * (H + 1) * G;
   const float* ctr = m.ctr + slot * 32;
   const int nr = live ? k.nrec[bb] : 0;
@@ -469,8 +479,7 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   const float* gxs = s_big + slot * T * S + gs;
   float* snap = k.snap + bb * H * 4 * S;
   float lam = 0.f, RSa = 0.f, RSd = 0.f, RTa = 0.f, RTd = 0.f;
-  unsigned onmask = 0u, tmask = 0u;   // onmask: the ge bits of the latest sample of the sweep
-  bool first = true;
+  int cnt_prev = 0, cnt_first = 0;   // segment index of the previous sample of the sweep (falls along it) and of its first sample
   int j = T - 1;
   float tj = s_times[j], gj = k.stage_gx ? gxs[j * S] : gxb[j * S];   // the next output sample of the sweep
   gj = own ? gj : 0.f;
@@ -494,12 +503,12 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
     const float te0 = t, te1 = t + dt * (1.f / 5), te2 = t + dt * (3.f / 10), te3 = t + dt * (4.f / 5), te4 = t + dt * (8.f / 9), te5 = t + dt;
     // ---- forward recomputation of the stages from the recorded (t, dt, y) ------------------------------------------------------
     float a0, a1, a2, a3, a4, a5, d0, d1, d2, d3, d4, d5;   // six independent table look-ups
-    const unsigned mk0 = eval_ad<H>(te0, w, g, own, tab, ctr, a0, d0);
-    const unsigned mk1 = eval_ad<H>(te1, w, g, own, tab, ctr, a1, d1);
-    const unsigned mk2 = eval_ad<H>(te2, w, g, own, tab, ctr, a2, d2);
-    const unsigned mk3 = eval_ad<H>(te3, w, g, own, tab, ctr, a3, d3);
-    const unsigned mk4 = eval_ad<H>(te4, w, g, own, tab, ctr, a4, d4);
-    const unsigned mk5 = eval_ad<H>(te5, w, g, own, tab, ctr, a5, d5);
+    const int mk0 = eval_ad<H>(te0, w, g, own, tab, ctr, a0, d0);
+    const int mk1 = eval_ad<H>(te1, w, g, own, tab, ctr, a1, d1);
+    const int mk2 = eval_ad<H>(te2, w, g, own, tab, ctr, a2, d2);
+    const int mk3 = eval_ad<H>(te3, w, g, own, tab, ctr, a3, d3);
+    const int mk4 = eval_ad<H>(te4, w, g, own, tab, ctr, a4, d4);
+    const int mk5 = eval_ad<H>(te5, w, g, own, tab, ctr, a5, d5);
     const float ap0 = a0 * (1.f - a0), dp0 = d0 * (1.f - d0), ap1 = a1 * (1.f - a1), dp1 = d1 * (1.f - d1);
     const float ap2 = a2 * (1.f - a2), dp2 = d2 * (1.f - d2), ap3 = a3 * (1.f - a3), dp3 = d3 * (1.f - d3);
     const float ap4 = a4 * (1.f - a4), dp4 = d4 * (1.f - d4), ap5 = a5 * (1.f - a5), dp5 = d5 * (1.f - d5);
@@ -517,7 +526,7 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
     const float y1 = fmaf(dt, (35.f / 384) * k1 + (500.f / 1113) * k3 + (125.f / 192) * k4 + (-2187.f / 6784) * k5 + (11.f / 84) * k6, y);
     // ---- dense outputs inside (t, t + dt]: x_j = y + q cd + q^2 cc + q^3 cb + q^4 ca with q = (times[j] - t) / dt ----------------
     float Ga = 0.f, Gb = 0.f, Gc = 0.f, Gd = 0.f, gy = 0.f;
-    const float rdt = 1.f / dt;
+    const float rdt = __builtin_amdgcn_rcpf(dt);   // (1 ulp: q only places the sample on the step's polynomial)
     while (act && j >= 1 && tj > t) {
       const float q = (tj - t) * rdt, q2 = q * q, q3 = q2 * q, q4 = q2 * q2;
       const float gq = gj;
@@ -560,7 +569,7 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
       g1 = fmaf(de, 9017.f / 3168, g1); g2 = fmaf(de, -355.f / 33, g2); g3 = fmaf(de, 46732.f / 5247, g3);
       g4 = fmaf(de, 49.f / 176, g4); g5 = fmaf(de, -5103.f / 18656, g5);
     }
-    sweep_sample<S>(te5, mk5, xa, xd, RSa, RSd, RTa, RTd, onmask, tmask, first, act, own, gs, snap);
+    sweep_sample<S>(te5, mk5, xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
     {   // stage 5
       xa = g5 * ap4; xd = -g5 * ys5 * dp4;
       const float e = -d4 * g5;
@@ -569,7 +578,7 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
       g1 = fmaf(de, 19372.f / 6561, g1); g2 = fmaf(de, -25360.f / 2187, g2); g3 = fmaf(de, 64448.f / 6561, g3);
       g4 = fmaf(de, -212.f / 729, g4);
     }
-    sweep_sample<S>(te4, mk4, xa, xd, RSa, RSd, RTa, RTd, onmask, tmask, first, act, own, gs, snap);
+    sweep_sample<S>(te4, mk4, xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
     {   // stage 4
       xa = g4 * ap3; xd = -g4 * ys4 * dp3;
       const float e = -d3 * g4;
@@ -577,7 +586,7 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
       const float de = dt * e;
       g1 = fmaf(de, 44.f / 45, g1); g2 = fmaf(de, -56.f / 15, g2); g3 = fmaf(de, 32.f / 9, g3);
     }
-    sweep_sample<S>(te3, mk3, xa, xd, RSa, RSd, RTa, RTd, onmask, tmask, first, act, own, gs, snap);
+    sweep_sample<S>(te3, mk3, xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
     {   // stage 3
       xa = g3 * ap2; xd = -g3 * ys3 * dp2;
       const float e = -d2 * g3;
@@ -585,18 +594,18 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
       const float de = dt * e;
       g1 = fmaf(de, 3.f / 40, g1); g2 = fmaf(de, 9.f / 40, g2);
     }
-    sweep_sample<S>(te2, mk2, xa, xd, RSa, RSd, RTa, RTd, onmask, tmask, first, act, own, gs, snap);
+    sweep_sample<S>(te2, mk2, xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
     {   // stage 2
       xa = g2 * ap1; xd = -g2 * ys2 * dp1;
       const float e = -d1 * g2;
       gy += e;
       g1 = fmaf(dt * e, 1.f / 5, g1);
     }
-    sweep_sample<S>(te1, mk1, xa, xd, RSa, RSd, RTa, RTd, onmask, tmask, first, act, own, gs, snap);
+    sweep_sample<S>(te1, mk1, xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
     // stage 1
     xa = g1 * ap0; xd = -g1 * y * dp0;
     gy = fmaf(-d0, g1, gy);
-    sweep_sample<S>(te0, mk0, xa, xd, RSa, RSd, RTa, RTd, onmask, tmask, first, act, own, gs, snap);
+    sweep_sample<S>(te0, mk0, xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
     lam = act ? gy : lam;
     t = t_n1; dt = dt_n1; y = y_n1;
     t_n1 = t_n2; dt_n1 = dt_n2; y_n1 = y_n2;
@@ -611,8 +620,11 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's own snapshot stores are back-readable
 #pragma unroll 5
     for (int jj = 0; jj < H; ++jj) {
-      const bool flipped = (tmask >> jj) & 1u, on_early = (on_bits(onmask, dirmask) >> jj) & 1u;
-      const float* sn = snap + jj * 4 * S + gs;
+      // unit jj has rank rk among the switching times: passed during the sweep iff cnt_prev <= rk < cnt_first; at the earliest
+      // sample `t >= th` holds iff rk < cnt_prev, and the unit is on there iff that agrees with its direction
+      const int rk = s_rnk[jj];
+      const bool flipped = rk >= cnt_prev && rk < cnt_first, on_early = (rk < cnt_prev) == (((dirmask >> jj) & 1u) != 0u);
+      const float* sn = snap + rk * 4 * S + gs;
       const float s0 = sn[0], s1 = sn[S], s2 = sn[2 * S], s3 = sn[3 * S];
       const float sma = flipped ? s0 : 0.f, smd = flipped ? s1 : 0.f, sta = flipped ? s2 : 0.f, std_ = flipped ? s3 : 0.f;
       // on at early times: flipped ? total - snapshot : total;   off at early times: flipped ? snapshot : 0
