@@ -124,6 +124,26 @@ __device__ __forceinline__ int eval_ad(float t, const Units& w, int g, bool own,
   return r;
 }
 
+// N evaluations at once: all the counts, then all the LDS reads in one batch (left alone, the scheduler waits for each row before it
+// issues the next evaluation's reads), then the sigmoids
+template <int H, int N>
+__device__ __forceinline__ void eval_ad_batch(const float (&t)[N], const Units& w, int g, bool own, const float4* __restrict__ tab,
+                                              const float* __restrict__ ctr, float (&a)[N], float (&d)[N], int (&r)[N]) {
+#pragma unroll
+  for (int n = 0; n < N; ++n) r[n] = count_passed(t[n], w);
+  float4 row[N];
+  float cc[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) { row[n] = tab[r[n] * G + g]; cc[n] = ctr[r[n]]; }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    const float dtau = t[n] - cc[n];
+    a[n] = own ? sigmoidf_fast(fmaf(row[n].z, dtau, row[n].x)) : 0.f;
+    d[n] = own ? sigmoidf_fast(fmaf(row[n].w, dtau, row[n].y)) : 0.f;
+  }
+}
+
 // x0 = sigmoid(W2 relu(W1 z + b1) + b2), this lane's component (blackbox_ode.py:19-22)
 template <int S, int H>
 __device__ __forceinline__ float init_state(const float* w2, const float* b2, const float (&pre0)[JL], int g, bool own) {
@@ -320,12 +340,11 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
     const bool act = live && j < T && steps < k.max_steps;
     ++steps;
     // the five evaluation times of the step are known up front: five independent table look-ups
-    float a2, d2, a3, d3, a4, d4, a5, d5, a6, d6;
-    eval_ad<H>(t + dt * (1.f / 5), w, g, own, tab, ctr, a2, d2);
-    eval_ad<H>(t + dt * (3.f / 10), w, g, own, tab, ctr, a3, d3);
-    eval_ad<H>(t + dt * (4.f / 5), w, g, own, tab, ctr, a4, d4);
-    eval_ad<H>(t + dt * (8.f / 9), w, g, own, tab, ctr, a5, d5);
-    eval_ad<H>(t + dt, w, g, own, tab, ctr, a6, d6);   // stages 6 and 7 share t + dt
+    const float te[5] = {t + dt * (1.f / 5), t + dt * (3.f / 10), t + dt * (4.f / 5), t + dt * (8.f / 9), t + dt};   // stages 6 and 7 share t + dt
+    float av[5], dv[5];
+    int rv[5];
+    eval_ad_batch<H, 5>(te, w, g, own, tab, ctr, av, dv, rv);
+    const float a2 = av[0], d2 = dv[0], a3 = av[1], d3 = dv[1], a4 = av[2], d4 = dv[2], a5 = av[3], d5 = dv[3], a6 = av[4], d6 = dv[4];
     const float k2 = a2 - d2 * fmaf(dt, (1.f / 5) * fcur, y);
     const float k3 = a3 - d3 * fmaf(dt, (3.f / 40) * fcur + (9.f / 40) * k2, y);
     const float k4 = a4 - d4 * fmaf(dt, (44.f / 45) * fcur + (-56.f / 15) * k2 + (32.f / 9) * k3, y);
@@ -483,8 +502,9 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   int j = T - 1;
   float tj = s_times[j], gj = k.stage_gx ? gxs[j * S] : gxb[j * S];   // the next output sample of the sweep
   gj = own ? gj : 0.f;
-  // the record of step K-1-it, two steps ahead of its use (a step is ~1 us of dependent arithmetic: about one memory latency)
-  float t, dt, y, t_n1, dt_n1, y_n1, t_n2, dt_n2, y_n2;
+  // The record of step K-1-it is loaded two steps ahead of its use into one of three register sets used in rotation (the loop is
+  // unrolled by three): a set is never copied, so nothing waits for a load before the step that consumes it.
+  float ta, dta, ya, tb, dtb, yb, tc, dtc, yc;
   const long long rstride = (long long)k.B * (S + 2);   // records of consecutive steps are B (S + 2) floats apart
   const float* rp = k.rec + (long long)(K > 0 ? K - 1 : 0) * rstride + bb * (S + 2);   // step K-1 first
 #define SLODE_LDREC(IT, T_, DT_, Y_)                                                            \
@@ -494,21 +514,19 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
     T_ = a_ ? r0_ : 0.f; DT_ = a_ ? r1_ : 0.f; Y_ = (a_ && own) ? r2_ : 0.f;                    \
     rp -= ((IT) + 1 < K) ? rstride : 0;                                                         \
   }
-  SLODE_LDREC(0, t, dt, y)
-  SLODE_LDREC(1, t_n1, dt_n1, y_n1)
+  SLODE_LDREC(0, ta, dta, ya)
+  SLODE_LDREC(1, tb, dtb, yb)
   // every lane leaves the loop after max(K) <= kmax iterations; the butterflies sit at the top level of the body (all lanes run them)
-  for (int it = 0; __any(it < K); ++it) {
-    const bool act = it < K;
-    SLODE_LDREC(it + 2, t_n2, dt_n2, y_n2)
+  auto step = [&](const float t, const float dt, const float y, const bool act) __attribute__((always_inline)) {
     const float te0 = t, te1 = t + dt * (1.f / 5), te2 = t + dt * (3.f / 10), te3 = t + dt * (4.f / 5), te4 = t + dt * (8.f / 9), te5 = t + dt;
     // ---- forward recomputation of the stages from the recorded (t, dt, y) ------------------------------------------------------
-    float a0, a1, a2, a3, a4, a5, d0, d1, d2, d3, d4, d5;   // six independent table look-ups
-    const int mk0 = eval_ad<H>(te0, w, g, own, tab, ctr, a0, d0);
-    const int mk1 = eval_ad<H>(te1, w, g, own, tab, ctr, a1, d1);
-    const int mk2 = eval_ad<H>(te2, w, g, own, tab, ctr, a2, d2);
-    const int mk3 = eval_ad<H>(te3, w, g, own, tab, ctr, a3, d3);
-    const int mk4 = eval_ad<H>(te4, w, g, own, tab, ctr, a4, d4);
-    const int mk5 = eval_ad<H>(te5, w, g, own, tab, ctr, a5, d5);
+    const float tev[6] = {te0, te1, te2, te3, te4, te5};   // six independent table look-ups, their LDS reads in one batch
+    float av[6], dv[6];
+    int rv[6];
+    eval_ad_batch<H, 6>(tev, w, g, own, tab, ctr, av, dv, rv);
+    const float a0 = av[0], a1 = av[1], a2 = av[2], a3 = av[3], a4 = av[4], a5 = av[5];
+    const float d0 = dv[0], d1 = dv[1], d2 = dv[2], d3 = dv[3], d4 = dv[4], d5 = dv[5];
+    const int mk0 = rv[0], mk1 = rv[1], mk2 = rv[2], mk3 = rv[3], mk4 = rv[4], mk5 = rv[5];
     const float ap0 = a0 * (1.f - a0), dp0 = d0 * (1.f - d0), ap1 = a1 * (1.f - a1), dp1 = d1 * (1.f - d1);
     const float ap2 = a2 * (1.f - a2), dp2 = d2 * (1.f - d2), ap3 = a3 * (1.f - a3), dp3 = d3 * (1.f - d3);
     const float ap4 = a4 * (1.f - a4), dp4 = d4 * (1.f - d4), ap5 = a5 * (1.f - a5), dp5 = d5 * (1.f - d5);
@@ -607,8 +625,16 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
     gy = fmaf(-d0, g1, gy);
     sweep_sample<S>(te0, mk0, xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
     lam = act ? gy : lam;
-    t = t_n1; dt = dt_n1; y = y_n1;
-    t_n1 = t_n2; dt_n1 = dt_n2; y_n1 = y_n2;
+  };
+  for (int it = 0; __any(it < K); it += 3) {
+    SLODE_LDREC(it + 2, tc, dtc, yc)
+    step(ta, dta, ya, it < K);
+    if (!__any(it + 1 < K)) break;
+    SLODE_LDREC(it + 3, ta, dta, ya)
+    step(tb, dtb, yb, it + 1 < K);
+    if (!__any(it + 2 < K)) break;
+    SLODE_LDREC(it + 4, tb, dtb, yb)
+    step(tc, dtc, yc, it + 2 < K);
   }
 #undef SLODE_LDREC
   const bool any_bad = __syncthreads_or(live && bad) != 0;   // (also: every wave is done with the staged dL/dx rows)
