@@ -196,6 +196,13 @@ __device__ __forceinline__ unsigned load_units(const float* wh, const float* bh,
     const int j = i >> 4, c = i & 15, gg = c & 7;
     m.wgd[i] = gg < S ? (c < 8 ? wg[gg * H + j] : wd[gg * H + j]) : 0.f;
   }
+  // both hidden-layer matrices go through LDS (one coalesced pass; 2 x H x L strided global loads per lane otherwise): they borrow the
+  // table region, which is written only after the last read below
+  float* s_whz = reinterpret_cast<float*>(m.tab);   // [H][1 + L]
+  float* s_w1m = s_whz + H * (1 + L);               // [H][L]
+  for (int i = tid; i < H * (1 + L); i += nthreads) s_whz[i] = wh[i];
+  for (int i = tid; i < H * L; i += nthreads) s_w1m[i] = w1[i];
+  __syncthreads();
   float* s_us = m.u + slot * 32;
   float* s_th = m.th + slot * 32;
   unsigned dm = 0u;
@@ -205,12 +212,15 @@ __device__ __forceinline__ unsigned load_units(const float* wh, const float* bh,
     const bool valid = j < H;
     const int jj = valid ? j : 0;
     float uj = bh[jj], pj = b1[jj];
+    const float* whr = s_whz + jj * (1 + L) + 1;
+    const float* w1r = s_w1m + jj * L;
+#pragma unroll 5
     for (int l = 0; l < L; ++l) {
       const float zl = zrow[l];
-      uj = fmaf(wh[jj * (1 + L) + 1 + l], zl, uj);
-      pj = fmaf(w1[jj * L + l], zl, pj);
+      uj = fmaf(whr[l], zl, uj);
+      pj = fmaf(w1r[l], zl, pj);
     }
-    const float wt = valid ? wh[jj * (1 + L)] : 0.f;
+    const float wt = valid ? s_whz[jj * (1 + L)] : 0.f;
     w.wt[i] = wt;
     w.u[i] = valid ? uj : 0.f;
     pre0[i] = valid ? pj : 0.f;
@@ -479,7 +489,13 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   if (k.stage_gx) {   // the workgroup's BTP rows of dL/dx are one contiguous block
     const long long base = (long long)blockIdx.x * BTP * T * S;
     const int ntr = min(BTP, k.B - blockIdx.x * BTP), n = ntr * T * S;
-    for (int i = tid; i < n; i += BNT) s_big[i] = k.gx[base + i];
+    if ((n & 3) == 0 && (base & 3) == 0) {   // 16-byte loads (T * S is a multiple of 4 for every supported shape but odd T with S = 5)
+      const float4* src = reinterpret_cast<const float4*>(k.gx + base);
+      float4* dst = reinterpret_cast<float4*>(s_big);
+      for (int i = tid; i < (n >> 2); i += BNT) dst[i] = src[i];
+    } else {
+      for (int i = tid; i < n; i += BNT) s_big[i] = k.gx[base + i];
+    }
   }
   __syncthreads();
   Units w;
@@ -644,29 +660,43 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   {
     float* tile = s_big;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's own snapshot stores are back-readable
-#pragma unroll 5
-    for (int jj = 0; jj < H; ++jj) {
-      // unit jj has rank rk among the switching times: passed during the sweep iff cnt_prev <= rk < cnt_first; at the earliest
-      // sample `t >= th` holds iff rk < cnt_prev, and the unit is on there iff that agrees with its direction
-      const int rk = s_rnk[jj];
-      const bool flipped = rk >= cnt_prev && rk < cnt_first, on_early = (rk < cnt_prev) == (((dirmask >> jj) & 1u) != 0u);
-      const float* sn = snap + rk * 4 * S + gs;
-      const float s0 = sn[0], s1 = sn[S], s2 = sn[2 * S], s3 = sn[3 * S];
-      const float sma = flipped ? s0 : 0.f, smd = flipped ? s1 : 0.f, sta = flipped ? s2 : 0.f, std_ = flipped ? s3 : 0.f;
-      // on at early times: flipped ? total - snapshot : total;   off at early times: flipped ? snapshot : 0
-      const float gma = on_early ? RSa - sma : sma, gmd = on_early ? RSd - smd : smd;
-      const float gta = on_early ? RTa - sta : sta, gtd = on_early ? RTd - std_ : std_;
-      const float wt = s_wt[jj], uj = s_us[jj];
-      const float w1 = s_wgd[jj * 16 + g], w2 = s_wgd[jj * 16 + 8 + g];   // 0 for lanes without a component
-      const float gu = group_add(fmaf(w1, gma, w2 * gmd)), gwt = group_add(fmaf(w1, gta, w2 * gtd));
-      if (own) {
-        tile[(jj * NTMP + g) * TS + slot] = fmaf(wt, gta, uj * gma);
-        tile[(jj * NTMP + S + g) * TS + slot] = fmaf(wt, gtd, uj * gmd);
+    // unit jj has rank rk among the switching times: passed during the sweep iff cnt_prev <= rk < cnt_first; at the earliest sample
+    // `t >= th` holds iff rk < cnt_prev, and the unit is on there iff that agrees with its direction.  Snapshots are read five units at
+    // a time, unconditionally (a select on a loaded value otherwise serialises one memory round trip per unit).
+    constexpr int UB = 5;
+    for (int j0 = 0; j0 < H; j0 += UB) {
+      int rk[UB];
+      float sv[UB][4];
+#pragma unroll
+      for (int q = 0; q < UB; ++q) rk[q] = s_rnk[min(j0 + q, H - 1)];
+#pragma unroll
+      for (int q = 0; q < UB; ++q) {
+        const float* sn = snap + rk[q] * 4 * S + gs;
+        sv[q][0] = sn[0]; sv[q][1] = sn[S]; sv[q][2] = sn[2 * S]; sv[q][3] = sn[3 * S];
       }
-      if (g == 0) {
-        tile[(jj * NTMP + 2 * S) * TS + slot] = gu;
-        tile[(jj * NTMP + 2 * S + 1) * TS + slot] = gwt;
-        s_gu[slot * 32 + jj] = gu;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < UB; ++q) {
+        const int jj = j0 + q;
+        if (jj < H) {   // (uniform)
+          const bool flipped = rk[q] >= cnt_prev && rk[q] < cnt_first, on_early = (rk[q] < cnt_prev) == (((dirmask >> jj) & 1u) != 0u);
+          const float sma = flipped ? sv[q][0] : 0.f, smd = flipped ? sv[q][1] : 0.f, sta = flipped ? sv[q][2] : 0.f, std_ = flipped ? sv[q][3] : 0.f;
+          // on at early times: flipped ? total - snapshot : total;   off at early times: flipped ? snapshot : 0
+          const float gma = on_early ? RSa - sma : sma, gmd = on_early ? RSd - smd : smd;
+          const float gta = on_early ? RTa - sta : sta, gtd = on_early ? RTd - std_ : std_;
+          const float wt = s_wt[jj], uj = s_us[jj];
+          const float w1 = s_wgd[jj * 16 + g], w2 = s_wgd[jj * 16 + 8 + g];   // 0 for lanes without a component
+          const float gu = group_add(fmaf(w1, gma, w2 * gmd)), gwt = group_add(fmaf(w1, gta, w2 * gtd));
+          if (own) {
+            tile[(jj * NTMP + g) * TS + slot] = fmaf(wt, gta, uj * gma);
+            tile[(jj * NTMP + S + g) * TS + slot] = fmaf(wt, gtd, uj * gmd);
+          }
+          if (g == 0) {
+            tile[(jj * NTMP + 2 * S) * TS + slot] = gu;
+            tile[(jj * NTMP + 2 * S + 1) * TS + slot] = gwt;
+            s_gu[slot * 32 + jj] = gu;
+          }
+        }
       }
     }
     if (own) {   // the constant-1 unit: head biases
@@ -710,17 +740,31 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
       if (jj >= H) s_gu[slot * 32 + jj] = 0.f;
     }
     __syncthreads();
-    // latent gradient of this trajectory: through the init net and (exact mode) through u = W_z z + b_h
-    for (int l = g; l < L; l += G) {
-      float gl = 0.f;
-      for (int jj = 0; jj < H; ++jj) {
-        gl = fmaf(s_w1[jj * L + l], s_gp[slot * 32 + jj], gl);
-        if (!k.drop_z) gl = fmaf(s_wz[jj * L + l], s_gu[slot * 32 + jj], gl);
+    // latent gradient of this trajectory: through the init net and (exact mode) through u = W_z z + b_h; the scorer's share it is
+    // added to (and eps) is fetched up front, eight latent dims at a time
+    for (int l0 = g; l0 < L; l0 += G * 8) {
+      float gl_[8], gs_[8], ep_[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const long long i = bb * L + min(l0 + q * G, L - 1);
+        gl_[q] = k.g_loc[i]; gs_[q] = k.g_scale[i]; ep_[q] = k.eps[i];
       }
-      if (live) {
-        const long long i = bb * L + l;
-        k.g_loc[i] += gl;
-        k.g_scale[i] = fmaf(gl, k.eps[i], k.g_scale[i]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int l = l0 + q * G;
+        if (l < L) {
+          float gl = 0.f;
+          for (int jj = 0; jj < H; ++jj) {
+            gl = fmaf(s_w1[jj * L + l], s_gp[slot * 32 + jj], gl);
+            if (!k.drop_z) gl = fmaf(s_wz[jj * L + l], s_gu[slot * 32 + jj], gl);
+          }
+          if (live) {
+            const long long i = bb * L + l;
+            k.g_loc[i] = gl_[q] + gl;
+            k.g_scale[i] = fmaf(gl, ep_[q], gs_[q]);
+          }
+        }
       }
     }
     // sums over the workgroup's trajectories (fixed order): outer products with z, with the init net's hidden values, bias columns
