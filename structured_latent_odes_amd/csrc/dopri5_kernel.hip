@@ -91,6 +91,21 @@ __device__ __forceinline__ float group_add(float v) {
   return v;
 }
 
+// global -> LDS copies in batches of NB loads per thread, then NB stores (written as `dst[i] = src[i]` in a loop, every LDS store waits
+// for its own load: one memory round trip per element and thread)
+template <typename T, int NB = 8>
+__device__ __forceinline__ void stage_to_lds(T* __restrict__ dst, const T* __restrict__ src, int n, int tid, int nthreads) {
+  for (int i0 = tid; i0 < n; i0 += NB * nthreads) {
+    T v[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) v[q] = src[min(i0 + q * nthreads, n - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+      if (i0 + q * nthreads < n) dst[i0 + q * nthreads] = v[q];
+  }
+}
+
 // The hidden layer is relu(w_t t + u_j): unit j switches at th_j = -u_j / w_t,j, so between two consecutive switching times the head
 // pre-activations o_c(t) = bias_c + sum_{j on} W_cj (w_t,j t + u_j) are LINEAR in t.  Per trajectory the H + 1 segments are tabulated
 // once (load_units): row r = (value of the growth / degradation head of component g at the segment's centre, their slopes), the
@@ -200,8 +215,8 @@ __device__ __forceinline__ unsigned load_units(const float* wh, const float* bh,
   // table region, which is written only after the last read below
   float* s_whz = reinterpret_cast<float*>(m.tab);   // [H][1 + L]
   float* s_w1m = s_whz + H * (1 + L);               // [H][L]
-  for (int i = tid; i < H * (1 + L); i += nthreads) s_whz[i] = wh[i];
-  for (int i = tid; i < H * L; i += nthreads) s_w1m[i] = w1[i];
+  stage_to_lds(s_whz, wh, H * (1 + L), tid, nthreads);
+  stage_to_lds(s_w1m, w1, H * L, tid, nthreads);
   __syncthreads();
   float* s_us = m.u + slot * 32;
   float* s_th = m.th + slot * 32;
@@ -310,7 +325,7 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
     }
     s_z[slot * L + l] = zl;
   }
-  for (int i = tid; i < T; i += DNT) s_times[i] = k.times[i];
+  stage_to_lds(s_times, k.times, T, tid, DNT);
   __syncthreads();
   Units w;
   float pre0[JL];
@@ -485,16 +500,14 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   float* prm = row + 1;
   for (int i = 1 + tid; i <= k.nseg; i += BNT) row[i] = 0.f;   // (every element is written again below; completes long before)
   for (int l = g; l < L; l += G) s_z[slot * L + l] = live ? k.z[bb * L + l] : 0.f;
-  for (int i = tid; i < T; i += BNT) s_times[i] = k.times[i];
+  stage_to_lds(s_times, k.times, T, tid, BNT);
   if (k.stage_gx) {   // the workgroup's BTP rows of dL/dx are one contiguous block
     const long long base = (long long)blockIdx.x * BTP * T * S;
     const int ntr = min(BTP, k.B - blockIdx.x * BTP), n = ntr * T * S;
     if ((n & 3) == 0 && (base & 3) == 0) {   // 16-byte loads (T * S is a multiple of 4 for every supported shape but odd T with S = 5)
-      const float4* src = reinterpret_cast<const float4*>(k.gx + base);
-      float4* dst = reinterpret_cast<float4*>(s_big);
-      for (int i = tid; i < (n >> 2); i += BNT) dst[i] = src[i];
+      stage_to_lds(reinterpret_cast<float4*>(s_big), reinterpret_cast<const float4*>(k.gx + base), n >> 2, tid, BNT);
     } else {
-      for (int i = tid; i < n; i += BNT) s_big[i] = k.gx[base + i];
+      stage_to_lds(s_big, k.gx + base, n, tid, BNT);
     }
   }
   __syncthreads();
@@ -719,10 +732,18 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   {
     float* s_w1 = s_big;            // [H][L]
     float* s_wz = s_big + H * L;    // [H][L]  z-columns of the dynamics net's hidden layer
-    for (int i = tid; i < H * L; i += BNT) {
-      const int jj = i / L, l = i - jj * L;
-      s_w1[i] = k.w1[i];
-      s_wz[i] = k.wh[jj * (1 + L) + 1 + l];
+    stage_to_lds(s_w1, k.w1, H * L, tid, BNT);
+    for (int i0 = tid; i0 < H * L; i0 += 8 * BNT) {   // z-columns of the hidden layer: row pitch 1 + L
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = min(i0 + q * BNT, H * L - 1), jj = i / L;
+        v[q] = k.wh[i + jj + 1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (i0 + q * BNT < H * L) s_wz[i0 + q * BNT] = v[q];
     }
     const float x0 = init_state<S, H>(k.w2, k.b2, pre0, g, own);
     const float g0 = (live && !bad && own) ? lam + gxb[0] : 0.f;
@@ -754,11 +775,13 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
       for (int q = 0; q < 8; ++q) {
         const int l = l0 + q * G;
         if (l < L) {
-          float gl = 0.f;
+          float gl = 0.f, gl2 = 0.f;   // two chains: through the init net, through the dynamics' hidden layer
+#pragma unroll 5
           for (int jj = 0; jj < H; ++jj) {
             gl = fmaf(s_w1[jj * L + l], s_gp[slot * 32 + jj], gl);
-            if (!k.drop_z) gl = fmaf(s_wz[jj * L + l], s_gu[slot * 32 + jj], gl);
+            gl2 = fmaf(s_wz[jj * L + l], s_gu[slot * 32 + jj], gl2);
           }
+          gl += k.drop_z ? 0.f : gl2;
           if (live) {
             const long long i = bb * L + l;
             k.g_loc[i] = gl_[q] + gl;
