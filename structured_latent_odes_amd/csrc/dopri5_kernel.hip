@@ -498,18 +498,27 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   const int gs = own ? g : 0;
   float* row = k.slabs + (long long)blockIdx.x * k.slab_stride;
   float* prm = row + 1;
+  if (k.stage_gx) {
+    // The workgroup's BTP rows of dL/dx are one contiguous block: global -> LDS by LDS-DMA (global_load_lds, 16 bytes per lane, 1 KB per
+    // wave instruction, no registers), issued before anything else and awaited only right before the sweep -- the whole set-up hides it.
+    const long long base = (long long)blockIdx.x * BTP * T * S;
+    const int ntr = min(BTP, k.B - blockIdx.x * BTP), n = ntr * T * S;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, NW = BNT >> 6;
+    if ((n & 3) == 0 && (base & 3) == 0) {
+      for (int b0 = wv * 256; b0 < n; b0 += NW * 256)
+        if (b0 + lane * 4 < n)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(k.gx + base + b0 + lane * 4),
+                                           (__attribute__((address_space(3))) void*)(s_big + b0), 16, 0, 0);
+    } else {
+      for (int b0 = wv * 64; b0 < n; b0 += NW * 64)
+        if (b0 + lane < n)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(k.gx + base + b0 + lane),
+                                           (__attribute__((address_space(3))) void*)(s_big + b0), 4, 0, 0);
+    }
+  }
   for (int i = 1 + tid; i <= k.nseg; i += BNT) row[i] = 0.f;   // (every element is written again below; completes long before)
   for (int l = g; l < L; l += G) s_z[slot * L + l] = live ? k.z[bb * L + l] : 0.f;
   stage_to_lds(s_times, k.times, T, tid, BNT);
-  if (k.stage_gx) {   // the workgroup's BTP rows of dL/dx are one contiguous block
-    const long long base = (long long)blockIdx.x * BTP * T * S;
-    const int ntr = min(BTP, k.B - blockIdx.x * BTP), n = ntr * T * S;
-    if ((n & 3) == 0 && (base & 3) == 0) {   // 16-byte loads (T * S is a multiple of 4 for every supported shape but odd T with S = 5)
-      stage_to_lds(reinterpret_cast<float4*>(s_big), reinterpret_cast<const float4*>(k.gx + base), n >> 2, tid, BNT);
-    } else {
-      stage_to_lds(s_big, k.gx + base, n, tid, BNT);
-    }
-  }
   __syncthreads();
   Units w;
   float pre0[JL];
@@ -528,6 +537,10 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   float* snap = k.snap + bb * H * 4 * S;
   float lam = 0.f, RSa = 0.f, RSd = 0.f, RTa = 0.f, RTd = 0.f;
   int cnt_prev = 0, cnt_first = 0;   // segment index of the previous sample of the sweep (falls along it) and of its first sample
+  if (k.stage_gx) {   // the LDS-DMA of dL/dx issued at the top has landed (every wave drains its own, the barrier covers the others')
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   int j = T - 1;
   float tj = s_times[j], gj = k.stage_gx ? gxs[j * S] : gxb[j * S];   // the next output sample of the sweep
   gj = own ? gj : 0.f;
@@ -771,22 +784,26 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
         gl_[q] = k.g_loc[i]; gs_[q] = k.g_scale[i]; ep_[q] = k.eps[i];
       }
       __builtin_amdgcn_sched_barrier(0);
+      float a1[8], a2[8];   // through the init net / through the dynamics' hidden layer: 16 independent chains, unit-major
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { a1[q] = 0.f; a2[q] = 0.f; }
+      for (int jj = 0; jj < H; ++jj) {
+        const float gp = s_gp[slot * 32 + jj], gu = s_gu[slot * 32 + jj];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int l = min(l0 + q * G, L - 1);
+          a1[q] = fmaf(s_w1[jj * L + l], gp, a1[q]);
+          a2[q] = fmaf(s_wz[jj * L + l], gu, a2[q]);
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int l = l0 + q * G;
-        if (l < L) {
-          float gl = 0.f, gl2 = 0.f;   // two chains: through the init net, through the dynamics' hidden layer
-#pragma unroll 5
-          for (int jj = 0; jj < H; ++jj) {
-            gl = fmaf(s_w1[jj * L + l], s_gp[slot * 32 + jj], gl);
-            gl2 = fmaf(s_wz[jj * L + l], s_gu[slot * 32 + jj], gl2);
-          }
-          gl += k.drop_z ? 0.f : gl2;
-          if (live) {
-            const long long i = bb * L + l;
-            k.g_loc[i] = gl_[q] + gl;
-            k.g_scale[i] = fmaf(gl, ep_[q], gs_[q]);
-          }
+        if (l < L && live) {
+          const float gl = a1[q] + (k.drop_z ? 0.f : a2[q]);
+          const long long i = bb * L + l;
+          k.g_loc[i] = gl_[q] + gl;
+          k.g_scale[i] = fmaf(gl, ep_[q], gs_[q]);
         }
       }
     }
