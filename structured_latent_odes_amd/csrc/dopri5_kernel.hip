@@ -445,7 +445,7 @@ namespace grp {
 // Reverse sweep in the forward kernel's mapping: EIGHT LANES PER TRAJECTORY, lane g = state component g.  The reverse mode of a
 // Dormand-Prince step is component-wise (the right-hand side a_g(t) - d_g(t) y_g couples components only through the time-dependent
 // coefficients), so every quantity of the step -- stage states, stage adjoints, dense-output sums, the running sums of the weight
-// gradients -- is ONE scalar per lane: ~80 registers, nothing spilled, nothing staged.
+// gradients -- is ONE scalar per lane: nothing spilled (tools/check_spills.py), no per-stage staging through LDS.
 constexpr int BNT = 128;        // threads per workgroup
 constexpr int BTP = BNT / G;    // trajectories per workgroup (= per slab row)
 constexpr int TS = BTP + 1;     // padded trajectory stride of the column-sum tile
