@@ -140,7 +140,7 @@ __host__ __device__ inline LdsMap lds_map(int T, int S, int H, int C, int L, int
   int stn = imax2(((2 * S + 4) & ~3) * T, Q * C * T);   // stage-0 exchange rows [T][SP]; dLoss/dmu [Q*C][T]
   stn = imax2(stn, (nt + padr) * 2 * S - 3 * m.ax);     // G rows (+ pad rows) overlay the whole block
   m.st = o; m.stn = pad4(stn); o += m.stn;
-  m.ct = o; o += pad4((nthreads / (2 * S)) * 4 * S);    // chunk sums [NQ][sum g (2S) | sum g t (2S)]
+  m.ct = o; o += pad4((nthreads / (2 * S) + 1) * 4 * S);   // chunk sums [NQ (+1: total)][sum g (2S) | sum g t (2S)]
   m.gm = o; o += 2 * 2 * S * 32;                        // GM | GT: [2][2S][32] (unit H = the constant-1 unit)
   m.hp = o; o += pad4(4 * Q * C * S);                   // head-weight partials [hsplit][Q*C*S]
   m.tau = o; o += 32;
@@ -1324,6 +1324,30 @@ ode_elbo_kernel(const OdeK k) {
           s_ct[q * 4 * S + 2 * S + r] = cgt;
         }
         __syncthreads();
+        // (A') shape-specialised kernels: one lane per column turns the chunk sums into exclusive prefix sums (in place; row NQ = the
+        // total) and suffix sums (in the event arrays of P0c / P1, dead by now), each column held in registers meanwhile -- (B) then
+        // reads ONE row instead of adding up to NQ.  Still only additions on a unit's "on" side.
+        const bool scanq = fullc && NQ <= 32 && (NQ + 1) * 4 * S <= 7 * 32 + 32 * 2 * S;
+        float* s_sx = s_tau;   // [NQ + 1][4S] suffix sums over tau | ps | ord | sgs | ewt | epre | epre0 | esw
+        if (scanq) {
+          if (tid < 4 * S) {
+            float cq[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) cq[q] = s_ct[min(q, NQ - 1) * 4 * S + tid];
+            __builtin_amdgcn_sched_barrier(0);
+            float run = 0.f;
+#pragma unroll
+            for (int q = 0; q < 32; ++q)
+              if (q < NQ) { s_ct[q * 4 * S + tid] = run; run += cq[q]; }
+            s_ct[NQ * 4 * S + tid] = run;
+            float rs = 0.f;
+            s_sx[NQ * 4 * S + tid] = 0.f;
+#pragma unroll
+            for (int q = 31; q >= 0; --q)
+              if (q < NQ) { rs += cq[q]; s_sx[q * 4 * S + tid] = rs; }
+          }
+          __syncthreads();
+        }
         // (B) lane (unit j, channel r): whole chunks on the unit's "on" side + the samples of the chunk its switching index cuts.
         //     Only additions on the "on" side: no total-minus-prefix cancellation.  Fixed trip counts, masked adds.
         for (int e = tid; e < H * 2 * S; e += NT) {
@@ -1333,6 +1357,10 @@ ode_elbo_kernel(const OdeK k) {
           const int qa = sf ? qs + 1 : 0, qn = max(sf ? NQ - qa : qs, 0);    // whole chunks [qa, qa + qn)  (a never-on unit: ms = nt, none)
           const int ma = sf ? ms : qs * CL, mn = max(sf ? (qs + 1) * CL - ms : ms - qs * CL, 0);   // cut chunk: samples [ma, ma + mn)
           float gmv = 0.f, gtv = 0.f;
+          if (scanq) {   // whole chunks [qs + 1, NQ) (on from ms upwards) or [0, qs) (on below ms): one row of the suffix / prefix sums
+            const float* src = (sf ? s_sx : s_ct) + min(sf ? qs + 1 : qs, NQ) * 4 * S;
+            gmv = src[r]; gtv = src[2 * S + r];
+          } else
           for (int q0 = 0; q0 < NQ; q0 += 8) {
             float v[8], w[8];
 #pragma unroll
@@ -1393,8 +1421,11 @@ ode_elbo_kernel(const OdeK k) {
         if (tid >= NT - 2 * S) {   // the constant-1 unit: every sample
           const int r = tid - (NT - 2 * S);
           float gmv = 0.f;
+          if (scanq) gmv = s_ct[NQ * 4 * S + r];
+          else {
 #pragma unroll 8
-          for (int q = 0; q < NQ; ++q) gmv += s_ct[q * 4 * S + r];
+            for (int q = 0; q < NQ; ++q) gmv += s_ct[q * 4 * S + r];
+          }
           s_gm[r * 32 + H] = gmv;
         }
       } else {

@@ -107,12 +107,15 @@ def test_instantiation_matches_oracle(shape, form, mode, monkeypatch):
     _run(_case(shape, mode), mode, FORMS[form], monkeypatch)
 
 
-def test_forms_agree_bitwise_where_the_order_is_the_same(monkeypatch):
-    """The specialised and the generic loop-free kernels run the same arithmetic in the same order."""
+def test_specialised_and_generic_forms_agree(monkeypatch):
+    """The specialised and the generic loop-free kernels run the same arithmetic; the only difference in ORDER is the weight-gradient
+    contraction's whole-chunk part (prefix / suffix sums of the chunk sums in the specialised kernels, masked adds in the generic one):
+    same loss bit for bit, gradients to rounding."""
     c = _case("c1_cvs_T200_L8_rk4", "exact")
     a = _run(c, "exact", FORMS["loop_free"], monkeypatch)
     b = _run(c, "exact", FORMS["generic_loop_free"], monkeypatch)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[0], b[0])
+    assert _rel(a[1], b[1]) < 2e-6
 
 
 @pytest.mark.parametrize("alg", [1, 2])
