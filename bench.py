@@ -225,6 +225,7 @@ def main():
                      "pipe": "fp32 VALU (the dominant kernel issues no MFMA; on gfx950 the f32 MFMA peak equals the f32 vector peak, 157.3 TF)",
                      "clock": "max(HIP-event bracket - live empty bracket, in-stream differential of a doubled launch), measured in this run",
                      "rocprof_kernel_avg_us": rocprof_us,
+                     "frac_on_rocprof_clock": (flops_launch / (rocprof_us * 1e-6) / 1e12 / PEAK_FP32) if rocprof_us else None,
                      "issue_roofline": issue,
                      "algorithmic_flops_per_launch": flops_launch, "kernel_us": roof_us, "kernel_us_event_bracket": dom_us,
                      "kernel_avg_us": roof_us, "kernel_us_instream_diff": dom_us_instream,
