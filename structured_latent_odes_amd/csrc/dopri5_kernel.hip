@@ -282,18 +282,35 @@ __device__ __forceinline__ unsigned load_units(const float* wh, const float* bh,
     }
     tab[g] = make_float4(va, vd, ala, ald);
     if (g == 0) ctr[0] = c;
-    for (int r = 0; r < H; ++r) {
-      const int j = m.ord[slot * 32 + r];
-      const float c1 = fminf(fmaxf(s_th[j], tlo), thi);
-      const float wt = m.wt[j], sg = ((dirmask >> j) & 1u) ? 1.f : -1.f;
-      const float pre = sg * fmaf(wt, c1, s_us[j]), swt = sg * wt;
-      const float w1_ = m.wgd[j * 16 + g], w2_ = m.wgd[j * 16 + 8 + g];
-      const float dc = c1 - c;
-      va = fmaf(w1_, pre, fmaf(ala, dc, va)); vd = fmaf(w2_, pre, fmaf(ald, dc, vd));
-      ala = fmaf(w1_, swt, ala); ald = fmaf(w2_, swt, ald);
-      c = c1;
-      tab[(r + 1) * G + g] = make_float4(va, vd, ala, ald);
-      if (g == 0) ctr[r + 1] = c;
+    // five events at a time: their units, then the units' five operands, are read in two batches ahead of the chain (one event at a
+    // time costs two dependent LDS round trips per event on the trajectory's critical path)
+    constexpr int EB = 5;
+    for (int r0 = 0; r0 < H; r0 += EB) {
+      int jv[EB];
+      float thv[EB], wtv[EB], usv[EB], w1v[EB], w2v[EB];
+#pragma unroll
+      for (int q = 0; q < EB; ++q) jv[q] = m.ord[slot * 32 + min(r0 + q, H - 1)];
+#pragma unroll
+      for (int q = 0; q < EB; ++q) {
+        thv[q] = s_th[jv[q]]; wtv[q] = m.wt[jv[q]]; usv[q] = s_us[jv[q]];
+        w1v[q] = m.wgd[jv[q] * 16 + g]; w2v[q] = m.wgd[jv[q] * 16 + 8 + g];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < EB; ++q) {
+        const int r = r0 + q;
+        if (r < H) {   // (uniform)
+          const float c1 = fminf(fmaxf(thv[q], tlo), thi);
+          const float sg = ((dirmask >> jv[q]) & 1u) ? 1.f : -1.f;
+          const float pre = sg * fmaf(wtv[q], c1, usv[q]), swt = sg * wtv[q];
+          const float dc = c1 - c;
+          va = fmaf(w1v[q], pre, fmaf(ala, dc, va)); vd = fmaf(w2v[q], pre, fmaf(ald, dc, vd));
+          ala = fmaf(w1v[q], swt, ala); ald = fmaf(w2v[q], swt, ald);
+          c = c1;
+          tab[(r + 1) * G + g] = make_float4(va, vd, ala, ald);
+          if (g == 0) ctr[r + 1] = c;
+        }
+      }
     }
   }
   __syncthreads();
