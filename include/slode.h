@@ -249,19 +249,16 @@ int slode_adam_region(slode_handle h, int64_t lo, int64_t hi, int64_t step_delta
 int slode_dopri5_step_counts(slode_handle h, const slode_shape* s, const slode_layout* lay, const void* workspace,
                              size_t workspace_bytes, int* counts, void* stream);
 
-/* Measurement aid for bench.py's roofline block (no reference counterpart): when enabled, slode_elbo_step records HIP
- * events on `stream` around each of its kernels; slode_profile_read waits for the last one and returns the durations in
- * milliseconds of [fold (W_eff), encoder_fwd, ode_elbo (fused solve + ELBO fwd/bwd), encoder_bwd (heads),
- * gemm (MFMA g_pre^T X), chain (back to lin/conv weights), reduce].  With non-dense observation strides the layer-by-layer
- * encoder runs instead: slot 0 = 0, slot 3 = its backward, slot 4 = its MFMA lin.weight GEMM, slot 5 = 0.
- * on = 1: events around every kernel (each bracket costs the kernels ~2-3 us); on = 2 + s: only slot s is bracketed (two events per
- * step: the least perturbed duration of that kernel; the other slots read 0); on = 0: off; on = 16 + r: no events, but the
- * (idempotent) ode_elbo kernel is launched 1 + r times per step -- the difference of two timed runs is its in-stream duration without
- * any event on the stream (bench.py).  In the folded-encoder step slots 3
- * (encoder heads backward, now inside ode_elbo) and 6 (reduction, now inside the chain launch) only measure event overhead. */
-#define SLODE_PROFILE_SLOTS 7
+/* Measurement aid for bench.py's roofline block (no reference counterpart).  on = 1: every kernel that slode_elbo_step /
+ * slode_elbo_adam_step / slode_aux_step / slode_adam_step launch from now on carries its own start / stop event pair (hipExtLaunchKernelGGL):
+ * the begin -> end device timestamps of that dispatch -- the duration rocprofv3 --kernel-trace reports for it -- without any extra
+ * packet on `stream`; on = 0: off.  slode_profile_read waits for the kernels of the LAST such call on this handle and returns their
+ * number n (<= max_kernels; a negative slode_status on error), their names (static strings: "weff", "enc_fwd2", "ode_elbo", "enc_bwd_lin",
+ * "enc_chain", "dopri5_fwd", "dopri5_bwd", "aux", "enc_bwd2", "slab_stage1", "reduce", "adam", ...) in launch order and their durations in
+ * microseconds. */
+#define SLODE_PROFILE_MAX_KERNELS 16
 int slode_profile_enable(slode_handle h, int on);
-int slode_profile_read(slode_handle h, float ms[SLODE_PROFILE_SLOTS]);
+int slode_profile_read(slode_handle h, int max_kernels, const char** names, float* us);
 
 #ifdef __cplusplus
 }

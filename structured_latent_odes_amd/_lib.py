@@ -95,7 +95,7 @@ def load():
     lib.slode_label_heads.argtypes = [VP, P(Shape), P(Layout), VP, VP, VP, VP]
     lib.slode_dopri5_step_counts.argtypes = [VP, P(Shape), P(Layout), VP, C.c_size_t, VP, VP]
     lib.slode_profile_enable.argtypes = [VP, C.c_int]
-    lib.slode_profile_read.argtypes = [VP, P(C.c_float)]
+    lib.slode_profile_read.argtypes = [VP, C.c_int, P(C.c_char_p), P(C.c_float)]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here == the ABI in include/slode.h is not fully exported
     _lib = lib

@@ -188,6 +188,6 @@ hipError_t slode_launch_aux(const AuxLaunch& a, hipStream_t stream) {
   const size_t lds = sizeof(float) * (2 * (size_t)((k.npar + 4) & ~3) + 4 * SLODE_MAX_L + SLODE_MAX_NU + 2 * SLODE_MAX_AUX * 32 +
                                       SLODE_MAX_AUX * 12 + 8);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)aux_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(aux_kernel, dim3(a.grid), dim3(ANT), lds, stream, k);
+  SLODE_LAUNCH("aux", aux_kernel, dim3(a.grid), dim3(ANT), lds, stream, k);
   return hipGetLastError();
 }

@@ -344,6 +344,12 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
   }
   stage_to_lds(s_times, k.times, T, tid, DNT);
   __syncthreads();
+  // The controller only integrates forward in time: a grid that is not strictly increasing (torchdiffeq accepts a decreasing one by
+  // integrating in -t; this engine rejects it -- Engine.set_times raises, and a caller that comes through the bare C ABI gets NaN
+  // trajectories, hence a NaN loss, instead of a quietly extrapolated dense output) fails the solve for the whole workgroup.
+  int bad_grid = 0;
+  for (int i = tid; i + 1 < T; i += DNT) bad_grid |= !(s_times[i + 1] > s_times[i]);
+  bad_grid = __syncthreads_or(bad_grid);
   Units w;
   float pre0[JL];
   const float t_first = s_times[0], t_last = s_times[T - 1];
@@ -374,9 +380,9 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
     dt = fminf(100.f * h0, h1);
   }
   int j = 1;
-  int steps = 0, nacc = 0;
+  int steps = bad_grid ? k.max_steps : 0, nacc = 0;
   float tj = s_times[j < T ? j : T - 1];   // the next output time, read ahead of its use
-  // every lane leaves the loop: either all outputs written or max_steps reached (outputs then hold the last state).  The butterflies
+  // every lane leaves the loop: either all outputs written or max_steps reached (the missing outputs are then NaN).  The butterflies
   // inside eval_ad / group_rms sit at the top level of the loop body: all 64 lanes execute them.
   while (__any(live && j < T && steps < k.max_steps)) {
     const bool act = live && j < T && steps < k.max_steps;
@@ -439,9 +445,11 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
   }
   if (live) {
     if (k.nrec && g == 0) k.nrec[b] = (j < T) ? -1 : nacc;
-    // max_steps exhausted: fill the remaining outputs with the last state (finite; the training path turns nrec < 0 into a NaN loss)
+    // max_steps exhausted (or a grid the controller cannot walk): the outputs that were never reached are NaN, so every consumer --
+    // the scorer's loss with or without gradients (SVI.evaluate_loss has no backward kernel to look at nrec), a bare solve -- fails
+    // loudly instead of scoring a trajectory that was not integrated to the end
     for (; j < T; ++j)
-      if (own) xo[j * S + gs] = y;
+      if (own) xo[j * S + gs] = __builtin_nanf("");
   }
 }
 
@@ -880,8 +888,8 @@ hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, co
   k.max_steps = 20000;
   const int grid = (s.B + TPB - 1) / TPB;
   const size_t lds = sizeof(float) * ((size_t)GroupLds<25>::floats(TPB) + (size_t)TPB * s.L + (size_t)s.T);
-  if (s.H == 25 && s.S == 5) hipLaunchKernelGGL((dopri5_kernel<5, 25>), dim3(grid), dim3(DNT), lds, stream, k);
-  else if (s.H == 25 && s.S == 8) hipLaunchKernelGGL((dopri5_kernel<8, 25>), dim3(grid), dim3(DNT), lds, stream, k);
+  if (s.H == 25 && s.S == 5) SLODE_LAUNCH("dopri5_fwd", (dopri5_kernel<5, 25>), dim3(grid), dim3(DNT), lds, stream, k);
+  else if (s.H == 25 && s.S == 8) SLODE_LAUNCH("dopri5_fwd", (dopri5_kernel<8, 25>), dim3(grid), dim3(DNT), lds, stream, k);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -912,10 +920,10 @@ hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (s.H == 25 && s.S == 5) {
       (void)hipFuncSetAttribute((const void*)grp::dopri5_bwd_kernel<5, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((grp::dopri5_bwd_kernel<5, 25>), dim3(grid), dim3(BNT), lds, stream, k);
+      SLODE_LAUNCH("dopri5_bwd", (grp::dopri5_bwd_kernel<5, 25>), dim3(grid), dim3(BNT), lds, stream, k);
     } else if (s.H == 25 && s.S == 8) {
       (void)hipFuncSetAttribute((const void*)grp::dopri5_bwd_kernel<8, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL((grp::dopri5_bwd_kernel<8, 25>), dim3(grid), dim3(BNT), lds, stream, k);
+      SLODE_LAUNCH("dopri5_bwd", (grp::dopri5_bwd_kernel<8, 25>), dim3(grid), dim3(BNT), lds, stream, k);
     } else return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -562,7 +562,7 @@ FoldK make_foldk(const FoldLaunch& a) {
 
 int slode_fold_small_count(const slode_shape& s) { return s.Hc + 2 * (s.L * s.Hc + s.L); }
 
-hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream, hipEvent_t mid) {
+hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream) {
   FoldK k = make_foldk(a);
   const int nb_w = (k.Hc * k.CT + WPB - 1) / WPB, nb_r = (k.Hc + 3) / 4 + (k.sigtab ? (k.CT + 255) / 256 : 0);
   // dynamic LDS: conv taps + (when they fit) the lin.weight rows a block's WPB consecutive outputs can touch
@@ -572,22 +572,21 @@ hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream, hipEve
   const size_t wlds = sizeof(float) * (cw + (stage_rows ? max_rows * (size_t)k.FQ : 0));
   if (k.J <= 14) {
     if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)weff_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
-    hipLaunchKernelGGL((weff_kernel<14>), dim3(nb_w + nb_r), dim3(256), wlds, stream, k, stage_rows);
+    SLODE_LAUNCH("weff", (weff_kernel<14>), dim3(nb_w + nb_r), dim3(256), wlds, stream, k, stage_rows);
   } else {
     if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)weff_kernel<SLODE_MAX_K + SLODE_MAX_P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
-    hipLaunchKernelGGL((weff_kernel<SLODE_MAX_K + SLODE_MAX_P>), dim3(nb_w + nb_r), dim3(256), wlds, stream, k, stage_rows);
+    SLODE_LAUNCH("weff", (weff_kernel<SLODE_MAX_K + SLODE_MAX_P>), dim3(nb_w + nb_r), dim3(256), wlds, stream, k, stage_rows);
   }
-  if (mid) (void)hipEventRecord(mid, stream);
   const size_t lds = sizeof(float) * ((size_t)TBE * k.CT + TBE * 64 + 2 * (size_t)k.L * k.Hc + 64);
   (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(enc_fwd2_kernel, dim3((k.B + TBE - 1) / TBE), dim3(FNT), lds, stream, k);
+  SLODE_LAUNCH("enc_fwd2", enc_fwd2_kernel, dim3((k.B + TBE - 1) / TBE), dim3(FNT), lds, stream, k);
   return hipGetLastError();
 }
 
 hipError_t slode_launch_fold_bwd_heads(const FoldLaunch& a, hipStream_t stream) {
   FoldK k = make_foldk(a);
   const size_t lds = sizeof(float) * (2 * (size_t)TBE * 64 + 2 * (size_t)TBE * k.L + 2 * (size_t)k.L * k.Hc);
-  hipLaunchKernelGGL(enc_bwd2_kernel, dim3((k.B + TBE - 1) / TBE), dim3(256), lds, stream, k);
+  SLODE_LAUNCH("enc_bwd2", enc_bwd2_kernel, dim3((k.B + TBE - 1) / TBE), dim3(256), lds, stream, k);
   return hipGetLastError();
 }
 
@@ -602,7 +601,7 @@ hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream) {
 #define SLODE_CHAIN(CC, JJ)                                                                                          \
   do {                                                                                                               \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)enc_chain_kernel<CC, JJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((enc_chain_kernel<CC, JJ>), grid, dim3(CNT), lds, stream, k, tl, with_tail);                              \
+    SLODE_LAUNCH("enc_chain", (enc_chain_kernel<CC, JJ>), grid, dim3(CNT), lds, stream, k, tl, with_tail);                              \
   } while (0)
   if (k.C == 3 && JM == 14) SLODE_CHAIN(3, 14);
   else if (k.C == 4 && JM == 14) SLODE_CHAIN(4, 14);

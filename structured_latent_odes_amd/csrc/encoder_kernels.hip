@@ -542,7 +542,7 @@ hipError_t slode_launch_gemm_gpre_x(const float* g_pre, const float* x, float* s
   GemmProbs ps{};
   ps.p[0] = GemmProb{g_pre, 64, x, slabs, Hc, N, (N + 1 + 31) / 32};
   ps.n_gemm_x = ps.p[0].ntiles;
-  hipLaunchKernelGGL(enc_bwd_lin_kernel, dim3(ps.p[0].ntiles, splitk), dim3(256), 0, stream, ps, B, per_wave, 1);
+  SLODE_LAUNCH("enc_bwd_lin", enc_bwd_lin_kernel, dim3(ps.p[0].ntiles, splitk), dim3(256), 0, stream, ps, B, per_wave, 1);
   return hipGetLastError();
 }
 
@@ -567,7 +567,7 @@ hipError_t slode_launch_gemm_tail(const float* g_pre, const float* x, float* gsl
     rider_x = (ps.rider_bx * SLODE_REDUCE_GROUPS + splitk - 1) / splitk;
     *ode_part_out = ode_part; *ode_n_out = (ode_n + per - 1) / per;
   }
-  hipLaunchKernelGGL(enc_bwd_lin_kernel, dim3(ps.n_gemm_x + rider_x, splitk), dim3(256), 0, stream, ps, B, per_wave, 1);
+  SLODE_LAUNCH("enc_bwd_lin", enc_bwd_lin_kernel, dim3(ps.n_gemm_x + rider_x, splitk), dim3(256), 0, stream, ps, B, per_wave, 1);
   return hipGetLastError();
 }
 
@@ -589,17 +589,17 @@ hipError_t slode_launch_enc_fwd(const EncLaunch& a, hipStream_t stream) {
   const int grid = (a.s.B + TBE - 1) / TBE;
   if (a.s.C == 3 && a.s.K == 10) {
     (void)hipFuncSetAttribute((const void*)enc_fwd_kernel<3, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((enc_fwd_kernel<3, 10>), dim3(grid), dim3(ENC_NT), lds, stream, k);
+    SLODE_LAUNCH("enc_fwd", (enc_fwd_kernel<3, 10>), dim3(grid), dim3(ENC_NT), lds, stream, k);
   } else if (a.s.C == 4 && a.s.K == 10) {
     (void)hipFuncSetAttribute((const void*)enc_fwd_kernel<4, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((enc_fwd_kernel<4, 10>), dim3(grid), dim3(ENC_NT), lds, stream, k);
+    SLODE_LAUNCH("enc_fwd", (enc_fwd_kernel<4, 10>), dim3(grid), dim3(ENC_NT), lds, stream, k);
   } else {
     return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream, hipEvent_t mid) {
+hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream) {
   EncK k = make_enck(a.s, a.lay, a.params);
   k.obs = a.obs; k.sb = a.sb; k.sc = a.sc; k.st = a.st;
   k.scale_in = a.scale; k.pooled_in = a.pooled; k.hid_in = a.hid; k.g_loc = a.g_loc; k.g_scale = a.g_scale;
@@ -608,16 +608,15 @@ hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream, hipEv
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (a.s.C == 3 && a.s.K == 10) {
     (void)hipFuncSetAttribute((const void*)enc_bwd_kernel<3, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((enc_bwd_kernel<3, 10>), dim3(a.grid_small), dim3(ENC_NT_BWD), lds, stream, k);
+    SLODE_LAUNCH("enc_bwd", (enc_bwd_kernel<3, 10>), dim3(a.grid_small), dim3(ENC_NT_BWD), lds, stream, k);
   } else if (a.s.C == 4 && a.s.K == 10) {
     (void)hipFuncSetAttribute((const void*)enc_bwd_kernel<4, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((enc_bwd_kernel<4, 10>), dim3(a.grid_small), dim3(ENC_NT_BWD), lds, stream, k);
+    SLODE_LAUNCH("enc_bwd", (enc_bwd_kernel<4, 10>), dim3(a.grid_small), dim3(ENC_NT_BWD), lds, stream, k);
   } else {
     return hipErrorInvalidValue;
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (mid) (void)hipEventRecord(mid, stream);
   // lin.weight gradient (MFMA split-K); consumes g_pre written by the kernel above (same stream => ordered)
   const int total_splits = a.splitk * 4;
   int per_wave = (a.s.B + total_splits - 1) / total_splits;
@@ -625,6 +624,6 @@ hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream, hipEv
   GemmProbs ps{};
   ps.p[0] = GemmProb{a.g_pre, 64, a.pooled, a.slabs_lin, a.s.Hc, k.FQ, (k.FQ + 31) / 32};
   ps.n_gemm_x = ps.p[0].ntiles;
-  hipLaunchKernelGGL(enc_bwd_lin_kernel, dim3(ps.p[0].ntiles, a.splitk), dim3(256), 0, stream, ps, a.s.B, per_wave, 0);
+  SLODE_LAUNCH("enc_bwd_lin", enc_bwd_lin_kernel, dim3(ps.p[0].ntiles, a.splitk), dim3(256), 0, stream, ps, a.s.B, per_wave, 0);
   return hipGetLastError();
 }

@@ -236,7 +236,7 @@ hipError_t slode_launch_reduce(const ReduceLaunch& a_in, hipStream_t stream) {
   const int small_count = a.folded ? slode_fold_small_count(s) : slode_enc_small_count(s);
   stage1(1, a.small_slabs, a.small_stride, a.small_n, small_count, a.small_part);
   if (maxcount > 0)
-    hipLaunchKernelGGL(slab_stage1_kernel, dim3((maxcount + 63) / 64, SLODE_REDUCE_GROUPS, 2), dim3(256), 0, stream, fam[0], fam[1]);
+    SLODE_LAUNCH("slab_stage1", slab_stage1_kernel, dim3((maxcount + 63) / 64, SLODE_REDUCE_GROUPS, 2), dim3(256), 0, stream, fam[0], fam[1]);
   k.ode_slabs = a.ode_slabs; k.ode_stride = a.ode_stride; k.ode_n = a.ode_n;
   k.nseg = a.lay.ode_end - a.lay.ode_begin; k.ode_begin = a.lay.ode_begin;
   k.small_slabs = a.small_slabs; k.small_stride = a.small_stride; k.small_n = a.small_n;
@@ -253,7 +253,7 @@ hipError_t slode_launch_reduce(const ReduceLaunch& a_in, hipStream_t stream) {
     k.n_total = a.adam_n > a.lay.n_params ? (int)a.adam_n : a.lay.n_params;
     n = k.n_total;
   }
-  hipLaunchKernelGGL(reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, k);
+  SLODE_LAUNCH("reduce", reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, k);
   return hipGetLastError();
 }
 
@@ -275,7 +275,7 @@ hipError_t slode_launch_dynamics_eval(const slode_shape& s, const slode_layout& 
 }
 
 hipError_t slode_launch_adam_k(int64_t n, const float* g, const AdamHost& a, hipStream_t stream) {
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (long long)n, g, make_adamk(&a));
+  SLODE_LAUNCH("adam", adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (long long)n, g, make_adamk(&a));
   return hipGetLastError();
 }
 

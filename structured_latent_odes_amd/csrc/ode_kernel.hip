@@ -1672,7 +1672,7 @@ template <int S, int H, bool BWD, int T_, int C_, int L_, int Q_, int M_, bool R
 hipError_t launch_one(const OdeK& k, int grid, int nthreads, size_t lds, hipStream_t stream) {
   auto fn = ode_elbo_kernel<S, H, BWD, T_, C_, L_, Q_, M_, RA, ONE, ALG>;
   (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(nthreads), lds, stream, k);
+  SLODE_LAUNCH("ode_elbo", fn, dim3(grid), dim3(nthreads), lds, stream, k);
   return hipGetLastError();
 }
 

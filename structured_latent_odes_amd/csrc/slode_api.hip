@@ -8,6 +8,15 @@
 #include <stdlib.h>
 
 static thread_local char g_err[512] = "";
+thread_local ClockTable* g_slode_clock = nullptr;
+
+// scope of one profiled entry point: the kernels launched inside it fill the handle's clock table from slot 0
+struct ClockScope {
+  explicit ClockScope(slode_handle h, bool on) {
+    if (on && h->profile && h->ev_ready) { h->clk.n = 0; g_slode_clock = &h->clk; }
+  }
+  ~ClockScope() { g_slode_clock = nullptr; }
+};
 
 static int fail(slode_handle h, int code, const char* fmt, ...) {
   char* dst = h ? h->err : g_err;
@@ -87,7 +96,7 @@ int slode_create(slode_handle* out, int device_id) {
   c->device = device_id;
   c->num_cu = prop.multiProcessorCount;
   c->err[0] = 0;
-  c->profile = 0; c->ev_ready = 0; c->ev_valid = 0; c->repeat_ode = 0;
+  c->profile = 0; c->ev_ready = 0; c->clk.n = 0;
   c->adam_lo2 = c->adam_hi2 = 0; c->adam_delta2 = 0;
   // diagnostics and test hooks: the environment is read here, once per handle, never at launch time
   c->no_fold = getenv("SLODE_NO_FOLD") != nullptr;   // force the layer-by-layer encoder kernels
@@ -101,7 +110,7 @@ int slode_create(slode_handle* out, int device_id) {
 
 int slode_destroy(slode_handle h) {
   if (h && h->ev_ready)
-    for (int i = 0; i <= SLODE_PROFILE_SLOTS; ++i) (void)hipEventDestroy(h->ev[i]);
+    for (int i = 0; i < SLODE_CLOCK_MAX; ++i) { (void)hipEventDestroy(h->clk.ev[i][0]); (void)hipEventDestroy(h->clk.ev[i][1]); }
   delete h;
   return SLODE_OK;
 }
@@ -400,10 +409,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
   if (workspace_bytes < w.bytes) return fail(h, SLODE_ENOSPC, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
   hipStream_t st = (hipStream_t)stream;
   const bool bwd = grads != nullptr;
-  const bool prof = h->profile && h->ev_ready && bwd;
-  // profile == 1: events around every kernel; profile == 2 + s: only around slot s (two events: least perturbation of that kernel)
-#define SLODE_MARK(i) do { if (prof && (h->profile == 1 || (i) == h->profile - 2 || (i) == h->profile - 1)) (void)hipEventRecord(h->ev[i], st); } while (0)
-  SLODE_MARK(0);
+  ClockScope clock_scope(h, true);
 
   // Folded encoder (encoder_fused.hip) when every trajectory's C*T observations are one dense block; else layer by layer.
   const long long CT = (long long)s->C * s->T;
@@ -419,16 +425,14 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     fl.gslabs = w.gslabs; fl.n_gslabs = w.gsplit; fl.g_lin_w = grads ? grads + lay->lin_w : nullptr; fl.conv_slabs = w.conv_slabs;
     fl.counter = w.counter;
     fl.sigtab = aux_mode ? nullptr : w.sigtab;
-    e = slode_launch_fold_fwd(fl, st, prof ? h->ev[1] : nullptr);
+    e = slode_launch_fold_fwd(fl, st);
     HIP_TRY(h, e);
   } else {
     EncLaunch ef{*s, *lay, params, obs, obs_strides[0], obs_strides[1], obs_strides[2], w.loc, w.scale, w.pooled, w.hid};
     e = slode_launch_enc_fwd(ef, st);
     if (e == hipErrorInvalidValue) return fail(h, SLODE_EINVAL, "unsupported encoder shape C=%d K=%d T=%d", s->C, s->K, s->T);
     HIP_TRY(h, e);
-    SLODE_MARK(1);
   }
-  SLODE_MARK(2);
 
   int n_slabs = w.ode_grid;
   if (aux_mode) {
@@ -460,18 +464,15 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
         n_slabs = w.ode_grid + w.dp_rows;
       }
     }
-    for (int rep = 0; rep <= h->repeat_ode; ++rep) {   // repeat_ode > 0: measurement aid (the kernel is idempotent)
-      e = slode_launch_ode(a, st, h->err, sizeof(h->err));
-      if (e == hipErrorInvalidValue) return SLODE_EINVAL;
-      HIP_TRY(h, e);
-    }
+    e = slode_launch_ode(a, st, h->err, sizeof(h->err));
+    if (e == hipErrorInvalidValue) return SLODE_EINVAL;
+    HIP_TRY(h, e);
     if (dp5 && bwd) {
       DopriRec rc{w.loc, w.scale, eps, w.dp_z, w.dp_rec, w.dp_nrec, w.dp_kmax};
       HIP_TRY(h, slode_launch_dopri5_bwd(*s, *lay, params, times, rc, w.dp_gx, w.g_loc, w.g_scale, w.ode_slabs + (size_t)w.ode_grid * w.ode_stride,
                                          w.ode_stride, s->grad_mode == SLODE_GRAD_REFERENCE_ADJOINT ? 1 : 0, w.dp_snap, st));
     }
   }
-  SLODE_MARK(3);
 
   if (bwd && folded && !aux_mode && !dp5) {
     // Fused tail.  The ODE kernel has already run the encoder heads + tanh backward (g_pre, glat): three launches remain --
@@ -483,10 +484,8 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     }
     const float* ode_part = nullptr;
     int ode_pn = 0;
-    SLODE_MARK(4);
     HIP_TRY(h, slode_launch_gemm_tail(w.g_pre, obs, w.gslabs, s->Hc, (int)CT, w.glat, w.hid, w.gslabs2, w.gslabs3, s->L, s->B, w.gsplit,
                                       w.ode_slabs, w.ode_stride, n_slabs, (lay->ode_end - lay->ode_begin) + 1, w.ode_part, &ode_part, &ode_pn, st));
-    SLODE_MARK(5);
     TailK tl{};
     tl.gslabs = w.gslabs; tl.gslabs_loc = w.gslabs2; tl.gslabs_ls = w.gslabs3; tl.conv_slabs = w.conv_slabs;
     tl.ode_part = ode_part; tl.ode_stride = w.ode_stride; tl.ode_n = ode_pn; tl.loss_out = loss_out;
@@ -497,38 +496,26 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     tl.grads = grads; tl.ad = make_adamk(adam ? &ah : nullptr); tl.counter = w.counter;
     fl.tail = &tl;
     HIP_TRY(h, slode_launch_fold_chain(fl, st));   // + rider blocks and the last-block conv reduction: the flat gradient is complete
-    SLODE_MARK(6);
-    SLODE_MARK(7);
-    if (prof) h->ev_valid = 1;
   } else if (bwd && folded) {
     HIP_TRY(h, slode_launch_fold_bwd_heads(fl, st));
-    SLODE_MARK(4);
     HIP_TRY(h, slode_launch_gemm_gpre_x(w.g_pre, obs, w.gslabs, s->B, s->Hc, (int)CT, w.gsplit, st));
-    SLODE_MARK(5);
     HIP_TRY(h, slode_launch_fold_chain(fl, st));
-    SLODE_MARK(6);
     ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, n_slabs, w.small_slabs, w.small_stride, w.small_grid,
                    w.conv_slabs, s->Hc, grads, loss_out, 0, w.ode_part, w.small_part, 1};
     if (adam) { r.adam_p = adam->p; r.adam_m = adam->m; r.adam_v = adam->v; r.adam_lr = adam->lr; r.adam_b1 = adam->b1;
                 r.adam_b2 = adam->b2; r.adam_eps = adam->eps; r.adam_step = adam->step; r.adam_n = adam->n;
                 r.adam_lo2 = h->adam_lo2; r.adam_hi2 = h->adam_hi2; r.adam_delta2 = h->adam_delta2; }
     HIP_TRY(h, slode_launch_reduce(r, st));
-    SLODE_MARK(7);
-    if (prof) h->ev_valid = 1;
   } else if (bwd) {
     EncBwdLaunch eb{*s, *lay, params, obs, obs_strides[0], obs_strides[1], obs_strides[2], w.scale, w.pooled, w.hid,
                     w.g_loc, w.g_scale, w.g_pre, w.small_slabs, w.small_stride, w.small_grid, w.lin_slabs, w.lin_splitk};
-    HIP_TRY(h, slode_launch_enc_bwd(eb, st, prof ? h->ev[4] : nullptr));
-    SLODE_MARK(5);
-    SLODE_MARK(6);
+    HIP_TRY(h, slode_launch_enc_bwd(eb, st));
     ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, n_slabs, w.small_slabs, w.small_stride, w.small_grid,
                    w.lin_slabs, w.lin_splitk, grads, loss_out, 1, w.ode_part, w.small_part, 0};
     if (adam) { r.adam_p = adam->p; r.adam_m = adam->m; r.adam_v = adam->v; r.adam_lr = adam->lr; r.adam_b1 = adam->b1;
                 r.adam_b2 = adam->b2; r.adam_eps = adam->eps; r.adam_step = adam->step; r.adam_n = adam->n;
                 r.adam_lo2 = h->adam_lo2; r.adam_hi2 = h->adam_hi2; r.adam_delta2 = h->adam_delta2; }
     HIP_TRY(h, slode_launch_reduce(r, st));
-    SLODE_MARK(7);
-    if (prof) h->ev_valid = 1;
   } else {
     ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, n_slabs, nullptr, 0, 0, nullptr, 0, nullptr, loss_out, 0, w.ode_part, nullptr, 0};
     HIP_TRY(h, slode_launch_reduce(r, st));
@@ -623,31 +610,32 @@ int slode_adam_region(slode_handle h, int64_t lo, int64_t hi, int64_t step_delta
 
 int slode_profile_enable(slode_handle h, int on) {
   if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
+  if (on != 0 && on != 1) return fail(h, SLODE_EINVAL, "profile mode %d: 0 (off) or 1 (per-kernel timestamps)", on);
   if (on && !h->ev_ready) {
-    for (int i = 0; i <= SLODE_PROFILE_SLOTS; ++i) HIP_TRY(h, hipEventCreate(&h->ev[i]));
+    for (int i = 0; i < SLODE_CLOCK_MAX; ++i) {
+      HIP_TRY(h, hipEventCreate(&h->clk.ev[i][0]));
+      HIP_TRY(h, hipEventCreate(&h->clk.ev[i][1]));
+    }
     h->ev_ready = 1;
   }
-  if (on >= 16 && on < 32) {   // 16 + r: no events; the ode_elbo kernel is launched 1 + r times per step
-    h->repeat_ode = on - 16; h->profile = 0; h->ev_valid = 0;
-    return SLODE_OK;
-  }
-  if (on < 0 || on > 1 + SLODE_PROFILE_SLOTS) return fail(h, SLODE_EINVAL, "profile mode %d outside [0, %d]", on, 1 + SLODE_PROFILE_SLOTS);
-  h->repeat_ode = 0;
   h->profile = on;
-  h->ev_valid = 0;
+  h->clk.n = 0;
   return SLODE_OK;
 }
 
-int slode_profile_read(slode_handle h, float ms[SLODE_PROFILE_SLOTS]) {
-  if (!h || !ms) return fail(h, SLODE_EINVAL, "handle / ms is NULL");
-  if (!h->ev_valid) return fail(h, SLODE_EINVAL, "no profiled slode_elbo_step (with gradients) has been recorded");
-  if (h->profile == 0) return fail(h, SLODE_EINVAL, "profiling is off");
-  HIP_TRY(h, hipEventSynchronize(h->ev[h->profile == 1 ? SLODE_PROFILE_SLOTS : h->profile - 1]));
-  for (int i = 0; i < SLODE_PROFILE_SLOTS; ++i) {
-    ms[i] = 0.f;
-    if (h->profile == 1 || i == h->profile - 2) HIP_TRY(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+int slode_profile_read(slode_handle h, int max_kernels, const char** names, float* us) {
+  if (!h || !names || !us || max_kernels < 1) return fail(h, SLODE_EINVAL, "handle / names / us is NULL or max_kernels < 1");
+  if (!h->profile) return fail(h, SLODE_EINVAL, "profiling is off");
+  if (h->clk.n < 1) return fail(h, SLODE_EINVAL, "no profiled step has been recorded on this handle");
+  const int n = h->clk.n < max_kernels ? h->clk.n : max_kernels;
+  for (int i = 0; i < n; ++i) {
+    float ms = 0.f;
+    HIP_TRY(h, hipEventSynchronize(h->clk.ev[i][1]));
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->clk.ev[i][0], h->clk.ev[i][1]));
+    names[i] = h->clk.name[i];
+    us[i] = 1e3f * ms;
   }
-  return SLODE_OK;
+  return n;
 }
 
 int slode_adam_step(slode_handle h, int64_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float lr,
@@ -657,6 +645,7 @@ int slode_adam_step(slode_handle h, int64_t n, float* params, const float* grads
   if (n == 0) return SLODE_OK;
   AdamHost a{params, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, n};
   a.lo2 = h->adam_lo2; a.hi2 = h->adam_hi2; a.delta2 = h->adam_delta2;
+  ClockScope clock_scope(h, true);
   HIP_TRY(h, slode_launch_adam_k(n, grads, a, (hipStream_t)stream));
   return SLODE_OK;
 }

@@ -1,6 +1,7 @@
 // Shared declarations for libslode.so (gfx950 only).  Internal; the public ABI is include/slode.h.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <math.h>
 #include "../../include/slode.h"
@@ -16,18 +17,35 @@
 #define SLODE_MAX_P 8
 #define SLODE_MAX_HC 64
 
+// Measurement aid (slode_profile_enable): while a profiled entry point runs, every kernel it launches goes out through
+// hipExtLaunchKernelGGL with its OWN start / stop event pair -- the begin and end timestamps of that dispatch, i.e. the quantity
+// rocprofv3 --kernel-trace reports -- and no extra packet enters the stream.  One table per handle; the launching thread finds it
+// through a thread-local pointer that is non-null only inside that entry point.
+#define SLODE_CLOCK_MAX SLODE_PROFILE_MAX_KERNELS
+struct ClockTable { int n; const char* name[SLODE_CLOCK_MAX]; hipEvent_t ev[SLODE_CLOCK_MAX][2]; };
+extern thread_local ClockTable* g_slode_clock;
+#define SLODE_LAUNCH(NAME, fn, grid, block, lds, stream, ...)                                                                        \
+  do {                                                                                                                               \
+    ClockTable* ct_ = g_slode_clock;                                                                                                 \
+    if (ct_ && ct_->n < SLODE_CLOCK_MAX) {                                                                                           \
+      const int i_ = ct_->n++;                                                                                                       \
+      ct_->name[i_] = NAME;                                                                                                          \
+      hipExtLaunchKernelGGL(fn, grid, block, lds, stream, ct_->ev[i_][0], ct_->ev[i_][1], 0, __VA_ARGS__);                            \
+    } else {                                                                                                                         \
+      hipLaunchKernelGGL(fn, grid, block, lds, stream, __VA_ARGS__);                                                                 \
+    }                                                                                                                                \
+  } while (0)
+
 struct slode_ctx {
   int device;
   int num_cu;
   char err[512];
-  int profile;            // record per-kernel events in slode_elbo_step
-  hipEvent_t ev[SLODE_PROFILE_SLOTS + 1];
+  int profile;            // slode_profile_enable: kernels of the step entry points carry their own timestamps
+  ClockTable clk;
   int ev_ready;           // events created
-  int ev_valid;           // a profiled step has been recorded
   int no_fold;            // env SLODE_NO_FOLD: use the layer-by-layer encoder kernels inside slode_elbo_step
   int adam_lo2, adam_hi2; // slode_adam_region: elements with their own Adam step count = step + adam_delta2
   int64_t adam_delta2;
-  int repeat_ode;         // measurement aid: extra (idempotent) launches of the ode_elbo kernel per step (slode_profile_enable)
   // diagnostics / test hooks, read from the environment ONCE in slode_create (never at launch time):
   int ode_loop;           // SLODE_ODE_LOOP: persistent-loop grid even when every trajectory could have its own workgroup
   int ode_generic;        // SLODE_ODE_GENERIC: skip the shape-specialised instantiations
@@ -284,7 +302,7 @@ struct EncBwdLaunch {
   float* slabs_lin;    // [splitk][Hc*FQ] partial lin.weight gradients
   int splitk;
 };
-hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream, hipEvent_t mid = nullptr);
+hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream);
 int slode_enc_small_count(const slode_shape& s);   // floats per small slab
 int slode_enc_bwd_grid(const slode_shape& s);
 int slode_enc_lin_splitk(const slode_shape& s);
@@ -306,7 +324,7 @@ struct FoldLaunch {
   float* sigtab = nullptr;           // [4][C*T] likelihood-scale table of this step (see OdeLaunch::sigtab), written by extra fold blocks
   const TailK* tail = nullptr;       // chain launch also finishes the whole flat gradient (+ loss, + optional Adam)
 };
-hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream, hipEvent_t mid = nullptr);
+hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream);
 hipError_t slode_launch_fold_bwd_heads(const FoldLaunch& a, hipStream_t stream);
 hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream);
 hipError_t slode_launch_gemm_gpre_x(const float* g_pre, const float* x, float* slabs, int B, int Hc, int N, int splitk, hipStream_t stream);

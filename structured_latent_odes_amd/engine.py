@@ -74,7 +74,7 @@ def _check(lib, handle, rc):
         raise L.SlodeError("libslode call failed (%d): %s" % (rc, msg.decode() if msg else "?"))
 
 
-PROFILE_SLOT_NAMES = ("fold", "enc_fwd", "ode_elbo", "enc_bwd", "gemm", "chain", "reduce")   # include/slode.h, slode_profile_read
+PROFILE_MAX_KERNELS = 16   # include/slode.h, SLODE_PROFILE_MAX_KERNELS
 
 
 class Engine:
@@ -223,6 +223,10 @@ class Engine:
         d = times[1:] - times[:-1]
         if not (bool((d > 0).all()) or bool((d < 0).all())):    # torchdiffeq odeint's own precondition (misc._check_timelike)
             raise ValueError("t must be strictly increasing or decreasing")
+        if self.spec.solver == "dopri5" and not bool((d > 0).all()):
+            # torchdiffeq integrates a decreasing grid in s = -t; the adaptive kernels here only walk forward in time
+            # (dopri5_kernel.hip: dt > 0, outputs emitted while tj <= t1) and answer such a grid with NaN trajectories
+            raise ValueError("solver='dopri5' needs a strictly increasing time grid (decreasing grids: fixed-grid solvers only)")
         n = int(self.lib.slode_num_stage_times(C.byref(self.shape(1))))
         st = torch.empty(n, dtype=torch.float32, device=self.device)
         _check(self.lib, self.handle, self.lib.slode_stage_times(self.handle, C.byref(self.shape(1)), self._p(times), self._p(st), self._stream()))
@@ -380,20 +384,18 @@ class Engine:
             return 0, 0
         return int(lay.aux_w1[0]), int(lay.cstd)
 
-    def profile_enable(self, on, only: Optional[str] = None):
-        """on: record HIP events around every kernel of elbo_step; only=<slot name>: bracket just that kernel (least perturbation)."""
-        mode = 0 if not on else (1 if only is None else 2 + PROFILE_SLOT_NAMES.index(only))
-        _check(self.lib, self.handle, self.lib.slode_profile_enable(self.handle, mode))
+    def profile_enable(self, on: bool):
+        """Per-kernel device timestamps for the step entry points (include/slode.h, slode_profile_enable)."""
+        _check(self.lib, self.handle, self.lib.slode_profile_enable(self.handle, 1 if on else 0))
 
-    def repeat_ode_kernel(self, extra: int):
-        """Measurement aid: launch the (idempotent) ode_elbo kernel 1 + extra times per elbo_step (0 restores normal operation)."""
-        _check(self.lib, self.handle, self.lib.slode_profile_enable(self.handle, 16 + int(extra) if extra else 0))
-
-    def profile_read(self):
-        """Durations (ms) of the kernels of the last profiled elbo_step (include/slode.h, slode_profile_read)."""
-        ms = (C.c_float * 7)()
-        _check(self.lib, self.handle, self.lib.slode_profile_read(self.handle, ms))
-        return dict(zip(PROFILE_SLOT_NAMES, [float(v) for v in ms]))
+    def profile_read(self) -> List[Tuple[str, float]]:
+        """[(kernel name, microseconds)] of the last profiled step call on this engine, in launch order."""
+        names = (C.c_char_p * PROFILE_MAX_KERNELS)()
+        us = (C.c_float * PROFILE_MAX_KERNELS)()
+        n = self.lib.slode_profile_read(self.handle, PROFILE_MAX_KERNELS, names, us)
+        if n < 0:
+            _check(self.lib, self.handle, n)
+        return [(names[i].decode(), float(us[i])) for i in range(n)]
 
 
 def cvs_spec(z_iext=5, z_rtpr=5, z_eps=5, gauss=False, solver="midpoint", quantile_diff=0.475) -> ModelSpec:

@@ -31,17 +31,23 @@ def test_two_ranks_real_engine_match_single_process():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "dp.pt")
+        # each child writes to its own file: a rank that floods a pipe nobody drains would stall, and its peer would then wait in the
+        # collective until the timeout while holding the GPU
+        log_paths = [os.path.join(tmp, "rank%d.log" % r) for r in range(world)]
+        handles = [open(lp, "wb") for lp in log_paths]
         procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), str(world), port, str(steps), out],
-                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
-        logs = []
-        for p in procs:
-            try:
-                o, _ = p.communicate(timeout=280)
-            except subprocess.TimeoutExpired:
-                for q in procs:
-                    q.kill()                       # exactly the children this test started
-                raise
-            logs.append(o.decode(errors="replace")[-2000:])
+                                  env=env, stdout=handles[r], stderr=subprocess.STDOUT) for r in range(world)]
+        try:
+            for p in procs:
+                p.wait(timeout=280)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()                       # exactly the children this test started
+            raise
+        finally:
+            for h in handles:
+                h.close()
+        logs = [open(lp, "rb").read().decode(errors="replace")[-2000:] for lp in log_paths]
         assert all(p.returncode == 0 for p in procs), logs
         dp = torch.load(out)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

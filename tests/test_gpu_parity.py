@@ -312,6 +312,36 @@ def test_dopri5_forward_solution_level(fam):
         eng.ode_solve_bwd(eng.pack(p), z.to(dev), torch.zeros(B, T, S, device=dev), torch.zeros(eng.n_params, device=dev))
 
 
+def test_dopri5_rejects_grids_it_cannot_walk():
+    """The adaptive kernels integrate forward in time only.  torchdiffeq would take a decreasing grid (it integrates in -t); here
+    Engine.set_times raises for solver='dopri5', and a caller that reaches the C ABI with such a table anyway (or with a repeated
+    time) gets NaN trajectories and a NaN loss with AND without gradients -- never a finite number from an extrapolated dense output."""
+    from structured_latent_odes_amd import engine as E
+    dev = torch.device("cuda:0")
+    ospec, espec, T, B = O.cvs_spec(3, 3, 2, solver="dopri5"), E.cvs_spec(3, 3, 2, solver="dopri5"), 60, 20
+    p = O.init_params(ospec, T=T)
+    obs, u, eps, times = O.synthetic_batch(ospec, B, T)
+    eng = E.Engine(espec, T, dev)
+    with pytest.raises(ValueError, match="strictly increasing"):
+        eng.set_times(times.flip(0))
+    flat = eng.pack(p)
+    obs_d = obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)
+    loss, grads = torch.zeros(1, device=dev), torch.zeros(eng.n_params, device=dev)
+    eng.set_times(times)
+    eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss, None)
+    assert torch.isfinite(loss).all()
+    repeated = times.clone()
+    repeated[30] = repeated[29]
+    for bad in (times.flip(0).contiguous(), repeated):
+        eng._times = bad.to(dev)                               # what a bare C-ABI caller could pass
+        x = eng.ode_solve(flat, torch.zeros(B, ospec.latent_dim, device=dev))
+        assert torch.isnan(x[:, 1:]).all()
+        eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss, None)          # SVI.evaluate_loss: no backward kernel runs
+        assert torch.isnan(loss).all()
+        eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss, grads)
+        assert torch.isnan(loss).all()
+
+
 @pytest.mark.parametrize("fam,mode", [("cvs", "exact"), ("proc", "exact"), ("cvs", "reference_adjoint"), ("proc_c2", "exact"), ("cvs_odd", "exact")])
 def test_dopri5_elbo_step_solution_level(fam, mode):
     """ELBO step with the adaptive solver (BASELINE config[2]): forward solve with recorded steps, reverse mode over the records.
@@ -415,6 +445,54 @@ def test_dopri5_config2_full_size_properties():
         want = O.main_loss({k: v.double() for k, v in p.items()}, ospec, obs[sl].double(), u[sl].double(), eps[sl].double(), times.double())
     got, _ = run(sl)
     assert abs(got.item() - want.item()) / abs(want.item()) < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["exact", "reference_adjoint"])
+def test_config4_full_shard_properties(mode):
+    """BASELINE config[4] as written: mechanistic_challenge_Gauss, T=300, batch 2048 over 4 GPUs = a shard of B=512 per GPU, latent 15
+    (5,5,5), rk4.  The fp64 oracle cannot finish 512 x 300 in seconds, so the full shard is checked through size-independent
+    properties -- finite, bitwise repeatable, additive over halves (the loss is a plain sum over trajectories, training_challenge.py
+    divides afterwards) -- and 16 of its trajectories against the fp64 oracle: -ELBO 1e-5 relative, every gradient tensor 5e-4 norm-wise
+    (the bars of the small cases).  reference_adjoint = the config's own adjoint_solver=True gradients."""
+    from structured_latent_odes_amd import engine as E
+    dev = torch.device("cuda:0")
+    B, T = 512, 300
+    import dataclasses
+    ospec = dataclasses.replace(O.challenge_spec(gauss=True, solver="rk4"), grad_mode=mode)
+    espec = dataclasses.replace(E.challenge_spec(gauss=True, solver="rk4"), grad_mode=mode)
+    p = O.init_params(ospec, T=T)
+    g = torch.Generator().manual_seed(5)
+    p = {k: v + 0.05 * torch.randn(v.shape, generator=g) for k, v in p.items()}
+    obs, u, eps, times = O.synthetic_batch(ospec, B, T)
+    eng = E.Engine(espec, T, dev)
+    eng.set_times(times)
+    flat = eng.pack(p)
+    obs_d = obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)       # the challenge batches' native layout (training_challenge.py:31)
+    u_d, eps_d = u.to(dev), eps.to(dev)
+
+    def run(sl):
+        loss, grads = torch.zeros(1, device=dev), torch.full((eng.n_params,), float("nan"), device=dev)
+        eng.elbo_step(flat, obs_d[sl], u_d[sl].contiguous(), eps_d[sl].contiguous(), loss, grads)
+        return loss.clone(), grads.clone()
+    l_all, g_all = run(slice(0, B))
+    assert torch.isfinite(l_all).all() and torch.isfinite(g_all).all()
+    l_again, g_again = run(slice(0, B))
+    assert torch.equal(l_all, l_again) and torch.equal(g_all, g_again)
+    l_a, g_a = run(slice(0, B // 2))
+    l_b, g_b = run(slice(B // 2, B))
+    assert abs((l_a + l_b - l_all).item()) / abs(l_all.item()) < 1e-6
+    assert ((g_a + g_b - g_all).double().norm() / g_all.double().norm()).item() < 1e-5
+    sl = slice(200, 216)
+    p64 = {k: v.double() for k, v in p.items()}
+    want_loss, want = O.loss_and_grads(p64, ospec, obs[sl].double(), u[sl].double(), eps[sl].double(), times.double())
+    got_loss, got = run(sl)
+    assert abs(got_loss.item() - want_loss.item()) / abs(want_loss.item()) < 1e-5
+    for k, v in eng.unpack(got).items():
+        w = want[k].double()
+        if w.norm() == 0:
+            assert v.abs().max().item() == 0, k
+            continue
+        assert _rel(v, w) < 5e-4, (k, _rel(v, w))
 
 
 @pytest.mark.parametrize("layout", ["c_major", "strided"])

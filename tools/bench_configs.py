@@ -36,4 +36,4 @@ for name, fam, gauss, B, T, kw in CASES:
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     eng.profile_enable(True); svi.step_async(obs_d, eps=eps_d, u=u_d); pr = eng.profile_read(); eng.profile_enable(False)
     print(json.dumps({"config": name, "params": int(flat.numel()), "us_per_step": round(1e6 * dt / n, 1), "traj_per_s": round(B * n / dt),
-                      "kernel_us": {k: round(v * 1e3, 1) for k, v in pr.items()}}), flush=True)
+                      "kernel_us": {k: round(v, 1) for k, v in pr}}), flush=True)

@@ -11,7 +11,6 @@ gradients with interval skipping enabled and right ones with any diagnostic comp
 kernels listed in MFMA_KERNELS, whose AGPRs are matrix-core accumulators by design.  Reads the `-Rpass-analysis=kernel-resource-usage` remarks
 the Makefile saves next to every object (csrc/*.res).
 """
-import glob
 import os
 import re
 import sys
@@ -30,9 +29,16 @@ def kernels(path):
 
 def main():
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "structured_latent_odes_amd", "csrc")
-    files = sorted(glob.glob(os.path.join(root, "*.res")))
-    if not files:
-        sys.exit("check_spills: no csrc/*.res files (build with the Makefile first)")
+    # The Makefile passes the list it expects (one .res per source of libslode.so): a missing one fails the gate, a stale one left
+    # behind by a renamed source is not looked at.  Without arguments (the CPU test): the sources named by the Makefile's SRCS line.
+    names = sys.argv[1:]
+    if not names:
+        srcs = re.search(r"^SRCS\s*:=\s*(.+)$", open(os.path.join(root, "Makefile")).read(), re.M).group(1).split()
+        names = [s[:-4] + ".res" for s in srcs]
+    files = [os.path.join(root, n) for n in names]
+    missing = [n for n, f in zip(names, files) if not os.path.exists(f)]
+    if missing:
+        sys.exit("check_spills: no resource remarks for %s (build with the Makefile: each object is compiled together with its .res)" % ", ".join(missing))
     bad, n = [], 0
     for path in files:
         for name, vsp, ssp, vg, scratch, ag in kernels(path):

@@ -20,4 +20,4 @@ for blk in range(8):
     for _ in range(50): svi.step_async(obs_d, eps=eps_d, u=u_d)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     eng.profile_enable(True); svi.step_async(obs_d, eps=eps_d, u=u_d); pr = eng.profile_read(); eng.profile_enable(False)
-    print("block %d: %.1f us/step  loss/traj %.2f  kernels %s" % (blk, 1e6*(t1-t0)/50, svi.loss.item()/1024, {k: round(v*1e3,1) for k,v in pr.items()}))
+    print("block %d: %.1f us/step  loss/traj %.2f  kernels %s" % (blk, 1e6*(t1-t0)/50, svi.loss.item()/1024, {k: round(v,1) for k,v in pr}))
