@@ -2,192 +2,255 @@
 //   models/mechanistic_cvs.py:240-276, mechanistic_proc.py:313-359, mechanistic_challenge.py:264-297.
 // The group latents are sampled IN THE MODEL (the guide is empty), so with z_g = loc_g + scale_g * eps_g
 //   -ELBO_aux = - [ sum_{l in label groups} log N(z_l; loc_l, scale_l)  +  aux_mult * sum_heads log p(label_h | MLP_h(z_g)) ]
-// One workgroup handles one trajectory at a time (persistent loop); the label-head code is the same as phases P0/P7 of
-// ode_elbo_kernel.  Outputs dLoss/dloc, dLoss/dscale (fed to the encoder backward kernels) and a gradient slab in the layout of
-// the ODE segment (only the label-head entries are non-zero), reduced by the common fixed-order reduction.
+// One workgroup handles one trajectory at a time (a half-wave per label head).  Outputs dLoss/dloc, dLoss/dscale (or, on the folded
+// encoder path, directly g_pre / glat: the encoder-head backward runs here as it does inside ode_elbo_kernel) and one gradient slab
+// row per workgroup, reduced by the common fixed-order reduction.
 #include "slode_common.h"
 
 namespace {
 
 struct AuxK {
-  int B, L, nu, n_aux, U;
+  int B, L, nu, n_aux, U, Hc;
   float aux_mult;
   slode_aux aux[SLODE_MAX_AUX];
-  int o_w1[SLODE_MAX_AUX], o_b1[SLODE_MAX_AUX], o_w2[SLODE_MAX_AUX], o_b2[SLODE_MAX_AUX], o_c[SLODE_MAX_AUX];
-  int npar, nseg;
-  const float *pseg, *loc, *scale, *eps, *u;
+  const float *w1[SLODE_MAX_AUX], *b1[SLODE_MAX_AUX], *w2[SLODE_MAX_AUX], *b2[SLODE_MAX_AUX], *cc[SLODE_MAX_AUX];   // label-head parameters (global)
+  int o_w1[SLODE_MAX_AUX], o_b1[SLODE_MAX_AUX], o_w2[SLODE_MAX_AUX], o_b2[SLODE_MAX_AUX], o_c[SLODE_MAX_AUX];      // slab index of their gradients
+  int row_floats;     // floats of a slab row this kernel is responsible for (the rest of the row, if any, is zero-filled)
+  const float *loc, *scale, *eps, *u;
   float *g_loc, *g_scale, *slabs;
   int slab_stride, backward;
+  // fused encoder-head backward (folded encoder path): see ode_elbo_kernel
+  const float *enc_hid, *enc_zloc_w, *enc_zls_w;
+  float *g_pre, *glat;
 };
 
-constexpr int ANT = 128;
+constexpr int AUX_ZMAX = 16;   // latent dims of one label head (slode_api.hip: check_shape)
+constexpr int AUX_QMAX = 8;    // label columns of one head
 
-__global__ void __launch_bounds__(ANT) aux_kernel(const AuxK k) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, L = k.L;
-  float* s_par = smem;                         // [npar]
-  float* s_acc = s_par + ((k.npar + 3) & ~3);  // [npar + 1]
-  float* s_z = s_acc + ((k.npar + 4) & ~3);    // [L]
-  float* s_eps = s_z + SLODE_MAX_L;            // [L]
-  float* s_sc = s_eps + SLODE_MAX_L;           // [L]
-  float* s_gz = s_sc + SLODE_MAX_L;            // [L]
-  float* s_uu = s_gz + SLODE_MAX_L;            // [n_u]
-  float* s_h = s_uu + SLODE_MAX_NU;            // [n_aux][32]
-  float* s_d = s_h + SLODE_MAX_AUX * 32;       // [n_aux][32]
-  float* s_go = s_d + SLODE_MAX_AUX * 32;      // [n_aux][12]
-  float* s_red = s_go + SLODE_MAX_AUX * 12;    // [4]
-  for (int i = tid; i < k.npar; i += ANT) s_par[i] = k.pseg[i];
-  for (int i = tid; i < k.npar + 1; i += ANT) s_acc[i] = 0.f;
+// Half-wave (32 lanes) = one label head, lane j = hidden unit j; a workgroup = the n_aux heads of one trajectory at a time.  Everything a
+// head needs lives in its own 32 lanes: the sums over hidden units are xor-butterflies (offsets 16..1 stay inside the half-wave), the
+// head's latent sample goes through a few LDS words written and read by the same wave (in program order: no barrier), and every
+// gradient element has ONE owner lane that carries it in a register across the workgroup's trajectories -- the slab row is written
+// once, at the end.  The only workgroup barriers are the two around the encoder-head backward (it needs every head's latent gradient).
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(128) aux_kernel(const AuxK k) {
+  __shared__ float s_z[SLODE_MAX_AUX][AUX_ZMAX];
+  __shared__ float s_gl[SLODE_MAX_L], s_gs[SLODE_MAX_L];   // dLoss/dloc, dLoss/dscale * scale of the current trajectory
+  __shared__ float s_red[4];
+  const int tid = threadIdx.x, L = k.L, hd = tid >> 5, j = tid & 31, U = k.U;
+  const bool head_on = hd < k.n_aux;
+  const slode_aux ax = k.aux[head_on ? hd : 0];
+  const int zd = ax.z_dim, ud = ax.u_dim;
+  const bool unit_on = head_on && j < U;
+  // this lane's parameters (row j of the hidden layer, column j of the output layer): registers for the whole launch
+  float w1r[AUX_ZMAX], w2c[AUX_QMAX];
+  float b1v = 0.f;
+#pragma unroll
+  for (int l = 0; l < AUX_ZMAX; ++l) w1r[l] = (unit_on && l < zd) ? k.w1[hd][j * zd + min(l, zd - 1)] : 0.f;
+#pragma unroll
+  for (int q = 0; q < AUX_QMAX; ++q) w2c[q] = (unit_on && q < ud) ? k.w2[hd][min(q, ud - 1) * U + j] : 0.f;
+  if (unit_on) b1v = k.b1[hd][j];
+  float b2v = (head_on && j < ud) ? k.b2[hd][j] : 0.f;     // lane q holds b2[q]
+  const float cpar = (head_on && ax.kind == SLODE_AUX_EXPEXP) ? k.cc[hd][0] : 0.f;
+  // gradient accumulators of the elements this lane owns
+  float a_w1[AUX_ZMAX], a_w2[AUX_QMAX], a_b1 = 0.f, a_b2 = 0.f, a_c = 0.f;
+#pragma unroll
+  for (int l = 0; l < AUX_ZMAX; ++l) a_w1[l] = 0.f;
+#pragma unroll
+  for (int q = 0; q < AUX_QMAX; ++q) a_w2[q] = 0.f;
   float loss_acc = 0.f;
-  __syncthreads();
-  for (int b = blockIdx.x; b < k.B; b += gridDim.x) {
-    if (tid < L) {
-      const float loc = k.loc[(long long)b * L + tid], sc = k.scale[(long long)b * L + tid], e = k.eps[(long long)b * L + tid];
-      const float z = fmaf(sc, e, loc);
-      bool in_aux = false;
-      for (int hd = 0; hd < k.n_aux; ++hd) in_aux = in_aux || (tid >= k.aux[hd].z_off && tid < k.aux[hd].z_off + k.aux[hd].z_dim);
-      if (in_aux) {
-        const float zq = (z - loc) / sc;
-        loss_acc += logf(sc) + 0.91893853320467274178f + 0.5f * zq * zq;   // - log N(z; loc, scale)
-      }
-      s_z[tid] = z;
-      s_eps[tid] = in_aux ? e : 0.f;
-      s_sc[tid] = in_aux ? sc : 0.f;    // 0 marks "not a label-group dim"
-      s_gz[tid] = 0.f;
-    }
-    if (tid < k.nu) s_uu[tid] = k.u[(long long)b * k.nu + tid];
-    __syncthreads();
-    {  // hidden layer (Softplus), thread (head, j)
-      const int hd = tid >> 5, j = tid & 31;
-      if (hd < k.n_aux && j < k.U) {
-        const slode_aux ax = k.aux[hd];
-        float pre = s_par[k.o_b1[hd] + j];
-        for (int l = 0; l < ax.z_dim; ++l) pre = fmaf(s_par[k.o_w1[hd] + j * ax.z_dim + l], s_z[ax.z_off + l], pre);
-        s_h[hd * 32 + j] = softplusf(pre);
-        s_d[hd * 32 + j] = 1.f / (1.f + expf(-pre));
-      }
-    }
-    __syncthreads();
-    if (tid < k.n_aux) {  // outputs + log-prob, one thread per head (same arithmetic as ode_elbo_kernel P0c)
-      const int hd = tid;
-      const slode_aux ax = k.aux[hd];
-      const float* w2 = s_par + k.o_w2[hd];
-      const float* b2 = s_par + k.o_b2[hd];
-      const float* hv = s_h + hd * 32;
-      auto logit = [&](int q) {
-        float o = b2[q];
-        for (int j = 0; j < k.U; ++j) o = fmaf(w2[q * k.U + j], hv[j], o);
-        return o;
-      };
-      float lp = 0.f;
-      if (ax.kind == SLODE_AUX_SOFTMAX) {
-        float mx = -3.0e38f, ysum = 0.f, se = 0.f;
-        for (int q = 0; q < ax.u_dim; ++q) mx = fmaxf(mx, logit(q));
-        for (int q = 0; q < ax.u_dim; ++q) { se += expf(logit(q) - mx); ysum += s_uu[ax.u_off + q]; }
-        const float lse = mx + logf(se);
-        for (int q = 0; q < ax.u_dim; ++q) {
-          const float lq = logit(q) - lse, y = s_uu[ax.u_off + q];
-          lp = fmaf(y, lq, lp);
-          s_go[hd * 12 + q] = k.aux_mult * (expf(lq) * ysum - y);
-        }
-      } else if (ax.kind == SLODE_AUX_SIGMOID) {
-        for (int q = 0; q < ax.u_dim; ++q) {
-          const float o = logit(q), y = s_uu[ax.u_off + q];
-          const float sp_pos = (o > 0.f ? o : 0.f) + log1pf(expf(-fabsf(o)));
-          lp += y * (o - sp_pos) + (1.f - y) * (-sp_pos);
-          s_go[hd * 12 + q] = k.aux_mult * (1.f / (1.f + expf(-o)) - y);
-        }
-      } else {
-        const float c = s_par[k.o_c[hd]];
-        const float bsc = softplusf(c), ib = 1.f / bsc;
-        float gc = 0.f;
-        for (int q = 0; q < ax.u_dim; ++q) {
-          const float loc = expf(logit(q)), y = s_uu[ax.u_off + q];
-          const float r = y - loc, ar = fabsf(r);
-          lp += -logf(2.f * bsc) - ar * ib;
-          const float sg = (r > 0.f) ? 1.f : ((r < 0.f) ? -1.f : 0.f);
-          s_go[hd * 12 + q] = -k.aux_mult * sg * ib * loc;
-          gc += k.aux_mult * (ib - ar * ib * ib);
-        }
-        s_go[hd * 12 + 8] = gc / (1.f + expf(-c));
-      }
-      loss_acc -= k.aux_mult * lp;
-    }
-    if (k.backward) {
-      __syncthreads();
-      {
-        const int hd = tid >> 5, j = tid & 31;
-        if (hd < k.n_aux && j < k.U) {
-          const slode_aux ax = k.aux[hd];
-          float gh = 0.f;
-          for (int q = 0; q < ax.u_dim; ++q) gh = fmaf(s_par[k.o_w2[hd] + q * k.U + j], s_go[hd * 12 + q], gh);
-          s_d[hd * 32 + j] *= gh;
-        }
-      }
-      __syncthreads();
-      if (tid < L) {
-        const int l = tid;
-        float gz = 0.f;
-        for (int hd = 0; hd < k.n_aux; ++hd) {
-          const slode_aux ax = k.aux[hd];
-          if (l >= ax.z_off && l < ax.z_off + ax.z_dim)
-            for (int j = 0; j < k.U; ++j) gz = fmaf(s_par[k.o_w1[hd] + j * ax.z_dim + (l - ax.z_off)], s_d[hd * 32 + j], gz);
-        }
-        const float sc = s_sc[l];
-        k.g_loc[(long long)b * L + l] = gz;                                       // d(-log N)/dloc = 0 (z moves with loc)
-        k.g_scale[(long long)b * L + l] = (sc > 0.f) ? fmaf(gz, s_eps[l], 1.0f / sc) : 0.f;   // + d(log scale)/dscale
-      }
-      float* acc = s_acc + 1;
-      for (int hd = 0; hd < k.n_aux; ++hd) {
-        const slode_aux ax = k.aux[hd];
-        for (int e = tid; e < k.U * ax.z_dim; e += ANT) {
-          const int j = e / ax.z_dim, l = e - j * ax.z_dim;
-          acc[k.o_w1[hd] + e] += s_d[hd * 32 + j] * s_z[ax.z_off + l];
-        }
-        for (int e = tid; e < ax.u_dim * k.U; e += ANT) {
-          const int q = e / k.U, j = e - q * k.U;
-          acc[k.o_w2[hd] + e] += s_go[hd * 12 + q] * s_h[hd * 32 + j];
-        }
-        if (tid < k.U) acc[k.o_b1[hd] + tid] += s_d[hd * 32 + tid];
-        if (tid < ax.u_dim) acc[k.o_b2[hd] + tid] += s_go[hd * 12 + tid];
-        if (tid == 0 && ax.kind == SLODE_AUX_EXPEXP) acc[k.o_c[hd]] += s_go[hd * 12 + 8];
-      }
-    }
-    __syncthreads();
+  if (tid < L) { s_gl[tid] = 0.f; s_gs[tid] = 0.f; }   // latent dims outside every head keep a zero gradient
+  // encoder head weights of hidden unit mm = tid (fused encoder-head backward): in registers from the start when the latent is short
+  constexpr int ZW = 16;
+  const bool zw_regs = k.g_pre != nullptr && L <= ZW;
+  float zw0[ZW], zw1[ZW];
+#pragma unroll
+  for (int l = 0; l < ZW; ++l) {
+    const bool on = zw_regs && tid < k.Hc && l < L;
+    zw0[l] = on ? k.enc_zloc_w[min(l, L - 1) * k.Hc + min(tid, k.Hc - 1)] : 0.f;
+    zw1[l] = on ? k.enc_zls_w[min(l, L - 1) * k.Hc + min(tid, k.Hc - 1)] : 0.f;
   }
-  // fixed-order workgroup sum of the loss, then the slab (zeros outside the label-head entries)
-  float v = wave_sum(loss_acc);
+  __syncthreads();
+
+  for (int b = blockIdx.x; b < k.B; b += gridDim.x) {
+    // ---- the head's latent sample z_g = loc + scale * eps (lane l' < z_dim), -log N(z_g; loc, scale) ----
+    float sc = 1.f, e = 0.f;
+    if (head_on && j < zd) {
+      const long long i = (long long)b * L + ax.z_off + j;
+      const float loc = k.loc[i];
+      sc = k.scale[i]; e = k.eps[i];
+      const float z = fmaf(sc, e, loc);
+      const float zq = (z - loc) / sc;
+      loss_acc += logf(sc) + 0.91893853320467274178f + 0.5f * zq * zq;
+      s_z[hd][j] = z;
+    }
+    float yv = (head_on && j < ud) ? k.u[(long long)b * k.nu + ax.u_off + j] : 0.f;   // lane q holds label column q
+    const float enc_hv = (k.g_pre != nullptr && k.backward && tid < k.Hc) ? k.enc_hid[(long long)b * k.Hc + tid] : 0.f;   // in flight until the end
+    // ---- hidden layer (Softplus) ----
+    float pre = b1v;
+#pragma unroll
+    for (int l = 0; l < AUX_ZMAX; ++l)
+      if (l < zd) pre = fmaf(w1r[l], s_z[hd][l], pre);
+    const float hv = unit_on ? softplusf(pre) : 0.f;
+    float dv = unit_on ? 1.f / (1.f + expf(-pre)) : 0.f;   // softplus'
+    // ---- output layer: logit[q] on every lane of the head ----
+    float lg[AUX_QMAX];
+#pragma unroll
+    for (int q = 0; q < AUX_QMAX; ++q) {
+      lg[q] = 0.f;
+      if (q < ud) lg[q] = half_sum(w2c[q] * hv) + __shfl(b2v, (tid & 32) + q, 64);   // (uniform per half-wave: ud belongs to the head)
+    }
+    // ---- log p(label | head) and dLoss/dlogit (go[q], every lane computes the head's few outputs: no divergence, no exchange) ----
+    float go[AUX_QMAX], lp = 0.f, gcst = 0.f;
+    float ys[AUX_QMAX];
+#pragma unroll
+    for (int q = 0; q < AUX_QMAX; ++q) { go[q] = 0.f; ys[q] = __shfl(yv, (tid & 32) + q, 64); }
+    if (ax.kind == SLODE_AUX_SOFTMAX) {
+      float mx = -3.0e38f, ysum = 0.f, se = 0.f;
+#pragma unroll
+      for (int q = 0; q < AUX_QMAX; ++q) if (q < ud) mx = fmaxf(mx, lg[q]);
+#pragma unroll
+      for (int q = 0; q < AUX_QMAX; ++q) if (q < ud) { se += expf(lg[q] - mx); ysum += ys[q]; }
+      const float lse = mx + logf(se);
+#pragma unroll
+      for (int q = 0; q < AUX_QMAX; ++q) if (q < ud) {
+        const float lq = lg[q] - lse;
+        lp = fmaf(ys[q], lq, lp);
+        go[q] = k.aux_mult * (expf(lq) * ysum - ys[q]);
+      }
+    } else if (ax.kind == SLODE_AUX_SIGMOID) {
+#pragma unroll
+      for (int q = 0; q < AUX_QMAX; ++q) if (q < ud) {
+        const float o = lg[q], y = ys[q];
+        const float sp_pos = (o > 0.f ? o : 0.f) + log1pf(expf(-fabsf(o)));   // softplus(o), stable
+        lp += y * (o - sp_pos) + (1.f - y) * (-sp_pos);
+        go[q] = k.aux_mult * (1.f / (1.f + expf(-o)) - y);
+      }
+    } else {   // EXPEXP: Laplace(loc = exp(head 0), b = softplus(constant_std_*)); the second Exp head is unused
+      const float bsc = softplusf(cpar), ib = 1.f / bsc;
+#pragma unroll
+      for (int q = 0; q < AUX_QMAX; ++q) if (q < ud) {
+        const float lc = expf(lg[q]), r = ys[q] - lc, ar = fabsf(r);
+        lp += -logf(2.f * bsc) - ar * ib;
+        const float sg = (r > 0.f) ? 1.f : ((r < 0.f) ? -1.f : 0.f);
+        go[q] = -k.aux_mult * sg * ib * lc;
+        gcst += k.aux_mult * (ib - ar * ib * ib);
+      }
+      gcst = gcst / (1.f + expf(-cpar));
+    }
+    if (head_on && j == 0) loss_acc -= k.aux_mult * lp;
+    if (k.backward) {
+      // ---- back through the output layer and the Softplus; the lane's own gradient elements ----
+      float gh = 0.f;
+#pragma unroll
+      for (int q = 0; q < AUX_QMAX; ++q) if (q < ud) { gh = fmaf(w2c[q], go[q], gh); a_w2[q] = fmaf(go[q], hv, a_w2[q]); }
+      dv *= gh;                                   // dLoss/d(hidden pre-activation)
+      a_b1 += dv;
+#pragma unroll
+      for (int l = 0; l < AUX_ZMAX; ++l) if (l < zd) a_w1[l] = fmaf(dv, s_z[hd][l], a_w1[l]);
+      if (j < ud) {   // lane q owns b2[q]
+        float gq = 0.f;
+#pragma unroll
+        for (int q = 0; q < AUX_QMAX; ++q) gq = (j == q) ? go[q] : gq;
+        a_b2 += gq;
+      }
+      if (j == 0) a_c += gcst;
+      // ---- latent gradient of the head's dims: sum over hidden units, lane l' < z_dim keeps dLoss/dz_l' ----
+      float gz = 0.f;
+#pragma unroll
+      for (int l = 0; l < AUX_ZMAX; ++l)
+        if (l < zd) { const float t = half_sum(w1r[l] * dv); gz = (j == l) ? t : gz; }
+      if (head_on && j < zd) {
+        const int l = ax.z_off + j;
+        const float gsc = fmaf(gz, e, 1.0f / sc);               // d(-log N)/dloc = 0 (z moves with loc); + d(log scale)/dscale
+        if (k.g_loc) { k.g_loc[(long long)b * L + l] = gz; k.g_scale[(long long)b * L + l] = gsc; }
+        s_gl[l] = gz; s_gs[l] = gsc * sc;
+      }
+      if (k.g_loc && tid < L) {   // dims outside every head
+        bool in = false;
+        for (int h2 = 0; h2 < k.n_aux; ++h2) in = in || (tid >= k.aux[h2].z_off && tid < k.aux[h2].z_off + k.aux[h2].z_dim);
+        if (!in) { k.g_loc[(long long)b * L + tid] = 0.f; k.g_scale[(long long)b * L + tid] = 0.f; }
+      }
+      if (k.g_pre) {
+        // encoder heads + tanh, backward (models/encoder_conv.py:48-51): thread <-> hidden unit of the encoder
+        __syncthreads();
+        if (tid < L) { k.glat[(long long)b * 128 + tid] = s_gl[tid]; k.glat[(long long)b * 128 + 64 + tid] = s_gs[tid]; }
+        if (zw_regs) {
+          if (tid < k.Hc) {
+            float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+            for (int l = 0; l < ZW; ++l)
+              if (l < L) { g0 = fmaf(zw0[l], s_gl[l], g0); g1 = fmaf(zw1[l], s_gs[l], g1); }
+            k.g_pre[(long long)b * 64 + tid] = (g0 + g1) * (1.f - enc_hv * enc_hv);
+          }
+        } else {
+          for (int mm = tid; mm < k.Hc; mm += blockDim.x) {
+            const float hvv = k.enc_hid[(long long)b * k.Hc + mm];
+            float g0 = 0.f, g1 = 0.f;
+#pragma unroll 4
+            for (int l = 0; l < L; ++l) {
+              g0 = fmaf(k.enc_zloc_w[l * k.Hc + mm], s_gl[l], g0);
+              g1 = fmaf(k.enc_zls_w[l * k.Hc + mm], s_gs[l], g1);
+            }
+            k.g_pre[(long long)b * 64 + mm] = (g0 + g1) * (1.f - hvv * hvv);
+          }
+        }
+        __syncthreads();   // s_gl / s_gs are rewritten by the next trajectory
+      }
+    }
+  }
+  // ---- fixed-order workgroup sum of the loss; the slab row: [loss | label-head gradients], zeros elsewhere ----
+  const float v = wave_sum(loss_acc);
   if ((tid & 63) == 0) s_red[tid >> 6] = v;
   __syncthreads();
   float* slab = k.slabs + (long long)blockIdx.x * k.slab_stride;
-  if (tid == 0) s_acc[0] = s_red[0] + s_red[1];
-  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < ((int)blockDim.x >> 6); ++w) t += s_red[w];
+    slab[0] = t;
+  }
   if (k.backward) {
-    for (int i = tid; i < k.nseg + 1; i += ANT) slab[i] = (i < k.npar + 1) ? s_acc[i] : 0.f;
-  } else if (tid == 0) {
-    slab[0] = s_acc[0];
+    for (int i = 1 + tid; i < k.row_floats; i += blockDim.x) slab[i] = 0.f;   // entries no head owns (e.g. the unused second Exp head)
+    __syncthreads();                                                            // (same workgroup: the owners' stores below come later)
+    if (unit_on) {
+#pragma unroll
+      for (int l = 0; l < AUX_ZMAX; ++l) if (l < zd) slab[1 + k.o_w1[hd] + j * zd + l] = a_w1[l];
+#pragma unroll
+      for (int q = 0; q < AUX_QMAX; ++q) if (q < ud) slab[1 + k.o_w2[hd] + q * U + j] = a_w2[q];
+      slab[1 + k.o_b1[hd] + j] = a_b1;
+    }
+    if (head_on && j < ud) slab[1 + k.o_b2[hd] + j] = a_b2;
+    if (head_on && j == 0 && ax.kind == SLODE_AUX_EXPEXP) slab[1 + k.o_c[hd]] = a_c;
   }
 }
 
 }  // namespace
 
+// compact != 0: the slab row is [loss | gradients of the flat range [aux_lo, aux_hi)] (the fused tail reduces only that range);
+// else the row has the layout of the whole ODE segment, zero outside the label heads (slode_launch_reduce).
 hipError_t slode_launch_aux(const AuxLaunch& a, hipStream_t stream) {
   const slode_shape& s = a.s;
   const slode_layout& lay = a.lay;
   AuxK k{};
-  k.B = s.B; k.L = s.L; k.nu = s.n_u; k.n_aux = s.n_aux; k.U = s.U; k.aux_mult = s.aux_mult;
-  const int ob = lay.ode_begin;
+  k.B = s.B; k.L = s.L; k.nu = s.n_u; k.n_aux = s.n_aux; k.U = s.U; k.aux_mult = s.aux_mult; k.Hc = s.Hc;
+  const int base = a.compact ? lay.aux_w1[0] : lay.ode_begin;
   for (int q = 0; q < SLODE_MAX_AUX; ++q) {
     k.aux[q] = s.aux[q];
-    k.o_w1[q] = lay.aux_w1[q] - ob; k.o_b1[q] = lay.aux_b1[q] - ob; k.o_w2[q] = lay.aux_w2[q] - ob;
-    k.o_b2[q] = lay.aux_b2[q] - ob; k.o_c[q] = lay.aux_c[q] - ob;
+    k.w1[q] = a.params + lay.aux_w1[q]; k.b1[q] = a.params + lay.aux_b1[q]; k.w2[q] = a.params + lay.aux_w2[q];
+    k.b2[q] = a.params + lay.aux_b2[q]; k.cc[q] = a.params + lay.aux_c[q];
+    k.o_w1[q] = lay.aux_w1[q] - base; k.o_b1[q] = lay.aux_b1[q] - base; k.o_w2[q] = lay.aux_w2[q] - base;
+    k.o_b2[q] = lay.aux_b2[q] - base; k.o_c[q] = lay.aux_c[q] - base;
   }
-  k.npar = lay.cstd - ob; k.nseg = lay.ode_end - ob;
-  k.pseg = a.params + ob; k.loc = a.loc; k.scale = a.scale; k.eps = a.eps; k.u = a.u;
+  k.row_floats = 1 + (a.compact ? lay.cstd - lay.aux_w1[0] : lay.ode_end - lay.ode_begin);
+  k.loc = a.loc; k.scale = a.scale; k.eps = a.eps; k.u = a.u;
   k.g_loc = a.g_loc; k.g_scale = a.g_scale; k.slabs = a.slabs; k.slab_stride = a.slab_stride; k.backward = a.backward;
-  const size_t lds = sizeof(float) * (2 * (size_t)((k.npar + 4) & ~3) + 4 * SLODE_MAX_L + SLODE_MAX_NU + 2 * SLODE_MAX_AUX * 32 +
-                                      SLODE_MAX_AUX * 12 + 8);
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)aux_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  SLODE_LAUNCH("aux", aux_kernel, dim3(a.grid), dim3(ANT), lds, stream, k);
+  k.enc_hid = a.enc_hid; k.enc_zloc_w = a.params + lay.zloc_w; k.enc_zls_w = a.params + lay.zls_w; k.g_pre = a.g_pre; k.glat = a.glat;
+  const int nthreads = s.n_aux <= 2 ? 64 : 128;
+  SLODE_LAUNCH("aux", aux_kernel, dim3(a.grid), dim3(nthreads), 0, stream, k);
   return hipGetLastError();
 }

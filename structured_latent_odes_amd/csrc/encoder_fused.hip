@@ -56,7 +56,9 @@ __device__ __forceinline__ int kappa_of(const FoldK& k, int c, int t) { return k
 // ---- fold: W_eff, rowsum, b_eff, w' ---------------------------------------------------------------------------------
 constexpr int WPB = 128;   // W_eff outputs per 256-thread block of weff_kernel
 template <int JM>  // compile-time bound on J = K + P - 1 (14 for every reference config)
-__global__ void __launch_bounds__(256) weff_kernel(const FoldK k, const int stage_rows) {
+// (pl_*: the pointers of the kernel's first loads as leading arguments -- preloaded into SGPRs at wave launch, see ode_elbo_kernel)
+__global__ void __launch_bounds__(256) weff_kernel(const float* __restrict__ pl_conv_w, const float* __restrict__ pl_lin_w, const FoldK k,
+                                                   const int stage_rows) {
   __shared__ float s_wp[SLODE_MAX_F * SLODE_MAX_C * JM];
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [F*C*K conv taps][stage_rows ? the block's lin.weight rows : 0]
   const int tid = threadIdx.x, J = k.J, C = k.C, K = k.K;
@@ -70,10 +72,10 @@ __global__ void __launch_bounds__(256) weff_kernel(const FoldK k, const int stag
   // Everything this block reads from global memory is fetched in ONE batch: the conv taps, and (W_eff blocks) the lin.weight rows
   // of the hidden units its WPB outputs belong to (2 for C*T >= WPB) -- coalesced, instead of F*JM = 140 strided loads per thread.
   const int e_first = (int)blockIdx.x * WPB, m0 = min(e_first, n_w - 1) / k.CT, m1 = min(e_first + WPB - 1, n_w - 1) / k.CT;
-  for (int i = tid; i < k.F * C * K; i += 256) s_cw[i] = k.conv_w[i];
+  for (int i = tid; i < k.F * C * K; i += 256) s_cw[i] = pl_conv_w[i];
   if (stage_rows && (int)blockIdx.x < nb_w) {
     const int n_st = (m1 - m0 + 1) * k.FQ;
-    const float* src = k.lin_w + (long long)m0 * k.FQ;
+    const float* src = pl_lin_w + (long long)m0 * k.FQ;
     for (int i0 = tid; i0 < n_st; i0 += 16 * 256) {
       float v[16];
 #pragma unroll
@@ -164,7 +166,8 @@ __global__ void __launch_bounds__(256) weff_kernel(const FoldK k, const int stag
 }
 
 // ---- forward: hid = tanh(W_eff x + b_eff), heads --------------------------------------------------------------------
-__global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const FoldK k) {
+__global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__ pl_x, const float* __restrict__ pl_zloc_w, const float* __restrict__ pl_zls_w,
+                                                       const float* __restrict__ pl_beff, const float* __restrict__ pl_weff, const FoldK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, NT = blockDim.x, CT = k.CT, Hc = k.Hc, L = k.L;
   float* s_x = smem;                 // [TBE][CT]   raw rows in memory order (= kappa order)
@@ -175,10 +178,10 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const FoldK k) {
   STAMP(8);
   for (int e = tid; e < TBE * CT; e += NT) {
     const int tb = e / CT;
-    s_x[e] = k.x[(long long)min(b0 + tb, k.B - 1) * CT + (e - tb * CT)];
+    s_x[e] = pl_x[(long long)min(b0 + tb, k.B - 1) * CT + (e - tb * CT)];
   }
-  for (int e = tid; e < 2 * L * Hc; e += NT) s_hw[e] = (e < L * Hc) ? k.zloc_w[e] : k.zls_w[e - L * Hc];
-  if (tid < Hc) s_be[tid] = k.beff[tid];
+  for (int e = tid; e < 2 * L * Hc; e += NT) s_hw[e] = (e < L * Hc) ? pl_zloc_w[e] : pl_zls_w[e - L * Hc];
+  if (tid < Hc) s_be[tid] = pl_beff[tid];
   __syncthreads();
   STAMP(9);
   {
@@ -193,7 +196,7 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const FoldK k) {
         for (int tb = 0; tb < TBE; ++tb) acc[r * TBE + tb] = 0.f;
       const float* wrow[RB];
 #pragma unroll
-      for (int r = 0; r < RB; ++r) wrow[r] = k.weff + (long long)min(m0 + r, Hc - 1) * CT;
+      for (int r = 0; r < RB; ++r) wrow[r] = pl_weff + (long long)min(m0 + r, Hc - 1) * CT;
       // CT is even for C*T of every supported config; odd CT falls back to scalar columns
       if ((CT & 1) == 0) {
         for (int i0 = 2 * lane; i0 < CT; i0 += 128 * IU) {
@@ -339,7 +342,8 @@ constexpr int QCH = 16;   // q-chunks for the w' partial sums
 // that does not depend on this kernel (ODE half, lin.bias, head layers, loss), the chain blocks apply Adam to their own lin.weight row,
 // and the LAST chain block to arrive (agent-scope release / counter / acquire) sums the Hc conv rows.  Fixed order => reproducible.
 template <int C, int JM>
-__global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const TailK tl, const int with_tail) {
+__global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict__ pl_gslabs, const float* __restrict__ pl_lin_w, const float* __restrict__ pl_wprime,
+                                                        const FoldK k, const TailK tl, const int with_tail) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, NT = blockDim.x, m = blockIdx.x;
   if (m >= k.Hc) {   // rider block
@@ -357,15 +361,13 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const Tai
   float* s_pm = s_wp + F * C * JM;            // [QCH][F][C][JM] partial dLoss/dw'
   float* s_glw = s_pm + QCH * F * C * JM;     // [FQ] this row's lin.weight gradient (for the fused Adam pass)
   STAMP(16);
-  for (int i = tid; i < GN; i += NT) {
-    float a = 0.f;
-    for (int s = 0; s < k.n_gslabs; ++s) a += k.gslabs[((long long)s * k.Hc + m) * GN + i];   // fixed order
-    s_G[i] = a;
-  }
-  for (int i = tid; i < FQ; i += NT) s_wl[i] = k.lin_w[(long long)m * FQ + i];
+  // split-K partials of row m: all of a column's loads in flight at once (a loop of load-then-add costs one L2 / HBM round trip per
+  // partial: the GEMM launch wrote them from other CUs; measured: staging 3.2 -> 2.0 us), summed in fixed order
+  for (int i = tid; i < GN; i += NT) s_G[i] = strided_sum(pl_gslabs + (long long)m * GN + i, k.Hc * GN, k.n_gslabs);
+  for (int i = tid; i < FQ; i += NT) s_wl[i] = pl_lin_w[(long long)m * FQ + i];
   for (int i = tid; i < F * C * JM; i += NT) {
     const int j = i % JM, fc = i / JM;
-    s_wp[i] = (j < J) ? k.wprime[fc * J + min(j, J - 1)] : 0.f;
+    s_wp[i] = (j < J) ? pl_wprime[fc * J + min(j, J - 1)] : 0.f;
   }
   __syncthreads();
   STAMP(17);
@@ -429,9 +431,12 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const Tai
     const int kk = e % K, fc = e / K;
     float s = 0.f;
     for (int p = 0; p < k.P; ++p) {
+      float pv[QCH];
+#pragma unroll
+      for (int ch = 0; ch < QCH; ++ch) pv[ch] = s_pm[(ch * F * C + fc) * JM + kk + p];   // the q-chunks' partials: one batch of LDS reads
       float v = 0.f;
 #pragma unroll
-      for (int ch = 0; ch < QCH; ++ch) v += s_pm[(ch * F * C + fc) * JM + kk + p];
+      for (int ch = 0; ch < QCH; ++ch) v += pv[ch];
       s += v;
     }
     if (with_tail) __hip_atomic_store(row + e, s / fP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the last block
@@ -473,7 +478,27 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const Tai
       }
     }
     STAMP(21);
-    if (tl.ad.p != nullptr) {   // meanwhile: Adam on this block's lin.weight row (its weights live in s_wl), two elements in flight
+    __syncthreads();
+    const bool last = s_last != 0;
+    if (last) STAMP_ANY(24);
+    // the last block to arrive is the one every other block's work waits behind: its loads of the Hc conv rows (4 lanes per element, each
+    // summing every 4th row in fixed order; 2 x 16 sc1 loads in flight per lane) go out now and fly during its own row's Adam pass
+    constexpr int NRV = 16;
+    constexpr bool EARLY_ROWS = C * JM <= 42;   // (register budget of the 1024-thread block)
+    float rv[NCI][NRV];
+    const int part = tid & 3, nrow = (k.Hc - part + 3) / 4;
+    const bool conv_regs = EARLY_ROWS && last && fast_conv && nrow <= NRV;
+    if (EARLY_ROWS && conv_regs) {
+#pragma unroll
+      for (int u = 0; u < NCI; ++u) {
+        const int ci = min((tid >> 2) + u * (CNT / 4), tl.lin_w - 1);
+        const float* src = tl.conv_slabs + (long long)part * tl.n_cv + (ci - tl.conv_w);
+#pragma unroll
+        for (int q = 0; q < NRV; ++q)
+          rv[u][q] = __hip_atomic_load(src + (long long)min(q, nrow - 1) * 4 * tl.n_cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (tl.ad.p != nullptr) {   // Adam on this block's lin.weight row (its weights live in s_wl), two elements in flight
       for (int e0 = tid; e0 < FQ; e0 += 2 * NT) {
         const int e1 = min(e0 + NT, FQ - 1), i0 = tl.lin_w + m * FQ + e0, i1 = tl.lin_w + m * FQ + e1;
         const float g0 = s_glw[e0], g1 = s_glw[e1];
@@ -493,16 +518,21 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const Tai
       }
     }
     STAMP(22);
-    __syncthreads();
-    STAMP(23);
-    if (s_last) STAMP_ANY(24);
-    if (s_last && fast_conv) {   // conv.weight, conv.bias: 4 lanes per element, each summing every 4th row (fixed order)
-      const int part = tid & 3, nrow = (k.Hc - part + 3) / 4;
+    if (last && fast_conv) {   // conv.weight, conv.bias
 #pragma unroll
       for (int u = 0; u < NCI; ++u) {
         const int ci = min((tid >> 2) + u * (CNT / 4), tl.lin_w - 1);
         const float* src = tl.conv_slabs + (long long)part * tl.n_cv + (ci - tl.conv_w);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (EARLY_ROWS && conv_regs) {
+#pragma unroll
+          for (int q = 0; q < NRV; q += 4) {
+            a0 += (q < nrow) ? rv[u][q] : 0.f;
+            a1 += (q + 1 < nrow) ? rv[u][q + 1] : 0.f;
+            a2 += (q + 2 < nrow) ? rv[u][q + 2] : 0.f;
+            a3 += (q + 3 < nrow) ? rv[u][q + 3] : 0.f;
+          }
+        } else
         for (int w = 0; w < nrow; w += 16) {
           float v[16];
 #pragma unroll
@@ -530,10 +560,10 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const FoldK k, const Tai
           }
         }
       }
-    } else if (s_last) {   // more conv taps than that: generic loop
+    } else if (last) {   // more conv taps than that: generic loop
       for (int i = tid; i < tl.lin_w; i += NT) tail_element(tl, i);
     }
-    if (s_last) {
+    if (last) {
       STAMP_ANY(25);
     }
   }
@@ -572,14 +602,14 @@ hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream) {
   const size_t wlds = sizeof(float) * (cw + (stage_rows ? max_rows * (size_t)k.FQ : 0));
   if (k.J <= 14) {
     if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)weff_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
-    SLODE_LAUNCH("weff", (weff_kernel<14>), dim3(nb_w + nb_r), dim3(256), wlds, stream, k, stage_rows);
+    SLODE_LAUNCH("weff", (weff_kernel<14>), dim3(nb_w + nb_r), dim3(256), wlds, stream, k.conv_w, k.lin_w, k, stage_rows);
   } else {
     if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)weff_kernel<SLODE_MAX_K + SLODE_MAX_P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
-    SLODE_LAUNCH("weff", (weff_kernel<SLODE_MAX_K + SLODE_MAX_P>), dim3(nb_w + nb_r), dim3(256), wlds, stream, k, stage_rows);
+    SLODE_LAUNCH("weff", (weff_kernel<SLODE_MAX_K + SLODE_MAX_P>), dim3(nb_w + nb_r), dim3(256), wlds, stream, k.conv_w, k.lin_w, k, stage_rows);
   }
   const size_t lds = sizeof(float) * ((size_t)TBE * k.CT + TBE * 64 + 2 * (size_t)k.L * k.Hc + 64);
   (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  SLODE_LAUNCH("enc_fwd2", enc_fwd2_kernel, dim3((k.B + TBE - 1) / TBE), dim3(FNT), lds, stream, k);
+  SLODE_LAUNCH("enc_fwd2", enc_fwd2_kernel, dim3((k.B + TBE - 1) / TBE), dim3(FNT), lds, stream, k.x, k.zloc_w, k.zls_w, k.beff, k.weff, k);
   return hipGetLastError();
 }
 
@@ -601,7 +631,7 @@ hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream) {
 #define SLODE_CHAIN(CC, JJ)                                                                                          \
   do {                                                                                                               \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)enc_chain_kernel<CC, JJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    SLODE_LAUNCH("enc_chain", (enc_chain_kernel<CC, JJ>), grid, dim3(CNT), lds, stream, k, tl, with_tail);                              \
+    SLODE_LAUNCH("enc_chain", (enc_chain_kernel<CC, JJ>), grid, dim3(CNT), lds, stream, k.gslabs, k.lin_w, (const float*)k.wprime, k, tl, with_tail);                              \
   } while (0)
   if (k.C == 3 && JM == 14) SLODE_CHAIN(3, 14);
   else if (k.C == 4 && JM == 14) SLODE_CHAIN(4, 14);

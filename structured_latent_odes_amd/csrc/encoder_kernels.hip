@@ -443,7 +443,9 @@ constexpr int KP = 16;  // batch-pairs (K = 2 each) whose operands a wave loads 
 // slabs have FQ + 1 columns per row (folded encoder path: g_beff comes for free).
 struct GemmProb { const float* A; int lda; const float* X; float* slabs; int M, N, ntiles; };   // A: [B][lda], rows m < 64 used
 struct GemmProbs { GemmProb p[3]; int n_gemm_x; Stage1 rider; int rider_bx; };   // rider: stage-1 slab reduction in extra blocks
-__global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const GemmProbs ps, int B, int per_wave, int ones_col) {
+// pl_A0 / pl_X0 = ps.p[0].A / .X (the big product's operands) as leading, SGPR-preloaded arguments (see ode_elbo_kernel)
+__global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restrict__ pl_A0, const float* __restrict__ pl_X0, const GemmProbs ps, int B,
+                                                          int per_wave, int ones_col) {
   __shared__ float s_part[4 * 32 * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if ((int)blockIdx.x >= ps.n_gemm_x) {   // rider blocks: (bx, group) = stage 1 of the ODE-slab reduction, independent of the GEMMs
@@ -457,8 +459,8 @@ __global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const GemmProbs ps, in
   const int which = tile < ps.p[0].ntiles ? 0 : (tile < ps.p[0].ntiles + ps.p[1].ntiles ? 1 : 2);
   tile -= which == 0 ? 0 : (which == 1 ? ps.p[0].ntiles : ps.p[0].ntiles + ps.p[1].ntiles);
   const GemmProb p = which == 0 ? ps.p[0] : (which == 1 ? ps.p[1] : ps.p[2]);
-  const float* __restrict__ g_pre = p.A;
-  const float* __restrict__ pooled = p.X;
+  const float* __restrict__ g_pre = which == 0 ? pl_A0 : p.A;
+  const float* __restrict__ pooled = which == 0 ? pl_X0 : p.X;
   float* __restrict__ slabs = p.slabs;
   const int Hc = p.M, FQ = p.N, lda = p.lda;
   const int i0 = tile * 32;
@@ -542,7 +544,7 @@ hipError_t slode_launch_gemm_gpre_x(const float* g_pre, const float* x, float* s
   GemmProbs ps{};
   ps.p[0] = GemmProb{g_pre, 64, x, slabs, Hc, N, (N + 1 + 31) / 32};
   ps.n_gemm_x = ps.p[0].ntiles;
-  SLODE_LAUNCH("enc_bwd_lin", enc_bwd_lin_kernel, dim3(ps.p[0].ntiles, splitk), dim3(256), 0, stream, ps, B, per_wave, 1);
+  SLODE_LAUNCH("enc_bwd_lin", enc_bwd_lin_kernel, dim3(ps.p[0].ntiles, splitk), dim3(256), 0, stream, ps.p[0].A, ps.p[0].X, ps, B, per_wave, 1);
   return hipGetLastError();
 }
 
@@ -567,7 +569,7 @@ hipError_t slode_launch_gemm_tail(const float* g_pre, const float* x, float* gsl
     rider_x = (ps.rider_bx * SLODE_REDUCE_GROUPS + splitk - 1) / splitk;
     *ode_part_out = ode_part; *ode_n_out = (ode_n + per - 1) / per;
   }
-  SLODE_LAUNCH("enc_bwd_lin", enc_bwd_lin_kernel, dim3(ps.n_gemm_x + rider_x, splitk), dim3(256), 0, stream, ps, B, per_wave, 1);
+  SLODE_LAUNCH("enc_bwd_lin", enc_bwd_lin_kernel, dim3(ps.n_gemm_x + rider_x, splitk), dim3(256), 0, stream, ps.p[0].A, ps.p[0].X, ps, B, per_wave, 1);
   return hipGetLastError();
 }
 
@@ -624,6 +626,6 @@ hipError_t slode_launch_enc_bwd(const EncBwdLaunch& a, hipStream_t stream) {
   GemmProbs ps{};
   ps.p[0] = GemmProb{a.g_pre, 64, a.pooled, a.slabs_lin, a.s.Hc, k.FQ, (k.FQ + 31) / 32};
   ps.n_gemm_x = ps.p[0].ntiles;
-  SLODE_LAUNCH("enc_bwd_lin", enc_bwd_lin_kernel, dim3(ps.p[0].ntiles, a.splitk), dim3(256), 0, stream, ps, a.s.B, per_wave, 0);
+  SLODE_LAUNCH("enc_bwd_lin", enc_bwd_lin_kernel, dim3(ps.p[0].ntiles, a.splitk), dim3(256), 0, stream, ps.p[0].A, ps.p[0].X, ps, a.s.B, per_wave, 0);
   return hipGetLastError();
 }

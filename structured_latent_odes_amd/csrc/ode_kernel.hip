@@ -46,7 +46,9 @@ extern "C" int slode_debug_wg_span(unsigned long long* out, int n) {
 // Product build: the phase boundaries rotate the issue priority between the workgroups that share a CU.  The CU arbitrates
 // oldest-first, so of the (up to four) co-resident trajectories the youngest only gets the issue slots the others leave and finishes
 // last (round 1: 27 / 31 / 36 / 41 us); alternating high / low priority by (phase + residency slot) parity evens their progress.  Wave 0
-// (every serial stretch) stays one level above its workgroup's bulk waves.
+// (every serial stretch) stays one level above its workgroup's bulk waves.  Round 3 measured two more schemes against this one: a rotation
+// over four levels by (phase + slot) mod 4 -- 27.6 us against 27.5, no better, and the four-way branch of the macro itself costs 0.4 us --
+// and a static level = residency slot (youngest highest): 28.4 us.
 #define STAMP(i) do { if (((i) + prio_slot) & 1) { if (threadIdx.x < 64) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); } \
                       else { if (threadIdx.x < 64) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } } while (0)
 #endif
@@ -487,7 +489,13 @@ __host__ __device__ constexpr int ode_max_threads(int S, int T_, int C_, int Q_,
 // control-flow join -- wrong gradients; tools/check_spills.py now rejects any kernel that uses scratch).
 template <int S, int H, bool BWD, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1, bool RA = false, bool ONE = false, int ALG = 0>
 __global__ void __launch_bounds__(ode_max_threads(S, T_, C_, Q_, ONE, BWD))
-ode_elbo_kernel(const OdeK k) {
+ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ pl_pseg, const float* __restrict__ pl_loc,
+                const float* __restrict__ pl_scale, const float* __restrict__ pl_eps, const float* __restrict__ pl_u,
+                const float* __restrict__ pl_sigtab, const OdeK k) {
+  // The seven leading pointers repeat fields of `k` (stage_t, pseg, loc | z_in, scale, eps, u, sigtab | cstd): as plain pointer arguments
+  // they are PRELOADED into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, Makefile), so the first global loads of the
+  // set-up go out at once instead of behind an s_load of the kernel-argument segment -- one of the two serialised cold misses every
+  // kernel of the step starts with.
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int T = T_ ? T_ : k.T, C = C_ ? C_ : k.C, L = L_ ? L_ : k.L, Q = Q_ ? Q_ : k.Q;
@@ -563,11 +571,11 @@ ode_elbo_kernel(const OdeK k) {
       const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, lane = tid & 63;
       for (int base = wv * 64; base < n_ts; base += NW * 64)
         if (base + lane < n_ts)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(k.stage_t + base + lane),
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pl_stage_t + base + lane),
                                            (__attribute__((address_space(3))) void*)(s_ts + base), 4, 0, 0);
       for (int base = wv * 64; base < n_par; base += NW * 64)
         if (base + lane < n_par)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(k.pseg + base + lane),
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pl_pseg + base + lane),
                                            (__attribute__((address_space(3))) void*)(s_par + base), 4, 0, 0);
     }
     float v_l0 = 0.f, v_l1 = 1.f, v_l2 = 0.f, v_u = 0.f;
@@ -575,17 +583,15 @@ ode_elbo_kernel(const OdeK k) {
     const int b_first = blockIdx.x;
     if (b_first < k.B) {
       const int lc = min(tid, L - 1);
-      if (k.loc != nullptr) {
-        v_l0 = k.loc[(long long)b_first * L + lc];
-        v_l1 = k.scale[(long long)b_first * L + lc];
-        v_l2 = k.eps[(long long)b_first * L + lc];
-      } else {
-        v_l0 = k.z_in[(long long)b_first * L + lc];
+      v_l0 = pl_loc[(long long)b_first * L + lc];     // (pure solve: z_in)
+      if (pl_scale != nullptr) {
+        v_l1 = pl_scale[(long long)b_first * L + lc];
+        v_l2 = pl_eps[(long long)b_first * L + lc];
       }
-      if (k.u != nullptr) v_u = k.u[(long long)b_first * k.nu + min(tid, k.nu - 1)];
+      if (pl_u != nullptr) v_u = pl_u[(long long)b_first * k.nu + min(tid, k.nu - 1)];
     }
     if (ONE && k.with_ll) {   // (with the per-step table: the scale itself instead of its parameter)
-      const float* src = k.sigtab ? k.sigtab : k.cstd;
+      const float* src = pl_sigtab;   // the table, or constant_std itself when there is none
 #pragma unroll
       for (int c = 0; c < SLODE_MAX_C; ++c) v_c[c] = src[min(c, C - 1) * T + min(tid, T - 1)];
     }
@@ -630,7 +636,7 @@ ode_elbo_kernel(const OdeK k) {
 
   float loss_acc = 0.f;   // the only value a thread carries from one trajectory to the next
   static_assert(H < 32, "the hidden units and the constant-1 bias unit share one 32-lane group");
-  constexpr int SP = (2 * S + 4) & ~3;  // stage-0 exchange rows: [a (S) | d (S) | pad], 16-B aligned
+  constexpr int SP = 2 * S + 1;         // stage-0 exchange rows [a (S) | d (S) | pad]: an odd pitch, lane n <-> row n is bank-conflict free (12: 4-way)
   constexpr int GP = 2 * S;             // pitch of the per-sample gradient rows
   const int hg_base = 64;  // head-grad role lives on waves >= 1 (the launcher guarantees NT >= 64 + roundup64(Q*C*S))
   const int n_headw = Q * C * S;
@@ -1672,7 +1678,8 @@ template <int S, int H, bool BWD, int T_, int C_, int L_, int Q_, int M_, bool R
 hipError_t launch_one(const OdeK& k, int grid, int nthreads, size_t lds, hipStream_t stream) {
   auto fn = ode_elbo_kernel<S, H, BWD, T_, C_, L_, Q_, M_, RA, ONE, ALG>;
   (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  SLODE_LAUNCH("ode_elbo", fn, dim3(grid), dim3(nthreads), lds, stream, k);
+  SLODE_LAUNCH("ode_elbo", fn, dim3(grid), dim3(nthreads), lds, stream, k.stage_t, k.pseg, k.loc ? k.loc : k.z_in, k.loc ? k.scale : nullptr,
+               k.eps, k.u, k.sigtab ? k.sigtab : k.cstd, k);
   return hipGetLastError();
 }
 

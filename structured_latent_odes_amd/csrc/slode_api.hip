@@ -68,6 +68,11 @@ static const char* check_shape(const slode_shape* s) {
     if (x.kind < SLODE_AUX_SIGMOID || x.kind > SLODE_AUX_EXPEXP) return "unknown aux head kind";
     if (x.z_off < 0 || x.z_dim < 1 || x.z_off + x.z_dim > s->L) return "aux head latent range outside [0, L)";
     if (x.u_off < 0 || x.u_dim < 1 || x.u_dim > 8 || x.u_off + x.u_dim > s->n_u) return "aux head label range outside [0, n_u) or wider than 8";
+    if (x.z_dim > 16) return "aux head reads more than 16 latent dims";
+    for (int a2 = 0; a2 < a; ++a2) {
+      const slode_aux& o = s->aux[a2];
+      if (x.z_off < o.z_off + o.z_dim && o.z_off < x.z_off + x.z_dim) return "aux heads read overlapping latent ranges";
+    }
   }
   if (s->grad_mode != SLODE_GRAD_EXACT && s->grad_mode != SLODE_GRAD_REFERENCE_ADJOINT) return "grad_mode must be SLODE_GRAD_EXACT or SLODE_GRAD_REFERENCE_ADJOINT";
   return nullptr;
@@ -435,9 +440,16 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
   }
 
   int n_slabs = w.ode_grid;
+  int part_lo = lay->ode_begin, part_hi = lay->n_params;   // flat range the slab rows carry (after the loss slot)
   if (aux_mode) {
+    // one workgroup per trajectory up to 2,048 of them, then a loop; on the folded path the kernel also runs the encoder-head backward and
+    // its slab rows carry only the label-head range (the fused tail below reduces exactly that)
     AuxLaunch al{*s, *lay, params, w.loc, w.scale, eps, u, w.g_loc, w.g_scale, w.ode_slabs, w.ode_stride,
-                 w.ode_grid < 512 ? w.ode_grid : 512, bwd ? 1 : 0};
+                 w.ode_grid < 2048 ? w.ode_grid : 2048, bwd ? 1 : 0};
+    if (bwd && folded) {
+      al.compact = 1; al.enc_hid = w.hid; al.g_pre = w.g_pre; al.glat = w.glat; al.g_loc = nullptr; al.g_scale = nullptr;
+      part_lo = lay->aux_w1[0]; part_hi = lay->cstd;
+    }
     n_slabs = al.grid;
     HIP_TRY(h, slode_launch_aux(al, st));
   } else {
@@ -474,7 +486,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     }
   }
 
-  if (bwd && folded && !aux_mode && !dp5) {
+  if (bwd && folded && !dp5) {
     // Fused tail.  The ODE kernel has already run the encoder heads + tanh backward (g_pre, glat): three launches remain --
     // split-K MFMA GEMMs (+ rider blocks: stage 1 of the ODE-slab reduction), chain rule, one final reduction (+ Adam).
     AdamHost ah{};
@@ -485,10 +497,11 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     const float* ode_part = nullptr;
     int ode_pn = 0;
     HIP_TRY(h, slode_launch_gemm_tail(w.g_pre, obs, w.gslabs, s->Hc, (int)CT, w.glat, w.hid, w.gslabs2, w.gslabs3, s->L, s->B, w.gsplit,
-                                      w.ode_slabs, w.ode_stride, n_slabs, (lay->ode_end - lay->ode_begin) + 1, w.ode_part, &ode_part, &ode_pn, st));
+                                      w.ode_slabs, w.ode_stride, n_slabs, (part_hi - part_lo) + 1, w.ode_part, &ode_part, &ode_pn, st));
     TailK tl{};
     tl.gslabs = w.gslabs; tl.gslabs_loc = w.gslabs2; tl.gslabs_ls = w.gslabs3; tl.conv_slabs = w.conv_slabs;
     tl.ode_part = ode_part; tl.ode_stride = w.ode_stride; tl.ode_n = ode_pn; tl.loss_out = loss_out;
+    tl.part_lo = part_lo; tl.part_hi = part_hi;
     tl.gsplit = w.gsplit; tl.Hc = s->Hc; tl.L = s->L; tl.CT = (int)CT; tl.n_cv = s->F * s->C * s->K + s->F;
     tl.conv_w = lay->conv_w; tl.lin_w = lay->lin_w; tl.lin_b = lay->lin_b; tl.zloc_w = lay->zloc_w; tl.zloc_b = lay->zloc_b;
     tl.zls_w = lay->zls_w; tl.zls_b = lay->zls_b; tl.ode_begin = lay->ode_begin; tl.n_params = lay->n_params;

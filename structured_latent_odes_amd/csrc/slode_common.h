@@ -152,6 +152,7 @@ inline AdamK make_adamk(const AdamHost* a) {
 struct TailK {
   const float *gslabs, *gslabs_loc, *gslabs_ls, *conv_slabs;
   const float* ode_part; int ode_stride, ode_n;
+  int part_lo, part_hi;   // the part rows hold [loss | flat elements [part_lo, part_hi)]; [ode_begin, n_params) outside it: zero gradient
   float* loss_out;
   int gsplit, Hc, L, CT, n_cv;                       // n_cv = F*C*K + F
   int conv_w, lin_w, lin_b, zloc_w, zloc_b, zls_w, zls_b, ode_begin, n_params, n_total;
@@ -169,7 +170,7 @@ __device__ __forceinline__ void tail_loss(const TailK& k) {
 __device__ __forceinline__ void tail_element(const TailK& k, int i) {
   float g = 0.f;
   if (i >= k.ode_begin && i < k.n_params) {
-    g = strided_sum(k.ode_part + 1 + (i - k.ode_begin), k.ode_stride, k.ode_n);
+    if (i >= k.part_lo && i < k.part_hi) g = strided_sum(k.ode_part + 1 + (i - k.part_lo), k.ode_stride, k.ode_n);
   } else if (i < k.lin_w) {
     g = strided_sum(k.conv_slabs + (i - k.conv_w), k.n_cv, k.Hc);
   } else if (i < k.n_params) {
@@ -346,6 +347,9 @@ struct AuxLaunch {
   const float *loc, *scale, *eps, *u;
   float *g_loc, *g_scale, *slabs;
   int slab_stride, grid, backward;
+  int compact = 0;                   // slab row = [loss | flat range [lay.aux_w1[0], lay.cstd)] instead of the whole ODE segment
+  const float* enc_hid = nullptr;    // folded encoder path: the kernel also runs the encoder heads + tanh backward (g_pre, glat)
+  float *g_pre = nullptr, *glat = nullptr;
 };
 hipError_t slode_launch_aux(const AuxLaunch& a, hipStream_t stream);
 

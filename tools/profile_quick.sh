@@ -2,11 +2,11 @@
 # kernel-trace statistics of the metric step (bench.py, 100 steps) -> average duration per kernel.  Usage on the GPU box: bash tools/profile_quick.sh <tag>
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r2/quick_$1
+OUT=$ROOT/gpurun_out/r3/quick_$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $ROOT
-rocprofv3 --kernel-trace --stats -f csv -d $OUT -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err || echo "failed"
+rocprofv3 --kernel-trace --stats -f csv -d $OUT -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-other-configs > $OUT/bench.json 2> $OUT/bench.err || echo "failed"
 python3 - "$OUT" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
