@@ -107,6 +107,14 @@ __host__ __device__ constexpr bool ode_full_chunks(int nt, int nthreads, int S) 
   return nq * cl - nt <= 8;
 }
 __host__ __device__ inline int imax2(int a, int b) { return a > b ? a : b; }
+// Long latents (L >= 32: the proc family's 50): only the parameters the solver phases re-read stay in LDS -- [init b1 | W2 | b2] and
+// [dyn b_h | W_g | b_g | W_d | b_d] -- the prior nets, the L-wide rows of the init net and of the hidden layer and the label heads are
+// read from global memory (L2 / L1 hits: every workgroup reads the same 20 KB) by the few phases that touch them once per trajectory.
+// 22 KB of LDS per workgroup less: 4 workgroups per CU instead of 2 for BASELINE config[2]'s shapes.
+__host__ __device__ constexpr bool ode_cold_global(int L_) { return L_ >= 32; }
+__host__ __device__ constexpr int ode_hot_r1(int S, int H) { return H + S * H + S; }            // b1 | W2 | b2
+__host__ __device__ constexpr int ode_hot_r2(int S, int H) { return H + 2 * (S * H + S); }      // b_h | W_g | b_g | W_d | b_d
+__host__ __device__ constexpr int ode_hot_floats(int S, int H) { return ode_hot_r1(S, H) + ode_hot_r2(S, H); }
 
 // `one`: loop-free form (one workgroup per trajectory): softplus(constant_std) stays in registers, no s_sig.
 // The block A | x | lam | st is one work region: besides the scan operands it holds, at different times, the piecewise-linear table of
@@ -398,10 +406,10 @@ __device__ __forceinline__ void wave_affine_scan(const float* __restrict__ s_A, 
 // has at least roundup64(T) threads), lanes (chunk, s): compose the chunk's maps, Kogge-Stone over the wave's chunks, the waves' total
 // maps through LDS (s_xw[NW][2][S]) and one barrier, then every lane applies the totals of the waves before its own and replays its
 // chunk.  Contains a barrier: every thread of the workgroup calls it.  The caller's next barrier publishes the results.
-template <int S, bool REV>
+template <int S, bool REV, int CLMAX = 8>
 __device__ __forceinline__ void block_affine_scan(const float* __restrict__ s_A, float* __restrict__ s_v, int T, int tid, int NT,
                                                   float* __restrict__ s_xw) {
-  constexpr int NC = 64 / S, CLMAX = 8;
+  constexpr int NC = 64 / S;   // (CLMAX: registers per lane; the shape-specialised kernels pass their exact chunk length)
   const int NW = NT >> 6, wave = tid >> 6, lane = tid & 63;
   const int nsteps = T - 1, nch = NW * NC;
   const int CL = (nsteps + nch - 1) / nch;   // <= 64 / NC <= CLMAX
@@ -466,7 +474,7 @@ __host__ __device__ constexpr int ode_threads_for(int T, int Q, int C, int S) {
 // (tools/check_spills.py).
 __host__ __device__ constexpr int ode_max_threads(int S, int T_, int C_, int Q_, bool one, bool bwd) {
   if (!one && bwd) return T_ > 0 ? ode_threads_for(T_, Q_, C_, S) : 512;
-  return (S > 5 && T_ > 0 && T_ <= 128) ? 512 : ((S > 5 || (T_ > 0 && T_ <= 128)) ? 768 : 1024);
+  return (S > 5 || (T_ > 0 && T_ <= 128)) ? 768 : 1024;
 }
 
 // Kernel algorithm variants (ALG).  The dynamics net never sees the state and its hidden layer is relu(w_t t + u_j(z)): every unit is
@@ -506,7 +514,8 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   // RA (grad_mode = reference_adjoint): the backward pass also needs a, d at node n+1 for euler / midpoint
   const int need_next = RA ? 1 : uses_next;
   const int NT = T_ ? ode_threads_for(T_, Q_, C_, S) : (int)blockDim.x;
-  const LdsMap m = lds_map(T, S, H, C, L, Q, n_stage_t, k.npar, NT, k.n_aux_lds, ONE, ALG == 3);
+  constexpr bool COLDG = ode_cold_global(L_);
+  const LdsMap m = lds_map(T, S, H, C, L, Q, n_stage_t, COLDG ? ode_hot_floats(S, H) : k.npar, NT, k.n_aux_lds, ONE, ALG == 3);
   float* s_ts = smem + m.ts;
   float* s_sig = smem + m.sig;
   float* s_A = smem + m.A;
@@ -529,6 +538,19 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   int* s_ms = reinterpret_cast<int*>(smem + m.ms);
   int* s_sf = reinterpret_cast<int*>(smem + m.sf);
   float* s_par = smem + m.par;  // small weights, staged once per workgroup (cold phases read LDS, not HBM/L2)
+  // offsets of the hot tensors inside s_par (the whole segment is there unless COLDG: then only the two hot ranges, back to back), and
+  // where the cold ones are read from
+  const int hb1 = COLDG ? 0 : k.o_b1, hw2 = hb1 + H, hb2 = hw2 + S * H;
+  const int hbh = COLDG ? ode_hot_r1(S, H) : k.o_bh, hwg = hbh + H, hbg = hwg + S * H, hwd = hbg + S, hbd = hwd + S * H;
+  const float* const cpar = COLDG ? pl_pseg : s_par;
+  // COLDB: during P0 (latent sample, priors, P0b's two L-long dot products, label heads) the cold parameters of a long-latent fixed-grid
+  // kernel sit in the -- then idle -- work block A | x | lam | st, put there by the set-up's LDS-DMA: three ranges back to back,
+  // [priors | W_1] (from the start of the segment), W_z (shifted by the hot range it follows), the label heads (shifted past both hot
+  // ranges and the decoder heads).  P0c / P1 overwrite the block; P7's second look at W_z / W_1 / the label heads reads global memory.
+  constexpr bool COLDB = COLDG && ALG != 3;
+  const float* const cp0 = COLDB ? s_A : cpar;
+  const int sh_wh = COLDB ? ode_hot_r1(S, H) : 0;
+  const int sh_aux = COLDB ? k.o_aux_w1[0] - (k.o_b1 + H * (1 + L)) : 0;
   float* s_uu = smem + m.uu;  // this trajectory's label row u[b, :]
   float* s_auxh = smem + m.auxh;    // label heads: hidden activations [head][32]
   float* s_auxd = smem + m.auxd;    //              softplus' then dLoss/d(hidden pre-activation)
@@ -564,6 +586,27 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   // The stage-time table and the parameter segment go global -> LDS by LDS-DMA (global_load_lds: 64 consecutive floats per wave
   // instruction, no registers, no address arithmetic per element); the few per-thread values (this trajectory's latent inputs, its
   // constant_std column) go through registers meanwhile.
+  // (COLDB) the cold parameter ranges -> the work block, by LDS-DMA; issued in the set-up and, in the persistent-loop form, again at the
+  // top of every later trajectory (the block is overwritten from P0c on)
+  auto stage_cold = [&]() {
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, lane = tid & 63;
+    const int n1 = k.o_b1, n2 = H * (1 + L), n3 = k.npar - k.o_aux_w1[0];
+    const float* g1 = pl_pseg;
+    const float* g2 = pl_pseg + k.o_wh;
+    const float* g3 = pl_pseg + k.o_aux_w1[0];
+    for (int base = wv * 64; base < n1; base += NW * 64)
+      if (base + lane < n1)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g1 + base + lane),
+                                         (__attribute__((address_space(3))) void*)(s_A + base), 4, 0, 0);
+    for (int base = wv * 64; base < n2; base += NW * 64)
+      if (base + lane < n2)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g2 + base + lane),
+                                         (__attribute__((address_space(3))) void*)(s_A + n1 + base), 4, 0, 0);
+    for (int base = wv * 64; base < n3; base += NW * 64)
+      if (base + lane < n3)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g3 + base + lane),
+                                         (__attribute__((address_space(3))) void*)(s_A + n1 + n2 + base), 4, 0, 0);
+  };
   float sigr[SLODE_MAX_C] = {1.f, 1.f, 1.f, 1.f};   // ONE: softplus(constant_std[c, t = tid]) stays in registers until P3
   {
     const int n_ts = n_stage_t, n_par = k.npar, n_sig = (!ONE && k.with_ll) ? C * T : 0;
@@ -573,11 +616,27 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
         if (base + lane < n_ts)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pl_stage_t + base + lane),
                                            (__attribute__((address_space(3))) void*)(s_ts + base), 4, 0, 0);
-      for (int base = wv * 64; base < n_par; base += NW * 64)
-        if (base + lane < n_par)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pl_pseg + base + lane),
-                                           (__attribute__((address_space(3))) void*)(s_par + base), 4, 0, 0);
+      if (!COLDG) {
+        for (int base = wv * 64; base < n_par; base += NW * 64)
+          if (base + lane < n_par)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pl_pseg + base + lane),
+                                             (__attribute__((address_space(3))) void*)(s_par + base), 4, 0, 0);
+      } else {   // the two hot ranges
+        const float* r1 = pl_pseg + k.o_b1;
+        const float* r2 = pl_pseg + k.o_bh;
+        for (int base = wv * 64; base < ode_hot_r1(S, H); base += NW * 64)
+          if (base + lane < ode_hot_r1(S, H))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(r1 + base + lane),
+                                             (__attribute__((address_space(3))) void*)(s_par + base), 4, 0, 0);
+        for (int base = wv * 64; base < ode_hot_r2(S, H); base += NW * 64)
+          if (base + lane < ode_hot_r2(S, H))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(r2 + base + lane),
+                                             (__attribute__((address_space(3))) void*)(s_par + ode_hot_r1(S, H) + base), 4, 0, 0);
+      }
     }
+    if (COLDB) stage_cold();
+    float v_wt = 0.f;   // COLDG: time column of dynamics_hidden, straight from global with the rest of the set-up loads
+    if (COLDG && tid < H) v_wt = pl_pseg[k.o_wh + tid * (1 + L)];
     float v_l0 = 0.f, v_l1 = 1.f, v_l2 = 0.f, v_u = 0.f;
     float v_c[SLODE_MAX_C] = {0.f, 0.f, 0.f, 0.f};
     const int b_first = blockIdx.x;
@@ -616,6 +675,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     }
     if (tid < L) { s_pf[tid] = v_l0; s_pf[pad4(L) + tid] = v_l1; s_pf[2 * pad4(L) + tid] = v_l2; }
     if (tid < k.nu) s_uu[tid] = v_u;
+    if (COLDG && tid < 32) s_wt[tid] = v_wt;
     if (ONE && k.with_ll) {
 #pragma unroll
       for (int c = 0; c < SLODE_MAX_C; ++c)
@@ -632,7 +692,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   }
   __syncthreads();
   STAMP(14);
-  if (tid < 32) s_wt[tid] = (tid < H) ? s_par[k.o_wh + tid * (1 + L)] : 0.f;  // time column of dynamics_hidden (col 0)
+  if (!COLDG && tid < 32) s_wt[tid] = (tid < H) ? s_par[k.o_wh + tid * (1 + L)] : 0.f;  // time column of dynamics_hidden (col 0)
 
   float loss_acc = 0.f;   // the only value a thread carries from one trajectory to the next
   static_assert(H < 32, "the hidden units and the constant-1 bias unit share one 32-lane group");
@@ -661,6 +721,11 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     float* const sl1 = k.slabs + (long long)blockIdx.x * k.slab_stride + 1;
     const bool first_traj = ONE || b == (int)blockIdx.x;
     auto accum = [&](int idx, float v) { float* d = sl1 + idx; *d = first_traj ? v : (*d + v); };
+    if (COLDB && !ONE && b != (int)blockIdx.x) {
+      __syncthreads();   // the previous trajectory's last readers of the work block (its encoder-head block) are done
+      stage_cold();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if (!ONE && b != (int)blockIdx.x) __syncthreads();   // s_pf / s_uu of this trajectory are in place (first one: the setup barrier)
 
     // ---- P0a: latent sample, log q, log p (mechanistic_cvs.py:125-135, 225-237) -------------------------
@@ -675,12 +740,29 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
         {
           const int4 m0 = reinterpret_cast<const int4*>(s_meta)[2 * l], m1 = reinterpret_cast<const int4*>(s_meta)[2 * l + 1];
           if (m0.x) {
-            pl = s_par[m0.y];
-            pls = s_par[m0.z];
-            for (int q = 0; q < m1.z; ++q) {
-              const float uv = s_uu[m1.y + q];
-              pl = fmaf(s_par[m0.w + q], uv, pl);
-              pls = fmaf(s_par[m1.x + q], uv, pls);
+            if (COLDG && !COLDB) {   // all of the two weight rows in flight at once (global memory), then the dot products
+              float wl[SLODE_MAX_NU], ws[SLODE_MAX_NU];
+#pragma unroll
+              for (int q = 0; q < SLODE_MAX_NU; ++q) {
+                wl[q] = cpar[m0.w + min(q, m1.z - 1)];
+                ws[q] = cpar[m1.x + min(q, m1.z - 1)];
+              }
+              pl = cpar[m0.y];
+              pls = cpar[m0.z];
+#pragma unroll
+              for (int q = 0; q < SLODE_MAX_NU; ++q) {
+                const float uv = (q < m1.z) ? s_uu[m1.y + min(q, m1.z - 1)] : 0.f;
+                pl = fmaf(wl[q], uv, pl);
+                pls = fmaf(ws[q], uv, pls);
+              }
+            } else {
+              pl = cp0[m0.y];
+              pls = cp0[m0.z];
+              for (int q = 0; q < m1.z; ++q) {
+                const float uv = s_uu[m1.y + q];
+                pl = fmaf(cp0[m0.w + q], uv, pl);
+                pls = fmaf(cp0[m1.x + q], uv, pls);
+              }
             }
           }
         }
@@ -704,29 +786,111 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     STAMP(15);
     // (P0a, P0b and the table part of P0c run on wave 0 only unless label heads are scored here: a wave's LDS accesses execute in
     //  program order, so the workgroup barriers in between are only needed for the label-head threads of the proc family)
-    if (k.n_aux > 0) __syncthreads();
+    if (COLDG || k.n_aux > 0) __syncthreads();
     // ---- P0b: u = W_z z + b_h (time-invariant part of the hidden layer), init-net hidden; each unit's switching index ------
+    float uj = 0.f;
+    if (tid < 64) {
+      // the two L-long dot products of hidden unit j run side by side: lane j the dynamics' hidden layer, lane 32 + j the init net's
+      const int j = tid & 31;
+      const bool init_net = tid >= 32;
+      float acc = 0.f;
+      if (j < H && !ext) {   // (the scorer of an external solution has no use for either: zeros keep the shared gradient code finite)
+        acc = s_par[(init_net ? hb1 : hbh) + j];
+        const float* row = cp0 + (init_net ? k.o_w1 + j * L : k.o_wh - sh_wh + j * (1 + L) + 1);
+#pragma unroll 4
+        for (int l = 0; l < L; ++l) acc = fmaf(row[l], s_z[l], acc);
+      }
+      if (init_net) {
+        if (j < H) { s_pre0[j] = acc; s_hid0[j] = fmaxf(acc, 0.f); }
+      } else {
+        uj = acc;
+      }
+    }
+    if (k.n_aux > 0 && tid < k.n_aux * 32) {
+      // q(label | z_g) on the replayed z at aux_mult x (mechanistic_proc.py:145-146,334-353): half-wave = head, lane j = hidden unit.  The sums
+      // over hidden units are xor-butterflies inside the half-wave (offsets 16..1); every lane of a head then holds its few logits and
+      // works out log p and dLoss/dlogit redundantly -- no serial per-head thread (round 2: one thread per head walked U x u_dim
+      // dependent FMAs three times over, 5.8 us of the proc trajectory's 30), no exchange, no barrier.
+      const int hd = tid >> 5, j = tid & 31;
+      const slode_aux ax = k.aux[hd];
+      const bool on = j < k.U;
+      float hvv = 0.f, dv = 0.f;
+      if (on) {
+        float pre = cp0[k.o_aux_b1[hd] - sh_aux + j];
+        if (COLDG && !COLDB) {
+          float rw[16];   // (a head reads at most 16 latent dims: check_shape)
+#pragma unroll
+          for (int l = 0; l < 16; ++l) rw[l] = cpar[k.o_aux_w1[hd] + j * ax.z_dim + min(l, ax.z_dim - 1)];
+#pragma unroll
+          for (int l = 0; l < 16; ++l) pre = fmaf((l < ax.z_dim) ? rw[l] : 0.f, s_z[ax.z_off + min(l, ax.z_dim - 1)], pre);
+        } else {
+          for (int l = 0; l < ax.z_dim; ++l) pre = fmaf(cp0[k.o_aux_w1[hd] - sh_aux + j * ax.z_dim + l], s_z[ax.z_off + l], pre);
+        }
+        hvv = softplusf(pre);
+        dv = 1.f / (1.f + expf(-pre));   // softplus'
+      }
+      constexpr int QM = 8;              // label columns of one head (check_shape)
+      float lg[QM], go[QM], w2c[QM];
+#pragma unroll
+      for (int q = 0; q < QM; ++q) {
+        lg[q] = 0.f; go[q] = 0.f;
+        w2c[q] = (on && q < ax.u_dim) ? cp0[k.o_aux_w2[hd] - sh_aux + min(q, ax.u_dim - 1) * k.U + j] : 0.f;
+        if (q < ax.u_dim) {   // (uniform per half-wave)
+          float v = w2c[q] * hvv;
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+          lg[q] = v + cp0[k.o_aux_b2[hd] - sh_aux + q];
+        }
+      }
+      float lp = 0.f, gcst = 0.f;
+      if (ax.kind == SLODE_AUX_SOFTMAX) {
+        float mx = -3.0e38f, ysum = 0.f, se = 0.f;
+#pragma unroll
+        for (int q = 0; q < QM; ++q) if (q < ax.u_dim) mx = fmaxf(mx, lg[q]);
+#pragma unroll
+        for (int q = 0; q < QM; ++q) if (q < ax.u_dim) { se += expf(lg[q] - mx); ysum += s_uu[ax.u_off + q]; }
+        const float lse = mx + logf(se);
+#pragma unroll
+        for (int q = 0; q < QM; ++q) if (q < ax.u_dim) {
+          const float lq = lg[q] - lse, y = s_uu[ax.u_off + q];
+          lp = fmaf(y, lq, lp);
+          go[q] = k.aux_mult * (expf(lq) * ysum - y);
+        }
+      } else if (ax.kind == SLODE_AUX_SIGMOID) {
+#pragma unroll
+        for (int q = 0; q < QM; ++q) if (q < ax.u_dim) {
+          const float o = lg[q], y = s_uu[ax.u_off + q];
+          const float sp_pos = (o > 0.f ? o : 0.f) + log1pf(expf(-fabsf(o)));  // softplus(o), stable
+          lp += y * (o - sp_pos) + (1.f - y) * (-sp_pos);
+          go[q] = k.aux_mult * (1.f / (1.f + expf(-o)) - y);
+        }
+      } else {  // EXPEXP: Laplace(loc = exp(head 0), b = softplus(constant_std_*)); the second Exp head is unused
+        const float c = cp0[k.o_aux_c[hd] - sh_aux];
+        const float bsc = softplusf(c), ib = 1.f / bsc;
+#pragma unroll
+        for (int q = 0; q < QM; ++q) if (q < ax.u_dim) {
+          const float loc = expf(lg[q]), y = s_uu[ax.u_off + q];
+          const float r = y - loc, ar = fabsf(r);
+          lp += -logf(2.f * bsc) - ar * ib;
+          const float sg = (r > 0.f) ? 1.f : ((r < 0.f) ? -1.f : 0.f);
+          go[q] = -k.aux_mult * sg * ib * loc;
+          gcst += k.aux_mult * (ib - ar * ib * ib);
+        }
+        gcst = gcst / (1.f + expf(-c));
+      }
+      float gh = 0.f;   // back through the output layer and the Softplus (P7 reads s_auxd again)
+#pragma unroll
+      for (int q = 0; q < QM; ++q) gh = fmaf(w2c[q], go[q], gh);
+      if (on) { s_auxh[hd * 32 + j] = hvv; s_auxd[hd * 32 + j] = dv * gh; }
+      if (j == 0) {
+        loss_acc -= k.aux_mult * lp;
+#pragma unroll
+        for (int q = 0; q < QM; ++q) if (q < ax.u_dim) s_auxgo[hd * 12 + q] = go[q];
+        if (ax.kind == SLODE_AUX_EXPEXP) s_auxgo[hd * 12 + 8] = gcst;
+      }
+    }
     if (tid < 32) {
       const int j = tid;
-      float uj = 0.f;
-      if (j < H) {
-        float p0 = s_par[k.o_b1 + j];
-        uj = s_par[k.o_bh + j];
-        const float* whr = s_par + k.o_wh + j * (1 + L) + 1;
-        const float* w1r = s_par + k.o_w1 + j * L;
-        if (!ext) {   // (the scorer of an external solution has no use for either: zeros keep the shared gradient code finite)
-#pragma unroll 4
-          for (int l = 0; l < L; ++l) {
-            const float zl = s_z[l];
-            uj = fmaf(whr[l], zl, uj);
-            p0 = fmaf(w1r[l], zl, p0);
-          }
-        } else {
-          uj = 0.f; p0 = 0.f;
-        }
-        s_pre0[j] = p0;
-        s_hid0[j] = fmaxf(p0, 0.f);
-      }
       s_u[j] = uj;
       if (!ext && (ALG == 0 || BWD)) {
         // relu(w_t t + u_j) is on exactly where fma(w_t, t, u_j) > 0 (the predicate the gradient uses too); fma is monotone in t and the
@@ -791,7 +955,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
             const int jc = min(j, H - 1);
             float wc[2 * S];
 #pragma unroll
-            for (int c = 0; c < 2 * S; ++c) wc[c] = s_par[(c < S ? k.o_wg + c * H : k.o_wd + (c - S) * H) + jc];
+            for (int c = 0; c < 2 * S; ++c) wc[c] = s_par[(c < S ? hwg + c * H : hwd + (c - S) * H) + jc];
 #pragma unroll
             for (int c = 0; c < 2 * S; ++c) s_esw[rk * 2 * S + c] = (j < H) ? sg * wc[c] : 0.f;
           }
@@ -799,22 +963,11 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
         }
       }
     }
-    if (k.n_aux > 0 && tid < k.n_aux * 32) {  // label heads of the main loss: hidden layer (Softplus), thread (head, j)
-      const int hd = tid >> 5, j = tid & 31;
-      if (j < k.U) {
-        const slode_aux ax = k.aux[hd];
-        float pre = s_par[k.o_aux_b1[hd] + j];
-        for (int l = 0; l < ax.z_dim; ++l) pre = fmaf(s_par[k.o_aux_w1[hd] + j * ax.z_dim + l], s_z[ax.z_off + l], pre);
-        s_auxh[hd * 32 + j] = softplusf(pre);
-        s_auxd[hd * 32 + j] = 1.f / (1.f + expf(-pre));
-      }
-    }
     STAMP(16);
-    if (k.n_aux > 0) __syncthreads();
     // ---- P0c: x0 = sigmoid(W2 relu(.) + b2)  (blackbox_ode.py:19-22)  ||  the piecewise-linear table ------------------------
     if (tid < S) {
-      float o = s_par[k.o_b2 + tid];
-      const float* w2r = s_par + k.o_w2 + tid * H;
+      float o = s_par[hb2 + tid];
+      const float* w2r = s_par + hw2 + tid * H;
 #pragma unroll
       for (int j = 0; j < H; ++j) o = fmaf(w2r[j], s_hid0[j], o);
       const float x0 = sigmoidf_fast(o);
@@ -827,7 +980,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
       // The rows stay in registers until the chain is done: with no store in the loops every LDS read is issued up front.
       const int c = tid - 32;
       // pass 1: the units that are on over a prefix (sign -1) are on at the first stage time
-      float al = 0.f, V = s_par[c < S ? k.o_bg + c : k.o_bd + (c - S)];
+      float al = 0.f, V = s_par[c < S ? hbg + c : hbd + (c - S)];
 #pragma unroll
       for (int k0 = 0; k0 < H; k0 += 8) {
         float sw[8], ew[8], p0[8], sg[8];
@@ -872,53 +1025,6 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
         s_tab[kk * 4 * S + c] = Vr[kk];
         s_tab[kk * 4 * S + 2 * S + c] = Ar[kk];
       }
-    }
-    if (k.n_aux > 0 && tid >= 64 && tid < 64 + k.n_aux) {
-      // q(label | z_g) on the replayed z at aux_mult x (mechanistic_proc.py:145-146,334-353); one thread per head
-      const int hd = tid - 64;
-      const slode_aux ax = k.aux[hd];
-      const float* w2 = s_par + k.o_aux_w2[hd];
-      const float* b2 = s_par + k.o_aux_b2[hd];
-      const float* hv = s_auxh + hd * 32;
-      auto logit = [&](int q) {
-        float o = b2[q];
-        for (int j = 0; j < k.U; ++j) o = fmaf(w2[q * k.U + j], hv[j], o);
-        return o;
-      };
-      float lp = 0.f;
-      if (ax.kind == SLODE_AUX_SOFTMAX) {
-        float mx = -3.0e38f, ysum = 0.f;
-        for (int q = 0; q < ax.u_dim; ++q) mx = fmaxf(mx, logit(q));
-        float se = 0.f;
-        for (int q = 0; q < ax.u_dim; ++q) { se += expf(logit(q) - mx); ysum += s_uu[ax.u_off + q]; }
-        const float lse = mx + logf(se);
-        for (int q = 0; q < ax.u_dim; ++q) {
-          const float lq = logit(q) - lse, y = s_uu[ax.u_off + q];
-          lp = fmaf(y, lq, lp);
-          s_auxgo[hd * 12 + q] = k.aux_mult * (expf(lq) * ysum - y);
-        }
-      } else if (ax.kind == SLODE_AUX_SIGMOID) {
-        for (int q = 0; q < ax.u_dim; ++q) {
-          const float o = logit(q), y = s_uu[ax.u_off + q];
-          const float sp_pos = (o > 0.f ? o : 0.f) + log1pf(expf(-fabsf(o)));  // softplus(o), stable
-          lp += y * (o - sp_pos) + (1.f - y) * (-sp_pos);
-          s_auxgo[hd * 12 + q] = k.aux_mult * (1.f / (1.f + expf(-o)) - y);
-        }
-      } else {  // EXPEXP: Laplace(loc = exp(head 0), b = softplus(constant_std_*)); the second Exp head is unused
-        const float c = s_par[k.o_aux_c[hd]];
-        const float bsc = softplusf(c), ib = 1.f / bsc;
-        float gc = 0.f;
-        for (int q = 0; q < ax.u_dim; ++q) {
-          const float loc = expf(logit(q)), y = s_uu[ax.u_off + q];
-          const float r = y - loc, ar = fabsf(r);
-          lp += -logf(2.f * bsc) - ar * ib;
-          const float sg = (r > 0.f) ? 1.f : ((r < 0.f) ? -1.f : 0.f);
-          s_auxgo[hd * 12 + q] = -k.aux_mult * sg * ib * loc;
-          gc += k.aux_mult * (ib - ar * ib * ib);
-        }
-        s_auxgo[hd * 12 + 8] = gc / (1.f + expf(-c));
-      }
-      loss_acc -= k.aux_mult * lp;
     }
     __syncthreads();   // table complete (ALG 0); u, w_t in place for every wave
 
@@ -1023,7 +1129,9 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     }
     // ---- P2: forward scan x_{n+1} = A_n x_n + b_n (the only serial part of the solve) -------------------
     if (!ext) {
-      block_affine_scan<S, false>(s_A, s_x, T, tid, NT, s_ct);   // (the chunk-sum buffer of P6 carries the waves' total maps)
+      constexpr int NTc = T_ ? ode_threads_for(T_ ? T_ : 1, Q_ ? Q_ : 1, C_ ? C_ : 1, S) : 64;
+      constexpr int CLc = T_ ? ((T_ - 1) + (NTc / 64) * (64 / S) - 1) / ((NTc / 64) * (64 / S)) : 8;   // steps per lane of the forward scan
+      block_affine_scan<S, false, (CLc < 8 ? CLc : 8)>(s_A, s_x, T, tid, NT, s_ct);   // (the chunk-sum buffer of P6 carries the waves' total maps)
     } else {   // score the adaptive solver's trajectory instead
       const float* xe = k.x_ext + (long long)b * T * S;
       for (int i = tid; i < T * S; i += NT) s_x[i] = xe[i];
@@ -1155,6 +1263,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
               a0 = fmaf(s_st[qc * T + t + q], s_x[(t + q) * S + s], a0);
               a1 = fmaf(s_st[qc * T + t + q + 1], s_x[(t + q + 1) * S + s], a1);
             }
+            if (S > 5) __builtin_amdgcn_sched_barrier(0);   // one batch of 16 LDS reads at a time (the S = 8 kernels have 168 VGPRs)
           }
           for (; t < t1; ++t) a0 = fmaf(s_st[qc * T + t], s_x[t * S + s], a0);
           s_hp[e] = a0 + a1;
@@ -1162,15 +1271,6 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
       }
       __syncthreads();
       STAMP(7);
-      if (k.n_aux > 0 && tid < k.n_aux * 32) {  // label heads: back through the output layer and the Softplus (read again in P7)
-        const int hd = tid >> 5, j = tid & 31;
-        if (j < k.U) {
-          const slode_aux ax = k.aux[hd];
-          float gh = 0.f;
-          for (int q = 0; q < ax.u_dim; ++q) gh = fmaf(s_par[k.o_aux_w2[hd] + q * k.U + j], s_auxgo[hd * 12 + q], gh);
-          s_auxd[hd * 32 + j] *= gh;
-        }
-      }
       if (!ext) {
       // ---- P5: reverse mode of the step coefficients (thread n <-> step n) ------------------------------
       // (the stage buffer is free again: re-exchange the first-stage values instead of carrying a3/d3 in registers)
@@ -1221,6 +1321,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           av[0][s] = ga[0]; av[1][s] = ga[1]; av[2][s] = ga[2];
           dv[0][s] = gd[0]; dv[1][s] = gd[1]; dv[2][s] = gd[2];
           g3a[s] = ga[3]; g3d[s] = gd[3];
+          if (S > 5) __builtin_amdgcn_sched_barrier(0);   // one state component at a time: eight interleaved reverse-mode chains cost 12 VGPRs too many
         }
       } else if (own_last) {
 #pragma unroll
@@ -1236,7 +1337,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           float gh0 = 0.f;
           if (j < H) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) gh0 = fmaf(s_par[k.o_w2 + s * H + j], s_go[s], gh0);
+            for (int s = 0; s < S; ++s) gh0 = fmaf(s_par[hw2 + s * H + j], s_go[s], gh0);
             gh0 = (s_pre0[j] > 0.f) ? gh0 : 0.f;
           }
           s_gp0[j] = gh0;
@@ -1490,7 +1591,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           if (j < H) {
 #pragma unroll
             for (int r = 0; r < 2 * S; ++r) {
-              const float w = s_par[(r < S ? k.o_wg + r * H : k.o_wd + (r - S) * H) + j];
+              const float w = s_par[(r < S ? hwg + r * H : hwd + (r - S) * H) + j];
               gu = fmaf(w, s_gm[r * 32 + j], gu);
               gwt = fmaf(w, s_gm[(2 * S + r) * 32 + j], gwt);
             }
@@ -1521,6 +1622,25 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
         const int Lp = (L > 32) ? 64 : ((L > 16) ? 32 : ((L > 8) ? 16 : 8)), parts = 64 / Lp;
         const int l = tid & (Lp - 1), part = tid / Lp, lc = min(l, L - 1);
         float gz = 0.f;
+        if (COLDG) {   // columns lc of W_z and W_1 from global memory: up to 2 x 13 loads in flight
+          for (int j0 = part; j0 < H; j0 += 13 * parts) {
+            float a[13], c[13];
+#pragma unroll
+            for (int q = 0; q < 13; ++q) {
+              const int j = min(j0 + q * parts, H - 1);
+              a[q] = RA ? 0.f : cpar[k.o_wh + j * (1 + L) + 1 + lc];
+              c[q] = cpar[k.o_w1 + j * L + lc];
+            }
+#pragma unroll
+            for (int q = 0; q < 13; ++q) {
+              const int j = j0 + q * parts;
+              if (j < H) {
+                if (!RA) gz = fmaf(a[q], s_gu[j], gz);   // reference_adjoint: z is not an adjoint parameter
+                gz = fmaf(c[q], s_gp0[j], gz);
+              }
+            }
+          }
+        } else
         for (int j = part; j < H; j += parts) {
           if (!RA) gz = fmaf(s_par[k.o_wh + j * (1 + L) + 1 + lc], s_gu[j], gz);   // reference_adjoint: z is not an adjoint parameter
           gz = fmaf(s_par[k.o_w1 + j * L + lc], s_gp0[j], gz);
@@ -1531,7 +1651,13 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           for (int hd = 0; hd < k.n_aux; ++hd) {
             const slode_aux ax = k.aux[hd];
             if (l >= ax.z_off && l < ax.z_off + ax.z_dim)
-              for (int j = 0; j < k.U; ++j) gz = fmaf(s_par[k.o_aux_w1[hd] + j * ax.z_dim + (l - ax.z_off)], s_auxd[hd * 32 + j], gz);
+              for (int j0 = 0; j0 < k.U; j0 += 16) {   // (batched: the weights may sit in global memory)
+                float wv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) wv[q] = cpar[k.o_aux_w1[hd] + min(j0 + q, k.U - 1) * ax.z_dim + (l - ax.z_off)];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) gz = fmaf((j0 + q < k.U) ? wv[q] : 0.f, s_auxd[hd * 32 + min(j0 + q, k.U - 1)], gz);
+              }
           }
           if (k.loc != nullptr) {
             const float sc = s_gls[L + l];
@@ -1706,11 +1832,22 @@ static int n_stage(const slode_shape& s) {
   return R * (s.T - 1) + 1;
 }
 
+// the shape-specialised instantiations with a long latent keep only the hot parameter ranges in LDS (ode_cold_global): BASELINE config[2]
+static bool static_cold(const slode_shape& s, bool force_generic) {
+  const int Q = s.likelihood == SLODE_GAUSS ? 1 : 3;
+  return !force_generic && s.H == 25 && s.S == 8 && s.T == 100 && s.C == 4 && s.L == 50 && Q == 3 &&
+         (s.method == SLODE_RK4 || s.method == SLODE_EULER) && ode_cold_global(s.L);
+}
+static int lds_npar(const slode_shape& s, const slode_layout& lay, bool force_generic, bool ext) {   // (occupancy estimates only)
+  const bool st = static_cold(s, force_generic) && (ext ? s.method == SLODE_EULER : s.method == SLODE_RK4);
+  return st ? ode_hot_floats(s.S, s.H) : lay.cstd - lay.ode_begin;
+}
+
 size_t slode_ode_lds_bytes(const slode_shape& s, int nthreads, bool one) {
   slode_layout lay;
   slode_layout_init(&s, &lay);
   const int Q = s.likelihood == SLODE_GAUSS ? 1 : 3;
-  const LdsMap m = lds_map(s.T, s.S, s.H, s.C, s.L, Q, n_stage(s), lay.cstd - lay.ode_begin, nthreads, s.aux_in_main ? s.n_aux : 0, one);
+  const LdsMap m = lds_map(s.T, s.S, s.H, s.C, s.L, Q, n_stage(s), lds_npar(s, lay, false, false), nthreads, s.aux_in_main ? s.n_aux : 0, one);
   return (size_t)m.total * sizeof(float);
 }
 
@@ -1798,9 +1935,16 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   }
   // loop-free form when every trajectory has its own workgroup (the grid policy is the caller's: ode_grid_for)
   const bool one = bwd && a.grid == s.B && !a.force_loop;
-  const size_t lds = slode_ode_lds_bytes(s, nthreads, one);
+  const bool ra = bwd && s.grad_mode == SLODE_GRAD_REFERENCE_ADJOINT;
+  // which launches take a long-latent shape-specialised instantiation (cold parameters in global memory, ode_cold_global) -- decided
+  // here, ONCE, for the LDS size and for the dispatch below
+  const bool shape_c2 = s.H == 25 && s.S == 8 && s.T == 100 && s.C == 4 && s.L == 50 && k.Q == 3;
+  const bool static_scorer = a.x_ext && !a.force_generic && a.alg == 0 && !ra && shape_c2 && s.method == SLODE_EULER && (!bwd || one);
+  const bool static_c2 = !a.x_ext && !a.force_generic && a.alg == 0 && shape_c2 && s.method == SLODE_RK4;
+  const int npar_lds = (static_scorer || static_c2) ? ode_hot_floats(s.S, s.H) : k.npar;
+  const size_t lds = sizeof(float) * (size_t)lds_map(s.T, s.S, s.H, s.C, s.L, k.Q, k.nt, npar_lds, nthreads, k.n_aux_lds, one).total;
   {
-    const LdsMap m = lds_map(s.T, s.S, s.H, s.C, s.L, k.Q, k.nt, k.npar, nthreads, k.n_aux_lds, one);
+    const LdsMap m = lds_map(s.T, s.S, s.H, s.C, s.L, k.Q, k.nt, npar_lds, nthreads, k.n_aux_lds, one);
     // z_loc.weight | z_loc.bias | z_scale.0.weight must be one block of the flat vector and fit the stage buffer
     k.stage_encw = (k.g_pre != nullptr && 2 * s.L * s.Hc + s.L <= m.stn && lay.zloc_b == lay.zloc_w + s.L * s.Hc &&
                     lay.zls_w == lay.zloc_b + s.L) ? 1 : 0;
@@ -1817,7 +1961,6 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
       return hipErrorInvalidValue;
     }
   }
-  const bool ra = bwd && s.grad_mode == SLODE_GRAD_REFERENCE_ADJOINT;
   // measured A/B arms: direct evaluation of the dynamics heads, MFMA contraction -- metric shape, exact gradients, loop-free
   if (a.alg != 0 && bwd) {
     if (!(s.H == 25 && s.S == 5 && s.T == 200 && s.C == 3 && s.L == 8 && k.Q == 3 && s.method == SLODE_RK4 && one && !ra && !a.x_ext)) {
@@ -1830,9 +1973,8 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
     return hipErrorInvalidValue;
   }
   // the scorer of BASELINE config[2] as written (proc, dopri5): shape-specialised, solver phases compiled out
-  if (a.x_ext && !a.force_generic && a.alg == 0 && !ra && s.H == 25 && s.S == 8 && s.T == 100 && s.C == 4 && s.L == 50 && k.Q == 3 &&
-      s.method == SLODE_EULER) {
-    const size_t lds_sc = sizeof(float) * (size_t)lds_map(s.T, s.S, s.H, s.C, s.L, k.Q, k.nt, k.npar, nthreads, k.n_aux_lds, one, true).total;
+  if (static_scorer) {
+    const size_t lds_sc = sizeof(float) * (size_t)lds_map(s.T, s.S, s.H, s.C, s.L, k.Q, k.nt, npar_lds, nthreads, k.n_aux_lds, one, true).total;
     if (!bwd) return launch_one<8, 25, false, 100, 4, 50, 3, SLODE_EULER, false, false, 3>(k, a.grid, nthreads, lds_sc, stream);
     if (one) return launch_one<8, 25, true, 100, 4, 50, 3, SLODE_EULER, false, true, 3>(k, a.grid, nthreads, lds_sc, stream);
   }
@@ -1843,7 +1985,7 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
       return launch_sh<SS, 25, TT, CC, LL, QQ, MM>(k, a.grid, nthreads, lds, bwd, one, ra, stream)
     SLODE_STATIC(5, 200, 3, 8, 3, SLODE_RK4);        // configs [1] / [3]: cvs, latent 3+3+2, ALD
     SLODE_STATIC(5, 100, 3, 4, 3, SLODE_RK4);        // config [0]: cvs, latent 1+1+2
-    SLODE_STATIC(8, 100, 4, 50, 3, SLODE_RK4);       // config [2] shapes: proc (fixed-grid stand-in for dopri5)
+    if (static_c2) return launch_sh<8, 25, 100, 4, 50, 3, SLODE_RK4>(k, a.grid, nthreads, lds, bwd, one, ra, stream);   // config [2] shapes: proc, fixed grid
     SLODE_STATIC(5, 300, 4, 15, 1, SLODE_RK4);       // config [4]: challenge, Gauss
     SLODE_STATIC(5, 86, 3, 15, 3, SLODE_MIDPOINT);   // reference default: training_cvs.py, config_cvs.py
 #undef SLODE_STATIC

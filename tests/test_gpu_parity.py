@@ -347,7 +347,8 @@ def test_dopri5_elbo_step_solution_level(fam, mode):
     """ELBO step with the adaptive solver (BASELINE config[2]): forward solve with recorded steps, reverse mode over the records.
     Parity is at solution level (see test_dopri5_forward_solution_level): -ELBO and every gradient against the fp64 oracle run at tight
     tolerances -- `exact`: autograd through the oracle's per-trajectory dopri5; `reference_adjoint`: the same with the latent detached
-    inside the dynamics (oracle solve_ode).  Tolerances: -ELBO 2e-5 relative; gradients: see the bar below."""
+    inside the dynamics (oracle solve_ode).  Tolerances: see the bars below (each = a fixed-grid-sized term + 3x the oracle's own sensitivity to
+    the adaptive step sequence)."""
     from structured_latent_odes_amd import engine as E
     dev = torch.device("cuda:0")
     if fam == "proc_c2":                       # BASELINE config[2] as written: proc, latent dim 50 (4 x 10 + 10), T = 100, dopri5
@@ -389,14 +390,17 @@ def test_dopri5_elbo_step_solution_level(fam, mode):
     want_loss.backward()
     want = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in q.items()}
     want_loss, tight = want_loss.detach(), parts["dec"][0].detach()
-    assert abs(loss.item() - want_loss.item()) / abs(want_loss.item()) < 2e-5, (loss.item(), want_loss.item())
     got = eng.unpack(grads)
     # Bar per tensor: 5e-4 (the fixed-grid bar) + 3x the oracle's own sensitivity to the step sequence -- its gradient at the engine's
     # tolerances (fp64) against the tight one.  The solver controls the error of the SOLUTION; gradients that integrate relu'(.) of
     # the hidden layer over time (dynamics_hidden, and through z the encoder) see an O(step) quadrature error at every kink and differ
     # by ~1e-3 between any two adaptive step sequences, the rest by ~1e-5.
     ospec.solver_kw = dict(rtol=1e-6, atol=1e-8, per_trajectory=True)
-    _, loose = O.loss_and_grads(p64, ospec, obs.double(), u.double(), eps.double(), times.double())
+    loose_loss, loose = O.loss_and_grads(p64, ospec, obs.double(), u.double(), eps.double(), times.double())
+    # -ELBO: the likelihood scale is 0.01, so the solver's own tolerance shows in the loss amplified a hundredfold -- the oracle at the
+    # engine's tolerances sits 1.6e-5 (relative) from the oracle at tight ones in the cvs case.  Bar: 2e-5 + 3x that sensitivity.
+    loss_sens = abs(loose_loss.item() - want_loss.item()) / abs(want_loss.item())
+    assert abs(loss.item() - want_loss.item()) / abs(want_loss.item()) < 2e-5 + 3.0 * loss_sens, (loss.item(), want_loss.item(), loose_loss.item())
     bad = {k: (_rel(v, want[k]), _rel(loose[k], want[k])) for k, v in got.items() if _rel(v, want[k]) > 5e-4 + 3.0 * _rel(loose[k], want[k])}
     assert not bad, bad
     assert all(_rel(v, want[k]) < 1e-2 for k, v in got.items())
