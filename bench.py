@@ -49,6 +49,7 @@ def parse_args():
     ap.add_argument("--repeats", type=int, default=25, help="timed K-step blocks; ms_per_step is their median / K")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-run-batch", action="store_true", help="skip the run_batch (main + auxiliary step) block: profiling runs of the metric step alone")
     ap.add_argument("--grad-mode", choices=["exact", "reference_adjoint"], default="exact",
                     help="exact: gradient of the discrete scheme (adjoint_solver=False); reference_adjoint: torchdiffeq.odeint_adjoint's")
     return ap.parse_args()
@@ -318,7 +319,7 @@ def main():
     }
 
     # ---- the reference's whole minibatch (training_cvs.py:147-157): main SVI step, auxiliary SVI step, Adam after each ----------------
-    if world == 1:
+    if world == 1 and not args.no_run_batch:
         aux = AuxStep(model, opt)
         aux_step = lambda: aux.step_async(obs_d, eps=eps_d, **labels_d)
         both = lambda: (step(), aux_step())

@@ -193,6 +193,12 @@ int slode_label_heads(slode_handle h, const slode_shape* s, const slode_layout* 
 int slode_decode_heads(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params,
                        const float* x, float* mu, float* std_ct, void* stream);
 
+/* Backward of slode_decode_heads (autograd through Decoder.forward / GaussianDecoder.forward, models/decoders.py:42-54, 84-91, as the
+ * reference's recon-style callers would differentiate it): g_mu[Q][B,C,T] (zeros for heads without a gradient), g_std[C,T] (NULL: none) ->
+ * g_x[B,T,S], g_heads[Q][C,S] (the head weights' gradients, in slode_decode_heads' head order), g_cstd[C,T] (NULL to skip). */
+int slode_decode_heads_bwd(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* x,
+                           const float* g_mu, const float* g_std, float* g_x, float* g_heads, float* g_cstd, void* stream);
+
 /* One SVI step's arithmetic for the main loss (pyro SVI.step on (model, guide); call sites training_cvs.py:152,236;
  * models/mechanistic_cvs.py:105-238 and the proc/challenge equivalents):
  *   encoder -> z = loc + scale*eps -> log q, log p -> ODE solve -> heads -> ALD/Gauss likelihood -> -ELBO (summed

@@ -44,7 +44,7 @@ EXPORTS = ["slode_version", "slode_create", "slode_destroy", "slode_last_error",
            "slode_num_stage_times", "slode_workspace_bytes", "slode_stage_times", "slode_encoder_conv_fwd",
            "slode_encoder_conv_bwd", "slode_ode_solve_fwd", "slode_ode_solve_bwd", "slode_decode_heads",
            "slode_elbo_step", "slode_adam_step", "slode_profile_enable", "slode_profile_read", "slode_dynamics_eval", "slode_elbo_adam_step", "slode_aux_step", "slode_adam_region",
-           "slode_initialize_state", "slode_prior_nets", "slode_label_heads", "slode_dopri5_step_counts"]
+           "slode_initialize_state", "slode_prior_nets", "slode_label_heads", "slode_dopri5_step_counts", "slode_decode_heads_bwd"]
 
 _lib = None
 
@@ -83,6 +83,7 @@ def load():
     lib.slode_ode_solve_fwd.argtypes = [VP, P(Shape), P(Layout), VP, VP, VP, VP, VP, VP]
     lib.slode_ode_solve_bwd.argtypes = [VP, P(Shape), P(Layout), VP, VP, VP, VP, VP, VP, VP, VP, C.c_size_t, VP]
     lib.slode_decode_heads.argtypes = [VP, P(Shape), P(Layout), VP, VP, VP, VP, VP]
+    lib.slode_decode_heads_bwd.argtypes = [VP, P(Shape), P(Layout), VP, VP, VP, VP, VP, VP, VP, VP]
     lib.slode_elbo_step.argtypes = [VP, P(Shape), P(Layout), VP, VP, VP, VP, I64P, VP, VP, VP, VP, VP, VP, VP, C.c_size_t, VP]
     lib.slode_adam_step.argtypes = [VP, C.c_int64, VP, VP, VP, VP, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64, VP]
     lib.slode_elbo_adam_step.argtypes = [VP, P(Shape), P(Layout), VP, VP, VP, VP, I64P, VP, VP, VP, VP, VP, C.c_size_t, C.c_int64, VP, VP,

@@ -166,17 +166,22 @@ __global__ void __launch_bounds__(256) weff_kernel(const float* __restrict__ pl_
 }
 
 // ---- forward: hid = tanh(W_eff x + b_eff), heads --------------------------------------------------------------------
+// TB trajectories per 1024-thread block (4, or 8 for large batches: every block streams the whole W_eff -- 120 KB at the metric shape --
+// so at B = 4096 the 1024 blocks of the 4-trajectory form pull 160 MB through the L2s: 30 us; twice the trajectories per block halve it)
+template <int TB>
 __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__ pl_x, const float* __restrict__ pl_zloc_w, const float* __restrict__ pl_zls_w,
                                                        const float* __restrict__ pl_beff, const float* __restrict__ pl_weff, const FoldK k) {
+  static_assert(TB % TBE == 0, "sets of four trajectories (wave_sum16 reduces RB x 4 partial sums)");
+  constexpr int NSET = TB / TBE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, NT = blockDim.x, CT = k.CT, Hc = k.Hc, L = k.L;
-  float* s_x = smem;                 // [TBE][CT]   raw rows in memory order (= kappa order)
-  float* s_hid = s_x + TBE * CT;     // [TBE][64]
-  float* s_hw = s_hid + TBE * 64;    // [2][L][Hc]
+  float* s_x = smem;                 // [TB][CT]   raw rows in memory order (= kappa order)
+  float* s_hid = s_x + TB * CT;      // [TB][64]
+  float* s_hw = s_hid + TB * 64;     // [2][L][Hc]
   float* s_be = s_hw + 2 * L * Hc;   // [64] b_eff
-  const int b0 = blockIdx.x * TBE;
+  const int b0 = blockIdx.x * TB;
   STAMP(8);
-  for (int e = tid; e < TBE * CT; e += NT) {
+  for (int e = tid; e < TB * CT; e += NT) {
     const int tb = e / CT;
     s_x[e] = pl_x[(long long)min(b0 + tb, k.B - 1) * CT + (e - tb * CT)];
   }
@@ -189,11 +194,11 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
     const int ngroups = (Hc + RB - 1) / RB;
     for (int g = wave; g < ngroups; g += nw) {
       const int m0 = g * RB;
-      float acc[RB * TBE];   // [r][tb] flattened: wave_sum16 reduces it in place
+      float acc[NSET][RB * TBE];   // [set][r][tb] flattened: wave_sum16 reduces each set in place
 #pragma unroll
-      for (int r = 0; r < RB; ++r)
+      for (int st = 0; st < NSET; ++st)
 #pragma unroll
-        for (int tb = 0; tb < TBE; ++tb) acc[r * TBE + tb] = 0.f;
+        for (int i = 0; i < RB * TBE; ++i) acc[st][i] = 0.f;
       const float* wrow[RB];
 #pragma unroll
       for (int r = 0; r < RB; ++r) wrow[r] = pl_weff + (long long)min(m0 + r, Hc - 1) * CT;
@@ -212,14 +217,16 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
             const bool in = i0 + 128 * u < CT;
             const int i = min(i0 + 128 * u, CT - 2);
 #pragma unroll
-            for (int tb = 0; tb < TBE; ++tb) {
-              const float2 pv = *reinterpret_cast<const float2*>(s_x + tb * CT + i);
+            for (int st = 0; st < NSET; ++st)
 #pragma unroll
-              for (int r = 0; r < RB; ++r) {
-                const float wx = in ? w[r][u].x : 0.f, wy = in ? w[r][u].y : 0.f;
-                acc[r * TBE + tb] = fmaf(wy, pv.y, fmaf(wx, pv.x, acc[r * TBE + tb]));
+              for (int tb = 0; tb < TBE; ++tb) {
+                const float2 pv = *reinterpret_cast<const float2*>(s_x + (st * TBE + tb) * CT + i);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                  const float wx = in ? w[r][u].x : 0.f, wy = in ? w[r][u].y : 0.f;
+                  acc[st][r * TBE + tb] = fmaf(wy, pv.y, fmaf(wx, pv.x, acc[st][r * TBE + tb]));
+                }
               }
-            }
           }
         }
       } else {
@@ -228,16 +235,19 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
           for (int r = 0; r < RB; ++r) {
             const float w = wrow[r][i];
 #pragma unroll
-            for (int tb = 0; tb < TBE; ++tb) acc[r * TBE + tb] = fmaf(w, s_x[tb * CT + i], acc[r * TBE + tb]);
+            for (int st = 0; st < NSET; ++st)
+#pragma unroll
+              for (int tb = 0; tb < TBE; ++tb) acc[st][r * TBE + tb] = fmaf(w, s_x[(st * TBE + tb) * CT + i], acc[st][r * TBE + tb]);
           }
         }
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the reduction's temporaries out of the load/FMA phase (spills otherwise)
       STAMP(12);
       static_assert(RB * TBE == 16, "wave_sum16 reduces RB x TBE = 16 partial sums");
-      const float v = wave_sum16(acc, lane);
-      {
-        const int idx = (lane >> 2) & 15, r = idx / TBE, tb = idx - r * TBE;
+#pragma unroll
+      for (int st = 0; st < NSET; ++st) {
+        const float v = wave_sum16(acc[st], lane);
+        const int idx = (lane >> 2) & 15, r = idx / TBE, tb = st * TBE + (idx - r * TBE);
         const int mm = min(m0 + r, Hc - 1);
         const float hv = tanhf(v + s_be[mm]);
         if ((lane & 3) == 0 && m0 + r < Hc) {
@@ -250,8 +260,8 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
   }
   __syncthreads();
   STAMP(10);
-  for (int e = tid; e < TBE * L * 2; e += NT) {
-    const int which = e / (TBE * L), r = e - which * (TBE * L);
+  for (int e = tid; e < TB * L * 2; e += NT) {
+    const int which = e / (TB * L), r = e - which * (TB * L);
     const int tb = r / L, l = r - tb * L;
     const float* W = s_hw + which * L * Hc;
     float acc = which ? k.zls_b[l] : k.zloc_b[l];
@@ -607,9 +617,15 @@ hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream) {
     if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)weff_kernel<SLODE_MAX_K + SLODE_MAX_P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
     SLODE_LAUNCH("weff", (weff_kernel<SLODE_MAX_K + SLODE_MAX_P>), dim3(nb_w + nb_r), dim3(256), wlds, stream, k.conv_w, k.lin_w, k, stage_rows);
   }
-  const size_t lds = sizeof(float) * ((size_t)TBE * k.CT + TBE * 64 + 2 * (size_t)k.L * k.Hc + 64);
-  (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  SLODE_LAUNCH("enc_fwd2", enc_fwd2_kernel, dim3((k.B + TBE - 1) / TBE), dim3(FNT), lds, stream, k.x, k.zloc_w, k.zls_w, k.beff, k.weff, k);
+  const int TB = k.B >= 2048 ? 2 * TBE : TBE;   // (a batch that fills the chip several times over: fewer, fatter blocks)
+  const size_t lds = sizeof(float) * ((size_t)TB * k.CT + TB * 64 + 2 * (size_t)k.L * k.Hc + 64);
+  if (TB == TBE) {
+    (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel<TBE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SLODE_LAUNCH("enc_fwd2", enc_fwd2_kernel<TBE>, dim3((k.B + TB - 1) / TB), dim3(FNT), lds, stream, k.x, k.zloc_w, k.zls_w, k.beff, k.weff, k);
+  } else {
+    (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel<2 * TBE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SLODE_LAUNCH("enc_fwd2", enc_fwd2_kernel<2 * TBE>, dim3((k.B + TB - 1) / TB), dim3(FNT), lds, stream, k.x, k.zloc_w, k.zls_w, k.beff, k.weff, k);
+  }
   return hipGetLastError();
 }
 

@@ -97,6 +97,51 @@ __global__ void decode_heads_kernel(const float* __restrict__ x, const float* __
   mu[i] = acc;
 }
 
+// Backward of decode_heads_kernel (the materialising recon API; autograd through Decoder.forward, models/decoders.py:42-54):
+//   g_x[b,t,s] = sum_{q,c} g_mu[q,b,c,t] W_q[c,s]   (thread per (b,t));   g_cstd[c,t] = g_std[c,t] sigmoid(constant_std[c,t])
+__global__ void decode_heads_bwd_x_kernel(const float* __restrict__ g_mu, const float* __restrict__ g_std, const float* __restrict__ params,
+                                          int B, int T, int C, int S, int Q, int h0, int h1, int h2, int cstd_off, float* __restrict__ g_x,
+                                          float* __restrict__ g_cstd) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g_cstd && i < (long long)C * T) g_cstd[i] = g_std ? g_std[i] / (1.f + expf(-params[cstd_off + i])) : 0.f;
+  if (i >= (long long)B * T) return;
+  const int t = i % T, b = i / T;
+  float acc[SLODE_MAX_S];
+#pragma unroll
+  for (int s = 0; s < SLODE_MAX_S; ++s) acc[s] = 0.f;
+  for (int q = 0; q < Q; ++q) {
+    const float* W = params + (q == 0 ? h0 : (q == 1 ? h1 : h2));
+    for (int c = 0; c < C; ++c) {
+      const float g = g_mu[(((long long)q * B + b) * C + c) * T + t];
+#pragma unroll
+      for (int s = 0; s < SLODE_MAX_S; ++s)
+        if (s < S) acc[s] = fmaf(g, W[c * S + s], acc[s]);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < SLODE_MAX_S; ++s)
+    if (s < S) g_x[i * S + s] = acc[s];
+}
+//   g_W[q][c][s] = sum_{b,t} g_mu[q,b,c,t] x[b,t,s]: one block per entry, fixed per-thread order + fixed tree => bitwise reproducible
+__global__ void __launch_bounds__(256) decode_heads_bwd_w_kernel(const float* __restrict__ g_mu, const float* __restrict__ x, int B, int T,
+                                                                  int C, int S, float* __restrict__ g_w) {
+  __shared__ float s_red[4];
+  const int e = blockIdx.x, s = e % S, c = (e / S) % C, q = e / (S * C);
+  float a0 = 0.f, a1 = 0.f;
+  const long long n = (long long)B * T;
+  for (long long i = threadIdx.x; i < n; i += 512) {
+    const long long i1 = i + 256;
+    const int b0 = i / T, t0 = i - (long long)b0 * T;
+    a0 = fmaf(g_mu[(((long long)q * B + b0) * C + c) * T + t0], x[i * S + s], a0);
+    if (i1 < n) {
+      const int b1 = i1 / T, t1 = i1 - (long long)b1 * T;
+      a1 = fmaf(g_mu[(((long long)q * B + b1) * C + c) * T + t1], x[i1 * S + s], a1);
+    }
+  }
+  const float v = block_sum(a0 + a1, s_red);
+  if (threadIdx.x == 0) g_w[e] = v;
+}
+
 // One evaluation of the dynamics net, OdeFunc.forward(t, state) -> dx/dt = a(t,z) - d(t,z) * state
 // (models/blackbox_ode.py:57-61,97-109).  Thread per trajectory; API-completeness kernel (the solver never calls it).
 __global__ void dynamics_eval_kernel(const float* __restrict__ params, int wh, int bh, int wg, int bg, int wd, int bd, int B, int L,
@@ -264,6 +309,17 @@ hipError_t slode_launch_decode_heads(const slode_shape& s, const slode_layout& l
   if (total < (long long)s.C * s.T) total = (long long)s.C * s.T;
   hipLaunchKernelGGL(decode_heads_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, params, s.B, s.T,
                      s.C, s.S, Q, lay.head_w[0], lay.head_w[1], lay.head_w[2], lay.cstd, mu, std_ct);
+  return hipGetLastError();
+}
+
+hipError_t slode_launch_decode_heads_bwd(const slode_shape& s, const slode_layout& lay, const float* params, const float* x, const float* g_mu,
+                                         const float* g_std, float* g_x, float* g_heads, float* g_cstd, hipStream_t stream) {
+  const int Q = s.likelihood == SLODE_GAUSS ? 1 : 3;
+  long long n = (long long)s.B * s.T;
+  if (n < (long long)s.C * s.T) n = (long long)s.C * s.T;
+  hipLaunchKernelGGL(decode_heads_bwd_x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g_mu, g_std, params, s.B, s.T, s.C, s.S, Q,
+                     lay.head_w[0], lay.head_w[1], lay.head_w[2], lay.cstd, g_x, g_cstd);
+  hipLaunchKernelGGL(decode_heads_bwd_w_kernel, dim3(Q * s.C * s.S), dim3(256), 0, stream, g_mu, x, s.B, s.T, s.C, s.S, g_heads);
   return hipGetLastError();
 }
 

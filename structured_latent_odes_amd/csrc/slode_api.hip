@@ -393,6 +393,15 @@ int slode_decode_heads(slode_handle h, const slode_shape* s, const slode_layout*
   return SLODE_OK;
 }
 
+int slode_decode_heads_bwd(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* x,
+                           const float* g_mu, const float* g_std, float* g_x, float* g_heads, float* g_cstd, void* stream) {
+  const char* why = check_common(h, s, lay, params);
+  if (why) return fail(h, SLODE_EINVAL, "%s", why);
+  if (!x || !g_mu || !g_x || !g_heads) return fail(h, SLODE_EINVAL, "x / g_mu / g_x / g_heads is NULL");
+  HIP_TRY(h, slode_launch_decode_heads_bwd(*s, *lay, params, x, g_mu, g_std, g_x, g_heads, g_cstd, (hipStream_t)stream));
+  return SLODE_OK;
+}
+
 struct AdamArgs { float *p, *m, *v; float lr, b1, b2, eps; int64_t step, n; };
 
 static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* times,

@@ -377,6 +377,8 @@ hipError_t slode_launch_reduce(const ReduceLaunch& a, hipStream_t stream);
 hipError_t slode_launch_stage_times(const slode_shape& s, const float* times, float* stage_t, hipStream_t stream);
 hipError_t slode_launch_decode_heads(const slode_shape& s, const slode_layout& lay, const float* params,
                                      const float* x, float* mu, float* std_ct, hipStream_t stream);
+hipError_t slode_launch_decode_heads_bwd(const slode_shape& s, const slode_layout& lay, const float* params, const float* x, const float* g_mu,
+                                         const float* g_std, float* g_x, float* g_heads, float* g_cstd, hipStream_t stream);
 hipError_t slode_launch_init_state(const slode_shape& s, const slode_layout& lay, const float* params, const float* z, float* x0, hipStream_t stream);
 hipError_t slode_launch_prior_nets(const slode_shape& s, const slode_layout& lay, const float* params, const float* u, float* loc, float* scale,
                                    hipStream_t stream);

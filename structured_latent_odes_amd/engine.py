@@ -331,6 +331,19 @@ class Engine:
             self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._f32(x, "x")), self._p(mu), self._p(std), self._stream()))
         return mu, std
 
+    def decode_heads_bwd(self, params, x, g_mu, g_std=None):
+        """Backward of decode_heads: g_mu [Q, B, C, T] (+ g_std [C, T]) -> (g_x [B, T, S], g_heads [Q, C, S], g_cstd [C, T])."""
+        B = x.shape[0]
+        sp = self.spec
+        Q = 1 if sp.gauss else 3
+        g_x = torch.empty(B, self.T, sp.ode_state_dim, dtype=torch.float32, device=self.device)
+        g_heads = torch.empty(Q, sp.n_channels, sp.ode_state_dim, dtype=torch.float32, device=self.device)
+        g_cstd = torch.empty(sp.n_channels, self.T, dtype=torch.float32, device=self.device)
+        _check(self.lib, self.handle, self.lib.slode_decode_heads_bwd(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._f32(x, "x")), self._p(self._f32(g_mu, "g_mu")),
+            self._p(self._f32(g_std, "g_std") if g_std is not None else None), self._p(g_x), self._p(g_heads), self._p(g_cstd), self._stream()))
+        return g_x, g_heads, g_cstd
+
     def elbo_step(self, params, obs, u, eps, loss_out, grads=None, x_out=None, z_out=None):
         """-ELBO (summed over the batch) into loss_out[0]; exact gradient into grads (flat) unless grads is None."""
         B = obs.shape[0]

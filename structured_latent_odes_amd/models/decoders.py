@@ -12,26 +12,29 @@ from .blackbox_ode import OdeModel
 
 
 class _HeadsFn(torch.autograd.Function):
-    """Heads + softplus std.  Forward = ``slode_decode_heads``; the backward of this materialising API (not on the fused
-    training path) is three small einsums."""
+    """Heads + softplus std.  Forward = ``slode_decode_heads``, backward = ``slode_decode_heads_bwd`` (the materialising API; the fused
+    training path never comes through here)."""
 
     @staticmethod
     def forward(ctx, dec, x, cstd, *heads):
         b = dec.ode_model._binding_or_raise()
-        mu, std = b.engine.decode_heads(b.flat, x.contiguous())
-        ctx.save_for_backward(x, cstd, *heads)
+        x = x.contiguous()
+        mu, std = b.engine.decode_heads(b.flat, x)
+        ctx.binding = b
+        ctx.save_for_backward(x)
+        ctx.mu_shape = tuple(mu.shape)
         return (std, *[mu[i] for i in range(mu.shape[0])])
 
     @staticmethod
     def backward(ctx, g_std, *g_mu):
-        x, cstd, *heads = ctx.saved_tensors
-        g_x = torch.zeros_like(x)
-        g_heads = []
-        for W, g in zip(heads, g_mu):
-            g_x = g_x + torch.einsum("bct,cs->bts", g, W)
-            g_heads.append(torch.einsum("bct,bts->cs", g, x))
-        g_c = g_std * torch.sigmoid(cstd) if g_std is not None else None
-        return (None, g_x, g_c, *g_heads)
+        (x,) = ctx.saved_tensors
+        b = ctx.binding
+        stacked = torch.zeros(ctx.mu_shape, dtype=torch.float32, device=x.device)
+        for i, g in enumerate(g_mu):
+            if g is not None:
+                stacked[i].copy_(g)
+        g_x, g_heads, g_c = b.engine.decode_heads_bwd(b.flat, x, stacked, g_std.contiguous() if g_std is not None else None)
+        return (None, g_x, g_c if g_std is not None else None, *[g_heads[i] for i in range(g_heads.shape[0])])
 
 
 class _DecoderBase(nn.Module):

@@ -1,7 +1,7 @@
-"""Copies the summaries of tools/profile_r02.sh (gpurun_out/r2/prof) into profiles/ under round-2 names and derives the two small
+"""Copies the summaries of tools/profile_r03.sh (gpurun_out/r3/prof) into profiles/ under round-3 names and derives the two small
 JSON files bench.py reads (traffic and instruction counts of the dominant kernel), both keyed to the sha1 of csrc/ode_kernel.hip
 so that a stale figure is never attached to a changed kernel.
-Usage: python tools/profile_r02_collect.py [gpurun_out/r2/prof] [tag]"""
+Usage: python tools/profile_r03_collect.py [gpurun_out/r3/prof] [tag]"""
 import collections
 import csv
 import glob
@@ -12,8 +12,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r2", "prof")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02_a"
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r3", "prof")
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03_a"
 dst = os.path.join(ROOT, "profiles")
 sha = hashlib.sha1(open(os.path.join(ROOT, "structured_latent_odes_amd", "csrc", "ode_kernel.hip"), "rb").read()).hexdigest()
 KERNELS = {"weff_kernel": "fold", "enc_fwd2_kernel": "enc_fwd", "ode_elbo_kernel": "ode_elbo", "enc_bwd_lin_kernel": "gemm", "enc_chain_kernel": "chain"}
@@ -44,30 +44,49 @@ def pmc(d):
     return {k: {c: (sum(v[len(v) // 4:]) / len(v[len(v) // 4:]), len(v)) for c, v in cs.items()} for k, cs in out.items()}
 
 
-ab = {"source_sha1_ode_kernel_hip": sha, "workload": "bench.py: B=1024, T=200, rk4, fp32 (BASELINE config[1])", "arms": {}}
-for alg in (0, 1, 2):
-    d = os.path.join(src, "stats_alg%d" % alg)
-    rows = stats(d)
-    if not rows:
-        continue
-    with open(os.path.join(dst, "%s_alg%d_kernel_stats.csv" % (tag, alg)), "w") as fh:
+def write_stats(rows, name):
+    with open(os.path.join(dst, name), "w") as fh:
         fh.write("kernel,calls,avg_ns,min_ns,max_ns,percent\n")
         for r in sorted(rows, key=lambda r: -r[1] * r[2]):
             fh.write("%s,%d,%.1f,%.0f,%.0f,%.2f\n" % r)
-    bj = os.path.join(src, "bench_alg%d.json" % alg)
+
+
+def stats_full(d):
+    """full kernel names (template arguments tell the shapes apart)"""
+    rows = []
+    for f in glob.glob(os.path.join(d, "*", "*kernel_stats.csv")):
+        for r in csv.DictReader(open(f)):
+            nm = r["Name"].replace("(anonymous namespace)::", "").replace(",", ";")[:110]
+            rows.append((nm, int(r["Calls"]), float(r["AverageNs"]), float(r["MinNs"]), float(r["MaxNs"]), float(r["Percentage"])))
+    return rows
+
+
+ab = {"source_sha1_ode_kernel_hip": sha, "workload": "bench.py --no-other-configs --no-run-batch: B=1024, T=200, rk4, fp32 (BASELINE config[1])", "arms": {}}
+rows = stats(os.path.join(src, "stats_main"))
+if rows:
+    write_stats(rows, "%s_main_kernel_stats.csv" % tag)
+    bj = os.path.join(src, "bench_main.json")
     if os.path.exists(bj):
-        shutil.copy(bj, os.path.join(dst, "%s_alg%d_bench_under_rocprof.json" % (tag, alg)))
+        shutil.copy(bj, os.path.join(dst, "%s_main_bench_under_rocprof.json" % tag))
     ode = [r for r in rows if r[0] == "ode_elbo_kernel"]
-    arm = {"what": ARMS[alg], "ode_elbo_avg_us": round(ode[0][2] / 1e3, 2) if ode else None, "ode_elbo_calls": ode[0][1] if ode else None}
+    arm = {"what": ARMS[0], "ode_elbo_avg_us": round(ode[0][2] / 1e3, 2) if ode else None, "ode_elbo_calls": ode[0][1] if ode else None}
     for kind in ("sq", "mfma"):
-        p = pmc(os.path.join(src, "pmc_%s_alg%d" % (kind, alg))).get("ode_elbo_kernel")
+        p = pmc(os.path.join(src, "pmc_%s" % kind)).get("ode_elbo_kernel")
         if p:
             arm["pmc_" + kind] = {c: round(v[0], 1) for c, v in p.items()}
-    if ode and arm.get("pmc_mfma", {}).get("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
-        # MFMA utilisation = matrix-pipe busy cycles / (kernel duration x 1024 SIMDs x 2.4 GHz)
-        arm["mfma_util"] = round(arm["pmc_mfma"]["SQ_VALU_MFMA_BUSY_CYCLES"] / (ode[0][2] * 1e-9 * 1024 * 2.4e9), 4)
-    ab["arms"]["alg%d" % alg] = arm
+    ab["arms"]["alg0"] = arm
 json.dump(ab, open(os.path.join(dst, "%s_ode_elbo_ab.json" % tag), "w"), indent=1)
+for sub, name in (("stats_full", "full_bench"), ("stats_config0", "config0"), ("stats_rk4fixed", "config2_rk4"), ("stats_dopri5", "config2_dopri5"),
+                  ("stats_config4", "config4")):
+    rows = stats_full(os.path.join(src, sub))
+    if rows:
+        write_stats(rows, "%s_%s_kernel_stats.csv" % (tag, name))
+for f in ("bench_full.json",):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, "%s_%s" % (tag, f.replace("bench_full", "full_bench_under_rocprof"))))
+for f, name in (("bench_config0.jsonl", "config0"), ("bench_rk4fixed.jsonl", "config2_rk4"), ("bench_dopri5.jsonl", "config2_dopri5"), ("bench_config4.jsonl", "config4")):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, "%s_%s_bench_under_rocprof.jsonl" % (tag, name)))
 
 fetch, write = pmc(os.path.join(src, "pmc_fetch")), pmc(os.path.join(src, "pmc_write"))
 traffic = {"source_sha1_ode_kernel_hip": sha,
@@ -80,13 +99,12 @@ for k, dom in KERNELS.items():
         traffic[dom] = {"FETCH_SIZE_KB_avg": round(f, 1), "WRITE_SIZE_KB_avg": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
 json.dump(traffic, open(os.path.join(dst, "%s_pmc_traffic.json" % tag), "w"), indent=1)
 for kind in ("sq", "mfma"):
-    for alg in (0, 2):
-        p = pmc(os.path.join(src, "pmc_%s_alg%d" % (kind, alg)))
-        if p:
-            with open(os.path.join(dst, "%s_alg%d_pmc_%s.csv" % (tag, alg, kind)), "w") as fh:
-                fh.write("kernel,counter,launches,avg_value\n")
-                for kn, cs in sorted(p.items()):
-                    for c, (v, n) in sorted(cs.items()):
-                        fh.write("%s,%s,%d,%.1f\n" % (kn, c, n, v))
+    p = pmc(os.path.join(src, "pmc_%s" % kind))
+    if p:
+        with open(os.path.join(dst, "%s_pmc_%s.csv" % (tag, kind)), "w") as fh:
+            fh.write("kernel,counter,launches,avg_value\n")
+            for kn, cs in sorted(p.items()):
+                for c, (v, n) in sorted(cs.items()):
+                    fh.write("%s,%s,%d,%.1f\n" % (kn, c, n, v))
 print(json.dumps(ab, indent=1)[:1500])
 print(json.dumps({k: v.get("hbm_bytes_per_launch") for k, v in traffic.items() if isinstance(v, dict)}))
