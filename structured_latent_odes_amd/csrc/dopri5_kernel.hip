@@ -24,6 +24,7 @@
 // time (grp::sweep_sample).  A workgroup's 16 trajectories are summed in a fixed order into one slab row in the
 // layout of the fixed-grid kernel's slabs (reduced by the same deterministic tail).
 #include "slode_common.h"
+#include <cstddef>
 
 namespace {
 
@@ -464,6 +465,11 @@ struct DpBK {
   float* snap;                 // [B][H][4S] running sums parked when the sweep passes a switching time, by RANK (see grp::sweep_sample)
   int slab_stride, nseg, stage_gx;
   int o_w1, o_b1, o_w2, o_b2, o_wh, o_bh, o_wg, o_bg, o_wd, o_bd;
+  // folded encoder path: once the latent gradient is complete the kernel also runs the encoder heads + tanh backward of its trajectories
+  // (g_pre [B][64], glat [B][128] = [g_loc | pad | g_scale * scale | pad]; see ode_elbo_kernel) -- g_pre == nullptr: not wanted
+  const float *scale, *enc_hid, *enc_zloc_w, *enc_zls_w;
+  float *g_pre, *glat;
+  int Hc, zw_off;   // zw_off: floats from s_big to the dedicated [2][L][Hc] copy of the encoder head weights
 };
 
 namespace grp {
@@ -523,6 +529,29 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   const int gs = own ? g : 0;
   float* row = k.slabs + (long long)blockIdx.x * k.slab_stride;
   float* prm = row + 1;
+  {   // encoder head weights for the epilogue: LDS-DMA now, awaited with the dL/dx rows (the sweep hides both).  (These kernel arguments
+      // are read through an opaque copy of the kernel-argument pointer, here and in the epilogue: see there.)
+    typedef const __attribute__((address_space(4))) char* kaptr;
+    typedef float* fptr_t;
+    typedef const float* cfptr_t;
+    kaptr ka = (kaptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+#define DP5_KFIELD(T, name) (*(const __attribute__((address_space(4))) T*)(ka + offsetof(DpBK, name)))
+    if (DP5_KFIELD(fptr_t, g_pre) != nullptr) {
+      const float* const zl = DP5_KFIELD(cfptr_t, enc_zloc_w);
+      const float* const zs = DP5_KFIELD(cfptr_t, enc_zls_w);
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, NW = BNT >> 6, n = L * DP5_KFIELD(int, Hc);
+      float* s_zw = s_big + DP5_KFIELD(int, zw_off);
+      for (int b0 = wv * 64; b0 < n; b0 += NW * 64)
+        if (b0 + lane < n) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(zl + b0 + lane),
+                                           (__attribute__((address_space(3))) void*)(s_zw + b0), 4, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(zs + b0 + lane),
+                                           (__attribute__((address_space(3))) void*)(s_zw + n + b0), 4, 0, 0);
+        }
+    }
+#undef DP5_KFIELD
+  }
   if (k.stage_gx) {
     // The workgroup's BTP rows of dL/dx are one contiguous block: global -> LDS by LDS-DMA (global_load_lds, 16 bytes per lane, 1 KB per
     // wave instruction, no registers), issued before anything else and awaited only right before the sweep -- the whole set-up hides it.
@@ -861,6 +890,71 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
       }
     }
   }
+  {
+    // ---- encoder heads + tanh, backward (models/encoder_conv.py:48-51) for the workgroup's trajectories: their latent gradient is
+    // final now (the stores above are this workgroup's own; the barrier orders them).  W1 | W_z in s_big are dead.
+    // The epilogue's own kernel arguments are read HERE, through the kernel-argument pointer, behind an opaque copy of it, so that they
+    // are not live across the sweep.  (Round 3, config[2]: with this epilogue the kernel takes 138 us instead of 125 and spills 61
+    // SGPRs instead of 33; reading the fields late did not change either figure -- the step as a whole is still 7 us faster than with
+    // the separate encoder-head launch, slab_stage1 and reduce launches this replaces.)
+    typedef const __attribute__((address_space(4))) char* kaptr;
+    kaptr ka = (kaptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    typedef float* fptr_t;
+    typedef const float* cfptr_t;
+#define DP5_KFIELD(T, name) (*(const __attribute__((address_space(4))) T*)(ka + offsetof(DpBK, name)))
+    float* const e_g_pre = DP5_KFIELD(fptr_t, g_pre);
+    if (e_g_pre != nullptr) {
+      const float* const e_hid = DP5_KFIELD(cfptr_t, enc_hid);
+      const float* const e_scale = DP5_KFIELD(cfptr_t, scale);
+      const float* const e_gloc = DP5_KFIELD(fptr_t, g_loc);
+      const float* const e_gscale = DP5_KFIELD(fptr_t, g_scale);
+      float* const e_glat = DP5_KFIELD(fptr_t, glat);
+      const int Hc = DP5_KFIELD(int, Hc), zw_off = DP5_KFIELD(int, zw_off), eB = DP5_KFIELD(int, B);
+#undef DP5_KFIELD
+      __syncthreads();
+      const float* s_zw = s_big + zw_off;     // [2][L][Hc]  z_loc.weight | z_scale.0.weight (in place since the prologue)
+      float* s_g = s_big;                     // [BTP][2][L] dLoss/dloc | dLoss/dscale * scale
+      for (int i = tid; i < BTP * L; i += BNT) {
+        const int r = i / L, l = i - r * L;
+        const long long b2 = (long long)blockIdx.x * BTP + r;
+        float gl = 0.f, gs = 0.f;
+        if (b2 < eB) {
+          gl = e_gloc[b2 * L + l];
+          gs = e_gscale[b2 * L + l] * e_scale[b2 * L + l];
+          e_glat[b2 * 128 + l] = gl;
+          e_glat[b2 * 128 + 64 + l] = gs;
+        }
+        s_g[(2 * r) * L + l] = gl;
+        s_g[(2 * r + 1) * L + l] = gs;
+      }
+      __syncthreads();
+      // item (hidden unit mm, half rq of the trajectories): the unit's two weights per latent dim are read once for eight trajectories
+      constexpr int RQ = BTP / 2;
+      for (int item = tid; item < 2 * Hc; item += BNT) {
+        const int rq = item / Hc, mm = item - rq * Hc;
+        float g0[RQ];
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) g0[q] = 0.f;
+        for (int l = 0; l < L; ++l) {
+          const float w0 = s_zw[l * Hc + mm], w1 = s_zw[(L + l) * Hc + mm];
+#pragma unroll
+          for (int q = 0; q < RQ; ++q) {
+            const int r = rq * RQ + q;
+            g0[q] = fmaf(w0, s_g[(2 * r) * L + l], fmaf(w1, s_g[(2 * r + 1) * L + l], g0[q]));
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) {
+          const long long b2 = (long long)blockIdx.x * BTP + rq * RQ + q;
+          if (b2 < eB) {
+            const float hv = e_hid[b2 * Hc + mm];
+            e_g_pre[b2 * 64 + mm] = g0[q] * (1.f - hv * hv);
+          }
+        }
+      }
+    }
+  }
 }
 
 }  // namespace grp
@@ -896,8 +990,10 @@ hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, co
 
 hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay, const float* p, const float* times, const DopriRec& rec,
                                    const float* gx, float* g_loc, float* g_scale, float* slabs, int slab_stride, int drop_z, float* snap,
-                                   hipStream_t stream) {
+                                   hipStream_t stream, const float* enc_hid, float* g_pre, float* glat) {
   DpBK k;
+  k.scale = rec.scale; k.enc_hid = enc_hid; k.g_pre = g_pre; k.glat = glat; k.Hc = s.Hc;
+  k.enc_zloc_w = p + lay.zloc_w; k.enc_zls_w = p + lay.zls_w;
   k.snap = snap; k.g_loc = g_loc; k.g_scale = g_scale; k.eps = rec.eps;
   k.B = s.B; k.T = s.T; k.L = s.L; k.kmax = rec.kmax; k.drop_z = drop_z;
   k.times = times; k.z = rec.z_out; k.gx = gx; k.rec = rec.rec; k.nrec = rec.nrec;
@@ -914,9 +1010,14 @@ hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay
     const size_t fixed = (size_t)GroupLds<25>::floats(BTP) + (size_t)BTP * 32 * 3 + BTP * 8 + (size_t)BTP * s.L + (size_t)((s.T + 3) & ~3);
     const size_t tile = (size_t)(s.H + 1) * (2 * s.S + 2) * TS, wz = 2 * (size_t)s.H * s.L, gxrows = (size_t)BTP * s.T * s.S;
     size_t big = tile > wz ? tile : wz;
-    k.stage_gx = sizeof(float) * (fixed + (gxrows > big ? gxrows : big)) <= 160 * 1024 ? 1 : 0;   // dL/dx rows in LDS when they fit
+    const size_t encb = g_pre ? 2 * (size_t)BTP * s.L : 0;   // the rows' latent gradients (epilogue)
+    if (encb > big) big = encb;
+    const size_t zwf = g_pre ? 2 * (size_t)s.L * s.Hc : 0;   // dedicated copy of the encoder head weights (fused encoder-head backward)
+    k.stage_gx = sizeof(float) * (fixed + zwf + (gxrows > big ? gxrows : big)) <= 160 * 1024 ? 1 : 0;   // dL/dx rows in LDS when they fit
     if (k.stage_gx && gxrows > big) big = gxrows;
-    const size_t lds = sizeof(float) * (fixed + big);
+    big = (big + 3) & ~(size_t)3;
+    k.zw_off = (int)big;
+    const size_t lds = sizeof(float) * (fixed + big + zwf);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (s.H == 25 && s.S == 5) {
       (void)hipFuncSetAttribute((const void*)grp::dopri5_bwd_kernel<5, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

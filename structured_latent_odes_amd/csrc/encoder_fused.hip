@@ -275,74 +275,6 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
   STAMP(11);
 }
 
-// ---- backward part 1: heads + tanh -> g_pre; small slab = [lin_b Hc][zloc_w L*Hc][zloc_b L][zls_w L*Hc][zls_b L] -----------
-__global__ void __launch_bounds__(256) enc_bwd2_kernel(const FoldK k) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, NT = blockDim.x, Hc = k.Hc, L = k.L;
-  float* s_hid = smem;               // [TBE][64]
-  float* s_gl = s_hid + TBE * 64;    // [TBE][L]
-  float* s_gs = s_gl + TBE * L;      // [TBE][L]
-  float* s_gpre = s_gs + TBE * L;    // [TBE][64]
-  float* s_hw = s_gpre + TBE * 64;   // [2][L][Hc]
-  const int b0 = blockIdx.x * TBE;
-  float* slab = k.slabs + (long long)blockIdx.x * k.small_stride;
-  const int o_linb = 0, o_zlw = Hc, o_zlb = o_zlw + L * Hc, o_zsw = o_zlb + L, o_zsb = o_zsw + L * Hc;
-  for (int e = tid; e < 2 * L * Hc; e += NT) s_hw[e] = (e < L * Hc) ? k.zloc_w[e] : k.zls_w[e - L * Hc];
-  for (int e = tid; e < TBE * L; e += NT) {
-    const int tb = e / L, l = e - tb * L, b = min(b0 + tb, k.B - 1);
-    const bool ok = b0 + tb < k.B;
-    const float gl = k.g_loc[(long long)b * L + l], gs = k.g_scale[(long long)b * L + l] * k.scale_in[(long long)b * L + l];
-    s_gl[e] = ok ? gl : 0.f;
-    s_gs[e] = ok ? gs : 0.f;
-  }
-  for (int e = tid; e < TBE * 64; e += NT) {
-    const int tb = e >> 6, mm = e & 63, b = min(b0 + tb, k.B - 1);
-    const float hv = k.hid_in[(long long)b * Hc + min(mm, Hc - 1)];
-    s_hid[e] = (b0 + tb < k.B && mm < Hc) ? hv : 0.f;
-  }
-  __syncthreads();
-  for (int e = tid; e < TBE * 64; e += NT) {
-    const int tb = e >> 6, mm = e & 63;
-    float g = 0.f;
-    if (mm < Hc) {
-#pragma unroll 4
-      for (int l = 0; l < L; ++l) {
-        g = fmaf(s_hw[l * Hc + mm], s_gl[tb * L + l], g);
-        g = fmaf(s_hw[(L + l) * Hc + mm], s_gs[tb * L + l], g);
-      }
-      const float hv = s_hid[tb * 64 + mm];
-      g *= (1.f - hv * hv);
-    }
-    s_gpre[e] = g;
-    if (b0 + tb < k.B) k.g_pre[(long long)(b0 + tb) * 64 + mm] = g;
-  }
-  for (int e = tid; e < L * Hc; e += NT) {
-    const int l = e / Hc, mm = e - l * Hc;
-    float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-    for (int tb = 0; tb < TBE; ++tb) {
-      a1 = fmaf(s_gl[tb * L + l], s_hid[tb * 64 + mm], a1);
-      a2 = fmaf(s_gs[tb * L + l], s_hid[tb * 64 + mm], a2);
-    }
-    slab[o_zlw + e] = a1;
-    slab[o_zsw + e] = a2;
-  }
-  for (int l = tid; l < L; l += NT) {
-    float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-    for (int tb = 0; tb < TBE; ++tb) { a1 += s_gl[tb * L + l]; a2 += s_gs[tb * L + l]; }
-    slab[o_zlb + l] = a1;
-    slab[o_zsb + l] = a2;
-  }
-  __syncthreads();
-  for (int mm = tid; mm < Hc; mm += NT) {
-    float a = 0.f;
-#pragma unroll
-    for (int tb = 0; tb < TBE; ++tb) a += s_gpre[tb * 64 + mm];
-    slab[o_linb + mm] = a;
-  }
-}
-
 // ---- backward part 3: chain rule from G = dLoss/dW_eff back to lin.weight (final) and conv.{weight,bias} (per-m partials) ---
 // One 1024-thread workgroup per hidden unit m.  G's columns [0, CT) are dLoss/dW_eff[m][:], column CT is g_beff[m] = sum_b g_pre[b][m]
 // (the MFMA GEMM appends a ones-column to X), both summed here over the split-K partials in fixed order.
@@ -626,13 +558,6 @@ hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel<2 * TBE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     SLODE_LAUNCH("enc_fwd2", enc_fwd2_kernel<2 * TBE>, dim3((k.B + TB - 1) / TB), dim3(FNT), lds, stream, k.x, k.zloc_w, k.zls_w, k.beff, k.weff, k);
   }
-  return hipGetLastError();
-}
-
-hipError_t slode_launch_fold_bwd_heads(const FoldLaunch& a, hipStream_t stream) {
-  FoldK k = make_foldk(a);
-  const size_t lds = sizeof(float) * (2 * (size_t)TBE * 64 + 2 * (size_t)TBE * k.L + 2 * (size_t)k.L * k.Hc);
-  SLODE_LAUNCH("enc_bwd2", enc_bwd2_kernel, dim3((k.B + TBE - 1) / TBE), dim3(256), lds, stream, k);
   return hipGetLastError();
 }
 

@@ -536,18 +536,6 @@ size_t enc_bwd_lds(const EncK& k) {
 
 }  // namespace
 
-hipError_t slode_launch_gemm_gpre_x(const float* g_pre, const float* x, float* slabs, int B, int Hc, int N, int splitk, hipStream_t stream) {
-  const int total_splits = splitk * 4;
-  int per_wave = (B + total_splits - 1) / total_splits;
-  per_wave = (per_wave + 1) & ~1;
-  // N real columns + one ones-column (index N): the grid covers N + 1 output columns
-  GemmProbs ps{};
-  ps.p[0] = GemmProb{g_pre, 64, x, slabs, Hc, N, (N + 1 + 31) / 32};
-  ps.n_gemm_x = ps.p[0].ntiles;
-  SLODE_LAUNCH("enc_bwd_lin", enc_bwd_lin_kernel, dim3(ps.p[0].ntiles, splitk), dim3(256), 0, stream, ps.p[0].A, ps.p[0].X, ps, B, per_wave, 1);
-  return hipGetLastError();
-}
-
 hipError_t slode_launch_gemm_tail(const float* g_pre, const float* x, float* gslabs, int Hc, int CT, const float* glat, const float* hid,
                                   float* gslabs_loc, float* gslabs_ls, int L, int B, int splitk, const float* ode_slabs, int ode_stride,
                                   int ode_n, int ode_count, float* ode_part, const float** ode_part_out, int* ode_n_out,

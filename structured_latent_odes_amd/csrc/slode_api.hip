@@ -491,12 +491,14 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     if (dp5 && bwd) {
       DopriRec rc{w.loc, w.scale, eps, w.dp_z, w.dp_rec, w.dp_nrec, w.dp_kmax};
       HIP_TRY(h, slode_launch_dopri5_bwd(*s, *lay, params, times, rc, w.dp_gx, w.g_loc, w.g_scale, w.ode_slabs + (size_t)w.ode_grid * w.ode_stride,
-                                         w.ode_stride, s->grad_mode == SLODE_GRAD_REFERENCE_ADJOINT ? 1 : 0, w.dp_snap, st));
+                                         w.ode_stride, s->grad_mode == SLODE_GRAD_REFERENCE_ADJOINT ? 1 : 0, w.dp_snap, st,
+                                         folded ? w.hid : nullptr, folded ? w.g_pre : nullptr, folded ? w.glat : nullptr));
     }
   }
 
-  if (bwd && folded && !dp5) {
-    // Fused tail.  The ODE kernel has already run the encoder heads + tanh backward (g_pre, glat): three launches remain --
+  if (bwd && folded) {
+    // Fused tail.  The ODE kernel (auxiliary step: the aux kernel; dopri5: its reverse sweep) has already run the encoder heads + tanh
+    // backward (g_pre, glat): two launches remain --
     // split-K MFMA GEMMs (+ rider blocks: stage 1 of the ODE-slab reduction), chain rule, one final reduction (+ Adam).
     AdamHost ah{};
     if (adam) {
@@ -518,16 +520,6 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     tl.grads = grads; tl.ad = make_adamk(adam ? &ah : nullptr); tl.counter = w.counter;
     fl.tail = &tl;
     HIP_TRY(h, slode_launch_fold_chain(fl, st));   // + rider blocks and the last-block conv reduction: the flat gradient is complete
-  } else if (bwd && folded) {
-    HIP_TRY(h, slode_launch_fold_bwd_heads(fl, st));
-    HIP_TRY(h, slode_launch_gemm_gpre_x(w.g_pre, obs, w.gslabs, s->B, s->Hc, (int)CT, w.gsplit, st));
-    HIP_TRY(h, slode_launch_fold_chain(fl, st));
-    ReduceLaunch r{*s, *lay, w.ode_slabs, w.ode_stride, n_slabs, w.small_slabs, w.small_stride, w.small_grid,
-                   w.conv_slabs, s->Hc, grads, loss_out, 0, w.ode_part, w.small_part, 1};
-    if (adam) { r.adam_p = adam->p; r.adam_m = adam->m; r.adam_v = adam->v; r.adam_lr = adam->lr; r.adam_b1 = adam->b1;
-                r.adam_b2 = adam->b2; r.adam_eps = adam->eps; r.adam_step = adam->step; r.adam_n = adam->n;
-                r.adam_lo2 = h->adam_lo2; r.adam_hi2 = h->adam_hi2; r.adam_delta2 = h->adam_delta2; }
-    HIP_TRY(h, slode_launch_reduce(r, st));
   } else if (bwd) {
     EncBwdLaunch eb{*s, *lay, params, obs, obs_strides[0], obs_strides[1], obs_strides[2], w.scale, w.pooled, w.hid,
                     w.g_loc, w.g_scale, w.g_pre, w.small_slabs, w.small_stride, w.small_grid, w.lin_slabs, w.lin_splitk};

@@ -326,9 +326,7 @@ struct FoldLaunch {
   const TailK* tail = nullptr;       // chain launch also finishes the whole flat gradient (+ loss, + optional Adam)
 };
 hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream);
-hipError_t slode_launch_fold_bwd_heads(const FoldLaunch& a, hipStream_t stream);
 hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream);
-hipError_t slode_launch_gemm_gpre_x(const float* g_pre, const float* x, float* slabs, int B, int Hc, int N, int splitk, hipStream_t stream);
 // The three split-K MFMA products of the fused tail in one launch, each with a ones-column appended to its right-hand matrix:
 //   gslabs[s][m < Hc][CT + 1] = g_pre^T [x | 1];  gslabs_loc[s][l < L][Hc + 1] = glat[:, 0:L]^T [hid | 1];  gslabs_ls likewise from
 //   glat[:, 64:64+L]   (g_pre: [B][64], glat: [B][128] = [g_loc | pad | g_scale * scale | pad])
@@ -392,7 +390,8 @@ int slode_dopri5_rows(const slode_shape& s);
 hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const float* z,
                                float* x, hipStream_t stream, const DopriRec* rec = nullptr);
 hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const DopriRec& rec,
-                                   const float* gx, float* g_loc, float* g_scale, float* slabs, int slab_stride, int drop_z, float* snap, hipStream_t stream);
+                                   const float* gx, float* g_loc, float* g_scale, float* slabs, int slab_stride, int drop_z, float* snap, hipStream_t stream,
+                                   const float* enc_hid = nullptr, float* g_pre = nullptr, float* glat = nullptr);
 hipError_t slode_launch_adam_k(int64_t n, const float* g, const AdamHost& a, hipStream_t stream);
 hipError_t slode_launch_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2,
                              float eps, int64_t step, hipStream_t stream);
