@@ -6,19 +6,23 @@
 //   models/blackbox_ode.py:36-47,97-109 (OdeModel.solve_ODE over Dynamics.forward via torchdiffeq.odeint),
 // and autograd's backward through all of it (== adjoint_solver=False gradients).
 //
-// Design: ONE workgroup integrates ONE trajectory at a time (persistent loop over
-// b = blockIdx.x, += gridDim.x), with NT = roundup64(T) threads.
-//   * f(t,x) = a(t,z) - d(t,z) * x never reads the state inside the net (blackbox_ode.py:97-109), so a, d are
-//     evaluated for every stage time in PARALLEL (thread n owns grid step n: its R stage evaluations stay in
-//     registers from forward to backward), weights arriving as SGPR operands through the constant address space.
-//   * every fixed-grid step collapses to the affine map x' = A x + b; the T-1 long serial dependency chain is
-//     then one v_fma per step on S lanes (forward scan) and one v_fma per step for the adjoint (reverse scan).
-//   * the exact discrete adjoint of the step coefficients is evaluated back in the step-parallel layout; the
-//     weight-gradient contraction over (sample, hidden unit) runs in a hidden-unit-major layout (lane = hidden
-//     unit j, half-wave = chunk of samples) with register accumulators, staged through a 2S*T LDS buffer.
-//   * likelihood (asymmetric Laplace x3 quantile heads, or Gaussian), latent log-probs and all small-net
-//     gradients are fused in; per-workgroup partial gradients are accumulated in LDS across the workgroup's
-//     trajectories and written once as a slab (fixed-order reduction in misc_kernels.hip => bitwise reproducible).
+// Design: ONE workgroup integrates ONE trajectory (loop-free form, B <= 65,536; a persistent loop beyond), with
+// NT = roundup64(T) threads (>= 64 + roundup64(Q*C*S)).
+//   * f(t,x) = a(t,z) - d(t,z) * x never reads the state inside the net (blackbox_ode.py:97-109), and the hidden layer is
+//     relu(w_t t + u_j(z)): along the monotone stage-time table every unit switches on over a prefix or a suffix.  The 2S head
+//     pre-activations are therefore piecewise linear in t with <= H+1 segments: wave 0 finds the switching indices, ranks them and
+//     builds a table [segment][value | slope] (P0b, P0c); a stage evaluation is a 5-step search, S ds_read_b128 and 2S fma + sigmoid (P1).
+//   * every fixed-grid step collapses to the affine map x' = A x + b; the forward recurrence runs as an affine scan on all waves
+//     (P2, block_affine_scan), its adjoint on wave 0 (P4, wave_affine_scan) beside the head-weight gradients of the other waves.
+//   * likelihood (asymmetric Laplace x3 quantile heads, or Gaussian), latent log-probs, prior nets and -- proc family -- label heads
+//     are fused in (P0a, P0b, P3); the reverse mode of the step coefficients is thread <-> step again (P5) and leaves per-sample
+//     gradient rows G[nt][2S] in LDS; the weight-gradient contraction (P6) needs no per-sample x per-unit work: chunked prefix /
+//     suffix sums of G evaluated at each unit's switching index.
+//   * every gradient element has ONE owner thread and goes straight to the workgroup's slab row (no LDS accumulators, nothing but the
+//     loss partial carried in registers across trajectories); slab rows are summed in fixed order by the tail => bitwise reproducible.
+//   * folded ELBO step: the encoder heads + tanh backward (g_pre, glat) run here too (P7 / last block of the trajectory).
+//   * long latents (L >= 32, shape-specialised): only the parameters the solver phases re-read live in LDS; the rest is staged in the
+//     idle work block for P0 and read from global memory in P7 (ode_cold_global) -- 4 workgroups per CU instead of 2.
 #include "slode_common.h"
 #include <cstdlib>
 #include <vector>
@@ -29,12 +33,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #ifdef SLODE_STAMPS  // diagnostic build only: phase boundaries of workgroup 0 in 10 ns ticks (s_memrealtime)
 __device__ unsigned long long g_stamps_ode[32];
+__device__ unsigned long long g_stamps_ode_late[32];   // the same phase boundaries for workgroup 1000 (last residency slot of its CU)
 __device__ unsigned long long g_wg_span[2 * 4096];   // [start, end] of every workgroup
 __device__ unsigned int g_wg_hw[2 * 4096];            // [HW_ID, XCC_ID] of every workgroup's wave 0
-#define STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); if (blockIdx.x == 0) g_stamps_ode[i] = t_; \
+#define STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); if (blockIdx.x == 0) g_stamps_ode[i] = t_; if (blockIdx.x == 1000) g_stamps_ode_late[i] = t_; \
     if ((i) == 0 && blockIdx.x < 4096) { g_wg_span[2 * blockIdx.x] = t_; g_wg_hw[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4); g_wg_hw[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } if ((i) == 11 && blockIdx.x < 4096) g_wg_span[2 * blockIdx.x + 1] = t_; } } while (0)
 extern "C" int slode_debug_stamps_ode(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_ode), sizeof(unsigned long long) * 32);
+}
+extern "C" int slode_debug_stamps_ode_late(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_ode_late), sizeof(unsigned long long) * 32);
 }
 extern "C" int slode_debug_wg_hw(unsigned int* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_hw), sizeof(unsigned int) * 2 * n);
@@ -48,7 +56,12 @@ extern "C" int slode_debug_wg_span(unsigned long long* out, int n) {
 // last (round 1: 27 / 31 / 36 / 41 us); alternating high / low priority by (phase + residency slot) parity evens their progress.  Wave 0
 // (every serial stretch) stays one level above its workgroup's bulk waves.  Round 3 measured two more schemes against this one: a rotation
 // over four levels by (phase + slot) mod 4 -- 27.6 us against 27.5, no better, and the four-way branch of the macro itself costs 0.4 us --
-// and a static level = residency slot (youngest highest): 28.4 us.
+// a static level = residency slot (youngest highest): 28.4 us; and a FEEDBACK scheme (level = how far the workgroup lags the solo
+// timeline of the phase boundary, s_memrealtime against a nominal table): 28.6 - 29.9 us over the thresholds tried.  The stamps of a
+// last-slot workgroup (tools/stamps.py, second column) show where it loses its 7 us -- P1, P2 and P4, the phases in which every wave of
+// every co-resident workgroup is busy -- so what it lacks is issue slots and LDS cycles, not priority.  Staggering the START of the
+// co-resident workgroups (slot s idles s x 0.4 .. 2.4 us behind its set-up loads, so that their all-wave phases coincide less) does not
+// help either: the kernel gets longer by about 0.6 x the last slot's delay (27.3 -> 27.2 / 29.0 / 28.6 / 30.1 / 31.8 us).
 #define STAMP(i) do { if (((i) + prio_slot) & 1) { if (threadIdx.x < 64) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); } \
                       else { if (threadIdx.x < 64) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } } while (0)
 #endif

@@ -150,3 +150,32 @@ def test_no_kernel_spills_or_parks_registers():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_spills.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "no VGPR spills, no AGPR parking" in r.stdout
+
+
+def test_chain_hand_off_is_write_through_in_the_isa():
+    """enc_chain_kernel hands its per-unit conv rows to the last block to arrive with RELAXED agent-scope atomics: sc1 (write-through)
+    stores, drained before the arrival count, and sc1 (L1-bypassing) loads in the reader -- no acquire fence on the fast path
+    (encoder_fused.hip; MI355X_MICROARCH.md).  The language-level memory model does not order those accesses; what does is the sc1 bit
+    on the instructions, so a compiler that stopped emitting it would silently break the hand-off: the ISA is checked here."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "structured_latent_odes_amd", "csrc", "encoder_fused.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "enc.s")
+        r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=on", "--cuda-device-only", "-S", "-o", out, src],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        asm = open(out).read()
+    name = [l.split(":")[0] for l in asm.splitlines() if l.startswith("_ZN") and "enc_chain_kernelILi3ELi14" in l][0]
+    body = asm[asm.index(name + ":"):]
+    body = body[:body.index(".Lfunc_end")]
+    stores = [l for l in body.splitlines() if "global_store_dword" in l and " sc1" in l]
+    loads = [l for l in body.splitlines() if "global_load_dword" in l and " sc1" in l]
+    atomics = [l for l in body.splitlines() if "global_atomic_add" in l]
+    assert len(stores) >= 2 and len(loads) >= 16 and len(atomics) >= 1, (len(stores), len(loads), len(atomics))

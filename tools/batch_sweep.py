@@ -33,4 +33,5 @@ for B in (256, 1024, 4096, 16384, 65536, 262144):
     row = {"B": B, "us_per_step": 1e6 * dt / n, "traj_per_s": B * n / dt, "ode_elbo_us": dict(pr)["ode_elbo"],
            "ode_frac_fp32": 1137720 * B / (dict(pr)["ode_elbo"] * 1e-6) / 157.3e12, "step_frac_fp32": 2075370 * B / (dt / n) / 157.3e12}
     out.append(row); print(json.dumps(row), flush=True)
-json.dump(out, open("gpurun_out/batch_sweep.json", "w"), indent=1)
+os.makedirs("gpurun_out/r3", exist_ok=True)
+json.dump(out, open("gpurun_out/r3/batch_sweep.json", "w"), indent=1)

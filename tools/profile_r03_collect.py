@@ -28,9 +28,14 @@ def short(name):
     return name.split("(")[0].split("<")[0].replace(",", ";")[-60:]
 
 
+def newest(files):
+    """the scratch directory may hold several collections of the same command: only the latest one counts"""
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 def stats(d):
     rows = []
-    for f in glob.glob(os.path.join(d, "*", "*kernel_stats.csv")):
+    for f in newest(glob.glob(os.path.join(d, "*", "*kernel_stats.csv"))):
         for r in csv.DictReader(open(f)):
             rows.append((short(r["Name"]), int(r["Calls"]), float(r["AverageNs"]), float(r["MinNs"]), float(r["MaxNs"]), float(r["Percentage"])))
     return rows
@@ -38,7 +43,7 @@ def stats(d):
 
 def pmc(d):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+    for f in newest(glob.glob(os.path.join(d, "*", "*counter_collection.csv"))):
         for r in csv.DictReader(open(f)):
             out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: (sum(v[len(v) // 4:]) / len(v[len(v) // 4:]), len(v)) for c, v in cs.items()} for k, cs in out.items()}
@@ -54,7 +59,7 @@ def write_stats(rows, name):
 def stats_full(d):
     """full kernel names (template arguments tell the shapes apart)"""
     rows = []
-    for f in glob.glob(os.path.join(d, "*", "*kernel_stats.csv")):
+    for f in newest(glob.glob(os.path.join(d, "*", "*kernel_stats.csv"))):
         for r in csv.DictReader(open(f)):
             nm = r["Name"].replace("(anonymous namespace)::", "").replace(",", ";")[:110]
             rows.append((nm, int(r["Calls"]), float(r["AverageNs"]), float(r["MinNs"]), float(r["MaxNs"]), float(r["Percentage"])))

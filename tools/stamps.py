@@ -35,7 +35,12 @@ lib = _lib.load()
 buf = (C.c_ulonglong * 32)()
 assert lib.slode_debug_stamps_ode(buf) == 0
 v = list(buf)
-print("== ode kernel, workgroup 0 (us)")
+late = None
+if hasattr(lib, "slode_debug_stamps_ode_late") and B > 1000:
+    buf2 = (C.c_ulonglong * 32)()
+    if lib.slode_debug_stamps_ode_late(buf2) == 0:
+        late = list(buf2)
+print("== ode kernel, workgroup 0 (us)   [second column: workgroup 1000, last residency slot of its CU]")
 tot = 0.0
 for lab, i, j in (("setup: table loads -> LDS", 0, 13), ("setup: zero acc + barrier", 13, 14), ("setup: w_t, table check", 14, 1),
                   ("P0a latent sample / log-probs", 1, 15), ("P0b u, init hidden, switching indices, rank", 15, 16),
@@ -45,7 +50,8 @@ for lab, i, j in (("setup: table loads -> LDS", 0, 13), ("setup: zero acc + barr
                   ("P7 aux, gp0", 17, 18), ("P7 latent gradient | owner accumulation", 18, 20), ("P7 last barrier", 20, 21),
                   ("g_pre block, prefetch", 21, 10), ("epilogue: loss", 10, 22), ("epilogue: slab write", 22, 11)):
     if v[i] and v[j]:
-        print("  %-46s %8.2f" % (lab, (v[j] - v[i]) / 100.0))
+        extra = "  %8.2f" % ((late[j] - late[i]) / 100.0) if late and late[i] and late[j] else ""
+        print("  %-46s %8.2f%s" % (lab, (v[j] - v[i]) / 100.0, extra))
         tot += (v[j] - v[i]) / 100.0
 print("  %-46s %8.2f" % ("total", tot))
 import numpy as np
