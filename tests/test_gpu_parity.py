@@ -103,6 +103,29 @@ def test_decode_heads(ctx):
     assert _rel(std, F.softplus(ctx["p"]["decoder.constant_std"])) < 1e-6
 
 
+def test_decode_heads_backward(ctx):
+    """slode_decode_heads_bwd (autograd through the materialising Decoder.forward, models/decoders.py:42-54) against a plain fp32 torch
+    reference of the same three contractions: g_x = sum_{q,c} g_mu W_q, g_W_q = sum_{b,t} g_mu x, g_cstd = g_std * sigmoid(constant_std).
+    Tolerance 2e-5 norm-wise (fp32 sums over B*T terms in a different order)."""
+    eng, dev, B, T, S = ctx["eng"], ctx["dev"], ctx["B"], ctx["T"], ctx["S"]
+    sp = ctx["ospec"]
+    names = ["output_mean"] if sp.gauss else ["output_q50", "output_q75", "output_q25"]
+    Q, C = len(names), ctx["obs"].shape[1]
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(B, T, S, generator=g)
+    g_mu = torch.randn(Q, B, C, T, generator=g)
+    g_std = torch.randn(C, T, generator=g)
+    g_x, g_heads, g_c = eng.decode_heads_bwd(ctx["flat"], x.to(dev), g_mu.to(dev), g_std.to(dev))
+    W = [ctx["p"]["decoder.%s.0.weight" % n] for n in names]
+    want_x = sum(torch.einsum("bct,cs->bts", g_mu[q], W[q]) for q in range(Q))
+    assert _rel(g_x, want_x) < 2e-5
+    for q in range(Q):
+        assert _rel(g_heads[q], torch.einsum("bct,bts->cs", g_mu[q], x)) < 2e-5
+    assert _rel(g_c, g_std * torch.sigmoid(ctx["p"]["decoder.constant_std"])) < 2e-6
+    g_x2, g_heads2, _ = eng.decode_heads_bwd(ctx["flat"], x.to(dev), g_mu.to(dev))          # no std gradient; bitwise repeatable
+    assert torch.equal(g_x, g_x2) and torch.equal(g_heads, g_heads2)
+
+
 def test_eval_side_small_nets(ctx):
     """slode_initialize_state / slode_prior_nets / slode_label_heads (the eval-side entry points: OdeModel.initialize_state, the prior
     nets of recon(is_post=False), classifier / pred_inputs) against the oracle's restatement of the same modules: 1e-6 relative."""
