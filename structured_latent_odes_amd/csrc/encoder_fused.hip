@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) weff_kernel(const float* __restrict__ pl_
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [F*C*K conv taps][stage_rows ? the block's lin.weight rows : 0]
   const int tid = threadIdx.x, J = k.J, C = k.C, K = k.K;
   const float fP = (float)k.P;
-  if (blockIdx.x == 0 && tid == 0 && k.counter) *k.counter = 0u;   // arrival counter of this step's chain blocks
+  if (blockIdx.x == 0 && tid < 8 && k.counter) k.counter[32 * tid] = 0u;   // arrival counters of this step's chain blocks (one per filter pair, 128 B apart)
   STAMP(0);
   const int n_w = k.Hc * k.CT;
   const int nb_w = (n_w + WPB - 1) / WPB;
@@ -168,7 +168,44 @@ __global__ void __launch_bounds__(256) weff_kernel(const float* __restrict__ pl_
 // ---- forward: hid = tanh(W_eff x + b_eff), heads --------------------------------------------------------------------
 // TB trajectories per 1024-thread block (4, or 8 for large batches: every block streams the whole W_eff -- 120 KB at the metric shape --
 // so at B = 4096 the 1024 blocks of the 4-trajectory form pull 160 MB through the L2s: 30 us; twice the trajectories per block halve it)
-template <int TB>
+template <int NSET>
+__device__ __forceinline__ void enc_tile_fma(const float2 (&w)[RB][IU], const float* s_x, int CT, int i0, float (&acc)[NSET][RB * TBE]) {
+#pragma unroll
+  for (int u = 0; u < IU; ++u) {
+    const bool in = i0 + 128 * u < CT;
+    const int i = min(i0 + 128 * u, CT - 2);
+#pragma unroll
+    for (int st = 0; st < NSET; ++st)
+#pragma unroll
+      for (int tb = 0; tb < TBE; ++tb) {
+        const float2 pv = *reinterpret_cast<const float2*>(s_x + (st * TBE + tb) * CT + i);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const float wx = in ? w[r][u].x : 0.f, wy = in ? w[r][u].y : 0.f;
+          acc[st][r * TBE + tb] = fmaf(wy, pv.y, fmaf(wx, pv.x, acc[st][r * TBE + tb]));
+        }
+      }
+  }
+}
+template <int NSET>
+__device__ __forceinline__ void enc_group_finish(float (&acc)[NSET][RB * TBE], int lane, int m0, int b0, const FoldK& k, const float* s_be, float* s_hid) {
+  static_assert(RB * TBE == 16, "wave_sum16 reduces RB x TBE = 16 partial sums");
+#pragma unroll
+  for (int st = 0; st < NSET; ++st) {
+    const float v = wave_sum16(acc[st], lane);
+    const int idx = (lane >> 2) & 15, r = idx / TBE, tb = st * TBE + (idx - r * TBE);
+    const int mm = min(m0 + r, k.Hc - 1);
+    const float hv = tanhf(v + s_be[mm]);
+    if ((lane & 3) == 0 && m0 + r < k.Hc) {
+      s_hid[tb * 64 + mm] = hv;
+      if (b0 + tb < k.B) k.hid[(long long)(b0 + tb) * k.Hc + mm] = hv;
+    }
+  }
+}
+// ONE: every wave owns at most one group of RB rows and a row is one tile of 128 * IU columns (C*T <= 640, Hc <= 64: every reference
+// shape with T <= 213) -- no loop, and the wave's tile of W_eff is requested BEFORE the observation rows are staged: it does not depend
+// on them and both are cold misses (W_eff was written by the fold launch a moment ago, from other CUs): one round trip instead of two.
+template <int TB, bool ONE>
 __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__ pl_x, const float* __restrict__ pl_zloc_w, const float* __restrict__ pl_zls_w,
                                                        const float* __restrict__ pl_beff, const float* __restrict__ pl_weff, const FoldK k) {
   static_assert(TB % TBE == 0, "sets of four trajectories (wave_sum16 reduces RB x 4 partial sums)");
@@ -181,20 +218,50 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
   float* s_be = s_hw + 2 * L * Hc;   // [64] b_eff
   const int b0 = blockIdx.x * TB;
   STAMP(8);
-  for (int e = tid; e < TB * CT; e += NT) {
-    const int tb = e / CT;
-    s_x[e] = pl_x[(long long)min(b0 + tb, k.B - 1) * CT + (e - tb * CT)];
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = NT >> 6;   // wave-uniform => row pointers in SGPRs
+  const int ngroups = (Hc + RB - 1) / RB;
+  float2 w1[RB][IU];
+  if (ONE && wave < ngroups) {
+#pragma unroll
+    for (int u = 0; u < IU; ++u) {
+      const int ic = min(2 * lane + 128 * u, CT - 2);
+#pragma unroll
+      for (int r = 0; r < RB; ++r) w1[r][u] = *reinterpret_cast<const float2*>(pl_weff + (long long)min(wave * RB + r, Hc - 1) * CT + ic);
+    }
+  }
+  {
+    // raw rows: the block's TB * CT floats are contiguous in memory (dense rows); four loads in flight per thread
+    const long long base = (long long)b0 * CT, lim = (long long)k.B * CT - 1;
+    for (int e0 = tid; e0 < TB * CT; e0 += 4 * NT) {
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = pl_x[min(base + e0 + q * NT, lim)];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (e0 + q * NT < TB * CT) s_x[e0 + q * NT] = v[q];
+    }
   }
   for (int e = tid; e < 2 * L * Hc; e += NT) s_hw[e] = (e < L * Hc) ? pl_zloc_w[e] : pl_zls_w[e - L * Hc];
   if (tid < Hc) s_be[tid] = pl_beff[tid];
   __syncthreads();
   STAMP(9);
-  {
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = NT >> 6;   // wave-uniform => row pointers in SGPRs
-    const int ngroups = (Hc + RB - 1) / RB;
+  if (ONE) {
+    if (wave < ngroups) {
+      float acc[NSET][RB * TBE];   // [set][r][tb] flattened: wave_sum16 reduces each set in place
+#pragma unroll
+      for (int st = 0; st < NSET; ++st)
+#pragma unroll
+        for (int i = 0; i < RB * TBE; ++i) acc[st][i] = 0.f;
+      enc_tile_fma<NSET>(w1, s_x, CT, 2 * lane, acc);
+      __builtin_amdgcn_sched_barrier(0);   // keep the reduction's temporaries out of the load/FMA phase (spills otherwise)
+      STAMP(12);
+      enc_group_finish<NSET>(acc, lane, wave * RB, b0, k, s_be, s_hid);
+      STAMP(13);
+    }
+  } else {
     for (int g = wave; g < ngroups; g += nw) {
       const int m0 = g * RB;
-      float acc[NSET][RB * TBE];   // [set][r][tb] flattened: wave_sum16 reduces each set in place
+      float acc[NSET][RB * TBE];
 #pragma unroll
       for (int st = 0; st < NSET; ++st)
 #pragma unroll
@@ -212,22 +279,7 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
 #pragma unroll
             for (int r = 0; r < RB; ++r) w[r][u] = *reinterpret_cast<const float2*>(wrow[r] + ic);
           }
-#pragma unroll
-          for (int u = 0; u < IU; ++u) {
-            const bool in = i0 + 128 * u < CT;
-            const int i = min(i0 + 128 * u, CT - 2);
-#pragma unroll
-            for (int st = 0; st < NSET; ++st)
-#pragma unroll
-              for (int tb = 0; tb < TBE; ++tb) {
-                const float2 pv = *reinterpret_cast<const float2*>(s_x + (st * TBE + tb) * CT + i);
-#pragma unroll
-                for (int r = 0; r < RB; ++r) {
-                  const float wx = in ? w[r][u].x : 0.f, wy = in ? w[r][u].y : 0.f;
-                  acc[st][r * TBE + tb] = fmaf(wy, pv.y, fmaf(wx, pv.x, acc[st][r * TBE + tb]));
-                }
-              }
-          }
+          enc_tile_fma<NSET>(w, s_x, CT, i0, acc);
         }
       } else {
         for (int i = lane; i < CT; i += 64) {
@@ -243,31 +295,26 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the reduction's temporaries out of the load/FMA phase (spills otherwise)
       STAMP(12);
-      static_assert(RB * TBE == 16, "wave_sum16 reduces RB x TBE = 16 partial sums");
-#pragma unroll
-      for (int st = 0; st < NSET; ++st) {
-        const float v = wave_sum16(acc[st], lane);
-        const int idx = (lane >> 2) & 15, r = idx / TBE, tb = st * TBE + (idx - r * TBE);
-        const int mm = min(m0 + r, Hc - 1);
-        const float hv = tanhf(v + s_be[mm]);
-        if ((lane & 3) == 0 && m0 + r < Hc) {
-          s_hid[tb * 64 + mm] = hv;
-          if (b0 + tb < k.B) k.hid[(long long)(b0 + tb) * Hc + mm] = hv;
-        }
-      }
+      enc_group_finish<NSET>(acc, lane, m0, b0, k, s_be, s_hid);
       STAMP(13);
     }
   }
   __syncthreads();
   STAMP(10);
-  for (int e = tid; e < TB * L * 2; e += NT) {
+  // heads: 16 lanes per output (which, trajectory, latent dim), each summing every 16th hidden unit; xor butterfly inside the 16 lanes
+  for (int e0 = (tid >> 4); e0 < ((TB * L * 2 + 3) & ~3); e0 += NT >> 4) {   // (wave-uniform trip count: four outputs per wave and pass)
+    const int e = min(e0, TB * L * 2 - 1), l16 = tid & 15;
     const int which = e / (TB * L), r = e - which * (TB * L);
     const int tb = r / L, l = r - tb * L;
-    const float* W = s_hw + which * L * Hc;
-    float acc = which ? k.zls_b[l] : k.zloc_b[l];
-#pragma unroll 10
-    for (int mm = 0; mm < Hc; ++mm) acc = fmaf(W[l * Hc + mm], s_hid[tb * 64 + mm], acc);
-    if (b0 + tb < k.B) {
+    const float* W = s_hw + which * L * Hc + l * Hc;
+    float acc = 0.f;
+    for (int mm = l16; mm < Hc; mm += 16) acc = fmaf(W[mm], s_hid[tb * 64 + mm], acc);
+    acc += __shfl_xor(acc, 8, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 1, 64);
+    acc += which ? k.zls_b[l] : k.zloc_b[l];
+    if (l16 == 0 && e0 < TB * L * 2 && b0 + tb < k.B) {
       if (which) k.scale[(long long)(b0 + tb) * L + l] = expf(acc);
       else k.loc[(long long)(b0 + tb) * L + l] = acc;
     }
@@ -276,78 +323,91 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
 }
 
 // ---- backward part 3: chain rule from G = dLoss/dW_eff back to lin.weight (final) and conv.{weight,bias} (per-m partials) ---
-// One 1024-thread workgroup per hidden unit m.  G's columns [0, CT) are dLoss/dW_eff[m][:], column CT is g_beff[m] = sum_b g_pre[b][m]
-// (the MFMA GEMM appends a ones-column to X), both summed here over the split-K partials in fixed order.
-constexpr int CNT = 1024;
-constexpr int QCH = 16;   // q-chunks for the w' partial sums
-// With a tail (folded ELBO step) the same launch finishes the whole flat gradient: rider blocks (blockIdx >= Hc) reduce everything
-// that does not depend on this kernel (ODE half, lin.bias, head layers, loss), the chain blocks apply Adam to their own lin.weight row,
-// and the LAST chain block to arrive (agent-scope release / counter / acquire) sums the Hc conv rows.  Fixed order => reproducible.
+// One 640-thread workgroup per (hidden unit m, pair of conv filters): Hc * ceil(F / 2) = 250 workgroups at the reference's shapes -- one
+// per CU (round 2: one 1024-thread workgroup per m, 50 of them, whose four LDS-issue-bound stages ran one after the other: 15.6 us).
+// G's columns [0, CT) are dLoss/dW_eff[m][:], column CT is g_beff[m] = sum_b g_pre[b][m] (the MFMA GEMM appends a ones-column to X),
+// both summed here over the split-K partials in fixed order (every workgroup of an m sums the row again: L2 hits).
+constexpr int CNT = 640;    // threads of a chain / rider block
+constexpr int CNT1 = 384;   // ... of which run contraction (i); the other 256 run (ii)
+constexpr int FPC = 2;      // conv filters per chain block
+constexpr int QCH = 32;     // q-chunks of (ii): the half-wave of an (f, c) pair
+constexpr int NPA = 2;      // Adam passes of a block's lin.weight piece whose state is fetched in the prologue
+static_assert(4 * (FPC * SLODE_MAX_C * SLODE_MAX_K + FPC) <= CNT, "four lanes per conv element in the last block of a filter pair");
+static_assert(SLODE_MAX_HC <= 64, "the last block holds ceil(Hc / 4) <= 16 row values per lane");
+// The same launch finishes the whole flat gradient: rider blocks (blockIdx >= Hc * NFC) reduce everything that does not depend on this
+// kernel (ODE half, lin.bias, head layers, loss), the chain blocks apply Adam to their own piece of the lin.weight row, and -- per filter
+// pair -- the LAST chain block to arrive (agent-scope counter, one per pair, 128 B apart) sums the Hc conv rows of the pair's taps.
+// Fixed order => reproducible.
 template <int C, int JM>
 __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict__ pl_gslabs, const float* __restrict__ pl_lin_w, const float* __restrict__ pl_wprime,
-                                                        const FoldK k, const TailK tl, const int with_tail) {
+                                                        const FoldK k, const TailK tl) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, NT = blockDim.x, m = blockIdx.x;
-  if (m >= k.Hc) {   // rider block
-    const int i = tl.lin_b + (m - k.Hc) * NT + tid;
-    if (m == k.Hc) STAMP_ANY(26);
+  const int tid = threadIdx.x;
+  const int NFC = (k.F + FPC - 1) / FPC, n_chain = k.Hc * NFC;
+  if ((int)blockIdx.x >= n_chain) {   // rider block
+    const int r = (int)blockIdx.x - n_chain, i = tl.lin_b + r * CNT + tid;
+    if (r == 0) STAMP_ANY(26);
     if (i < tl.n_total) tail_element(tl, i);
     else if (i == tl.n_total) tail_loss(tl);
-    if (m == k.Hc) STAMP_ANY(27);
+    if (r == 0) STAMP_ANY(27);
     return;
   }
+  const int m = (int)blockIdx.x % k.Hc, fci = (int)blockIdx.x / k.Hc, f0 = fci * FPC, nf = min(FPC, k.F - f0);
   const int CT = k.CT, J = k.J, K = k.K, F = k.F, n_pool = k.n_pool, FQ = k.FQ, T = k.T, GN = CT + 1;
-  float* s_G = smem;                          // [CT + 1]
-  float* s_wl = s_G + ((GN + 3) & ~3);        // [FQ]          lin.weight[m][:]
-  float* s_wp = s_wl + ((FQ + 3) & ~3);       // [F][C][JM]    w' (zero padded)
-  float* s_pm = s_wp + F * C * JM;            // [QCH][F][C][JM] partial dLoss/dw'
-  float* s_glw = s_pm + QCH * F * C * JM;     // [FQ] this row's lin.weight gradient (for the fused Adam pass)
+  const int n_lw = nf * n_pool;                          // this block's piece of the lin.weight row: [f0 * n_pool, f0 * n_pool + n_lw)
+  float* s_G = smem;                                     // [CT + 1]
+  float* s_wl = s_G + ((GN + 3) & ~3);                   // [FPC * n_pool]   lin.weight[m][f0 * n_pool ...]
+  float* s_wp = s_wl + ((FPC * n_pool + 3) & ~3);        // [FPC][C][JM]     w' (zero padded)
+  float* s_pw = s_wp + FPC * C * JM;                     // [FPC][C][JM]     dLoss/dw' of this m
+  float* s_glw = s_pw + FPC * C * JM;                    // [FPC * n_pool]   this piece's lin.weight gradient (for the fused Adam pass)
   STAMP(16);
+  // Adam state of this block's lin.weight elements: fetched first, used last (a cold miss off the block's tail)
+  const int lw0 = tl.lin_w + m * FQ + f0 * n_pool;
+  float am[NPA], av[NPA], ap[NPA];
+#pragma unroll
+  for (int u = 0; u < NPA; ++u) {
+    const int i = lw0 + min(tid + u * CNT, n_lw - 1);
+    const bool on = tl.ad.p != nullptr && tid + u * CNT < n_lw;
+    am[u] = on ? tl.ad.m[i] : 0.f; av[u] = on ? tl.ad.v[i] : 0.f; ap[u] = on ? tl.ad.p[i] : 0.f;
+  }
   // split-K partials of row m: all of a column's loads in flight at once (a loop of load-then-add costs one L2 / HBM round trip per
-  // partial: the GEMM launch wrote them from other CUs; measured: staging 3.2 -> 2.0 us), summed in fixed order
-  for (int i = tid; i < GN; i += NT) s_G[i] = strided_sum(pl_gslabs + (long long)m * GN + i, k.Hc * GN, k.n_gslabs);
-  for (int i = tid; i < FQ; i += NT) s_wl[i] = pl_lin_w[(long long)m * FQ + i];
-  for (int i = tid; i < F * C * JM; i += NT) {
+  // partial: the GEMM launch wrote them from other CUs), summed in fixed order
+  for (int i = tid; i < GN; i += CNT) s_G[i] = strided_sum(pl_gslabs + (long long)m * GN + i, k.Hc * GN, k.n_gslabs);
+  for (int i = tid; i < n_lw; i += CNT) s_wl[i] = pl_lin_w[(long long)m * FQ + f0 * n_pool + i];
+  for (int i = tid; i < nf * C * JM; i += CNT) {
     const int j = i % JM, fc = i / JM;
-    s_wp[i] = (j < J) ? pl_wprime[fc * J + min(j, J - 1)] : 0.f;
+    s_wp[i] = (j < J) ? pl_wprime[(f0 * C + fc) * J + min(j, J - 1)] : 0.f;
   }
   __syncthreads();
   STAMP(17);
   const float gb = s_G[CT];
   const int sC = k.t_major ? 1 : T, sT = k.t_major ? C : 1;   // kappa(c, t) = c*sC + t*sT
-  // The two contractions are independent: the lower half of the workgroup runs (i) while the upper half runs (ii).
-  const int NT1 = NT / 2, NT2 = NT - NT1;
-  // (i) dLoss/d lin.weight[m][f*n_pool + q] = g_beff[m]*conv_b[f] + sum_{c,j} G[kappa(c, q+j)] * w'[f][c][j]; thread (fh, q)
-  if (tid < NT1) {
-    const int nfh = (NT1 / n_pool) < 1 ? 1 : ((NT1 / n_pool) > F ? F : (NT1 / n_pool));   // filter groups handled in parallel
-    const int fper = (F + nfh - 1) / nfh;
-    for (int e = tid; e < nfh * n_pool; e += NT1) {
-      const int fh = e / n_pool, q = e - fh * n_pool;
-      float Gw[C][JM];
+  // The two contractions are independent: waves 0..5 run (i) while waves 6..9 run (ii).
+  if (tid < CNT1) {
+    // (i) dLoss/d lin.weight[m][f*n_pool + q] = g_beff[m]*conv_b[f] + sum_{c,j} G[kappa(c, q+j)] * w'[f][c][j]; thread (f, q)
+    for (int e = tid; e < n_lw; e += CNT1) {
+      const int fl = e / n_pool, q = e - fl * n_pool;
+      float acc = gb * k.conv_b[f0 + fl];
 #pragma unroll
       for (int c = 0; c < C; ++c)
 #pragma unroll
-        for (int j = 0; j < JM; ++j) Gw[c][j] = s_G[c * sC + min(q + j, T - 1) * sT];   // taps beyond J meet w' == 0
-      for (int f = fh * fper; f < min(F, (fh + 1) * fper); ++f) {
-        float acc = gb * k.conv_b[f];
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-#pragma unroll
-          for (int j = 0; j < JM; ++j) acc = fmaf(Gw[c][j], s_wp[(f * C + c) * JM + j], acc);
-        k.g_lin_w[(long long)m * FQ + f * n_pool + q] = acc;
-        s_glw[f * n_pool + q] = acc;
-      }
+        for (int j = 0; j < JM; ++j)   // taps beyond J meet w' == 0
+          acc = fmaf(s_G[c * sC + min(q + j, T - 1) * sT], s_wp[(fl * C + c) * JM + j], acc);
+      k.g_lin_w[(long long)m * FQ + f0 * n_pool + e] = acc;
+      s_glw[e] = acc;
     }
-  }
-  STAMP(18);
-  // (ii) partial dLoss/dw'[f][c][j] (this m) = sum_q G[kappa(c, q+j)] * lin.weight[m][f*n_pool + q]; thread (qchunk, f, c) keeps all
-  // JM taps in registers and slides a JM-wide window of G along q (2 LDS reads per JM FMAs)
-  if (tid >= NT1) {
+    STAMP(18);
+  } else {
+    // (ii) dLoss/dw'[f][c][j] (this m) = sum_q G[kappa(c, q+j)] * lin.weight[m][f*n_pool + q]: the 32 lanes of a half-wave share (f, c) and
+    // split q; a lane keeps all JM taps in registers and slides a JM-wide window of G along its q range (2 LDS reads per JM FMAs); the
+    // half-wave's partial sums meet in an xor butterfly (fixed order)
     const int per = (n_pool + QCH - 1) / QCH;
-    for (int e = tid - NT1; e < QCH * F * C; e += NT2) {
-      const int fc = e % (F * C), ch = e / (F * C), f = fc / C, c = fc - f * C;
-      const int q0 = ch * per, q1 = min(n_pool, q0 + per);
-      const float* wl = s_wl + f * n_pool;
+    for (int e0 = tid - CNT1; e0 < ((nf * C * QCH + 63) & ~63); e0 += CNT - CNT1) {   // wave-uniform trip count
+      const bool valid = e0 < nf * C * QCH;
+      const int e = valid ? e0 : 0;
+      const int fc = e / QCH, ch = e - fc * QCH, fl = fc / C, c = fc - fl * C;
+      const int q0 = min(ch * per, n_pool), q1 = valid ? min(n_pool, q0 + per) : q0;
+      const float* wl = s_wl + fl * n_pool;
       const float* gp = s_G + c * sC;
       float acc[JM], win[JM];
 #pragma unroll
@@ -361,153 +421,110 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
         win[JM - 1] = gp[min(q + JM, T - 1) * sT];
       }
 #pragma unroll
-      for (int j = 0; j < JM; ++j) s_pm[(ch * F * C + fc) * JM + j] = (j < J) ? acc[j] : 0.f;
+      for (int j = 0; j < JM; ++j) {
+        float v = acc[j];
+#pragma unroll
+        for (int off = QCH / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (valid && ch == 0) s_pw[fc * JM + j] = (j < J) ? v : 0.f;
+      }
     }
   }
   __syncthreads();
   STAMP(19);
-  // w' -> conv taps (adjoint of the box filter) and conv.bias; one slab row per m
+  // w' -> conv taps (adjoint of the box filter) and conv.bias; this block's columns of slab row m, stored agent-scope (sc1, write-through)
   float* row = k.conv_slabs + (long long)m * (F * C * K + F);
   const float fP = (float)k.P;
-  for (int e = tid; e < F * C * K; e += NT) {
+  for (int e = tid; e < nf * C * K; e += CNT) {
     const int kk = e % K, fc = e / K;
     float s = 0.f;
-    for (int p = 0; p < k.P; ++p) {
-      float pv[QCH];
-#pragma unroll
-      for (int ch = 0; ch < QCH; ++ch) pv[ch] = s_pm[(ch * F * C + fc) * JM + kk + p];   // the q-chunks' partials: one batch of LDS reads
-      float v = 0.f;
-#pragma unroll
-      for (int ch = 0; ch < QCH; ++ch) v += pv[ch];
-      s += v;
-    }
-    if (with_tail) __hip_atomic_store(row + e, s / fP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the last block
-    else row[e] = s / fP;
+    for (int p = 0; p < k.P; ++p) s += s_pw[fc * JM + kk + p];
+    __hip_atomic_store(row + f0 * C * K + e, s / fP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the pair's last block
   }
-  for (int f = tid; f < F; f += NT) {
-    const float v = gb * k.rowsum[m * F + f];
-    if (with_tail) __hip_atomic_store(row + F * C * K + f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else row[F * C * K + f] = v;
-  }
+  if (tid < nf) __hip_atomic_store(row + F * C * K + f0 + tid, gb * k.rowsum[m * F + f0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   STAMP(20);
-  if (with_tail) {
-    // Hand-off of the conv rows to the last block to arrive, without a cache-wide release: the rows are stored with agent-scope (sc1,
-    // write-through) stores; EVERY storing wave drains them (explicit s_waitcnt vmcnt(0) below: the compiler does not emit one
-    // for a store it has no later use for) ahead of the barrier behind which one lane bumps the agent-scope counter; the block that
-    // sees the final count reads the rows behind an acquire (invalidate-only) fence followed by a workgroup barrier.
-    __shared__ int s_last;
-    // conv Adam state of the (up to two) elements this lane would finish as part 0 of the last block: fetched now, off the critical path
-    constexpr int NCI = 2;
-    const bool fast_conv = tl.lin_w <= NCI * (CNT / 4);
-    float cm[NCI], cv[NCI], cp[NCI];
+  // Hand-off of the conv rows to the pair's last block to arrive, without a cache-wide release: the rows are stored with agent-scope (sc1,
+  // write-through) stores; EVERY storing wave drains them (explicit s_waitcnt vmcnt(0) below: the compiler does not emit one for a
+  // store it has no later use for) ahead of the barrier behind which one lane bumps the pair's agent-scope counter; the block that sees
+  // the final count reads the rows with sc1 (L1-bypassing) loads behind the next barrier -- every byte was stored sc1 and drained
+  // before its block's counter add, and the add's returned value is what told this block it is last (MI355X_MICROARCH.md, hand-offs
+  // measured with sc1 loads in place of the acquire: 4-byte stores and loads, one counter; tests/test_host_cpu.py pins the sc1 bits).
+  __shared__ int s_last;
+  // conv element of this lane group as part of the last block (4 lanes per element): its Adam state is fetched now, off the critical path
+  const int n_el = nf * C * K + nf, el = tid >> 2, part = tid & 3;
+  const bool el_on = el < n_el;
+  const int col = el < nf * C * K ? f0 * C * K + el : F * C * K + f0 + (el - nf * C * K);   // column of the conv slab rows
+  const int ci = tl.conv_w + min(col, F * C * K + F - 1);
+  const bool c_on = el_on && part == 0 && tl.ad.p != nullptr;
+  const float cm = c_on ? tl.ad.m[ci] : 0.f, cv = c_on ? tl.ad.v[ci] : 0.f, cp = c_on ? tl.ad.p[ci] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's sc1 row stores have reached L2 before the counter can move
+  __syncthreads();
+  if (tid == 0)
+    s_last = (__hip_atomic_fetch_add(tl.counter + 32 * fci, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(k.Hc - 1)) ? 1 : 0;
+  STAMP(21);
+  __syncthreads();
+  const bool last = s_last != 0;
+  if (last) STAMP_ANY(24);
+  // the last block to arrive is the one every other block's work waits behind: its loads of the Hc conv rows (4 lanes per element, each
+  // summing every 4th row in fixed order; 16 sc1 loads in flight per lane) go out now and fly during its own piece's Adam pass
+  constexpr int NRV = 16;
+  float rv[NRV];
+  const int nrow = (k.Hc - part + 3) / 4;
+  if (last && el_on) {
+    const float* src = tl.conv_slabs + (long long)part * tl.n_cv + col;
 #pragma unroll
-    for (int u = 0; u < NCI; ++u) {
-      const int ci = min((tid >> 2) + u * (CNT / 4), tl.lin_w - 1);
-      const bool on = fast_conv && tl.ad.p != nullptr && (tid & 3) == 0;
-      cm[u] = on ? tl.ad.m[ci] : 0.f; cv[u] = on ? tl.ad.v[ci] : 0.f; cp[u] = on ? tl.ad.p[ci] : 0.f;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's sc1 row stores have reached L2 before the counter can move
-    __syncthreads();
-    if (tid == 0) {
-      s_last = (__hip_atomic_fetch_add(tl.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(k.Hc - 1)) ? 1 : 0;
-      // fast path: the last block reads the rows with sc1 (L1-bypassing) loads behind the barrier below -- every byte was stored sc1
-      // and drained before its block's counter add, and the add's returned value is what told this block it is last
-      // (MI355X_MICROARCH.md, hand-offs measured with sc1 loads in place of the acquire: 4-byte stores and loads, one counter).  The
-      // generic path (plain strided loads in tail_element) keeps the acquire: an L1 invalidate, completed before the barrier.
-      if (s_last && !fast_conv) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int q = 0; q < NRV; ++q)
+      rv[q] = __hip_atomic_load(src + (long long)min(q, nrow - 1) * 4 * tl.n_cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tl.ad.p != nullptr) {   // Adam on this block's piece of the lin.weight row
+#pragma unroll
+    for (int u = 0; u < NPA; ++u) {
+      const int e = tid + u * CNT;
+      if (e < n_lw) {
+        const float g = s_glw[e];
+        const float mi = am[u] + tl.ad.one_minus_b1 * (g - am[u]);
+        const float vi = av[u] * tl.ad.b2 + tl.ad.one_minus_b2 * g * g;
+        tl.ad.p[lw0 + e] = ap[u] - tl.ad.step_size * (mi / (sqrtf(vi) / tl.ad.sqrt_bc2 + tl.ad.eps));
+        tl.ad.m[lw0 + e] = mi;
+        tl.ad.v[lw0 + e] = vi;
       }
     }
-    STAMP(21);
-    __syncthreads();
-    const bool last = s_last != 0;
-    if (last) STAMP_ANY(24);
-    // the last block to arrive is the one every other block's work waits behind: its loads of the Hc conv rows (4 lanes per element, each
-    // summing every 4th row in fixed order; 2 x 16 sc1 loads in flight per lane) go out now and fly during its own row's Adam pass
-    constexpr int NRV = 16;
-    constexpr bool EARLY_ROWS = C * JM <= 42;   // (register budget of the 1024-thread block)
-    float rv[NCI][NRV];
-    const int part = tid & 3, nrow = (k.Hc - part + 3) / 4;
-    const bool conv_regs = EARLY_ROWS && last && fast_conv && nrow <= NRV;
-    if (EARLY_ROWS && conv_regs) {
+    for (int e = tid + NPA * CNT; e < n_lw; e += CNT) {   // (rows longer than the prologue fetched state for)
+      const int i = lw0 + e;
+      const float g = s_glw[e];
+      float mi = tl.ad.m[i], vi = tl.ad.v[i];
+      mi = mi + tl.ad.one_minus_b1 * (g - mi);
+      vi = vi * tl.ad.b2 + tl.ad.one_minus_b2 * g * g;
+      tl.ad.p[i] = tl.ad.p[i] - tl.ad.step_size * (mi / (sqrtf(vi) / tl.ad.sqrt_bc2 + tl.ad.eps));
+      tl.ad.m[i] = mi;
+      tl.ad.v[i] = vi;
+    }
+  }
+  STAMP(22);
+  if (last) {   // conv.weight, conv.bias of this filter pair
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (el_on) {
 #pragma unroll
-      for (int u = 0; u < NCI; ++u) {
-        const int ci = min((tid >> 2) + u * (CNT / 4), tl.lin_w - 1);
-        const float* src = tl.conv_slabs + (long long)part * tl.n_cv + (ci - tl.conv_w);
-#pragma unroll
-        for (int q = 0; q < NRV; ++q)
-          rv[u][q] = __hip_atomic_load(src + (long long)min(q, nrow - 1) * 4 * tl.n_cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int q = 0; q < NRV; q += 4) {
+        a0 += (q < nrow) ? rv[q] : 0.f;
+        a1 += (q + 1 < nrow) ? rv[q + 1] : 0.f;
+        a2 += (q + 2 < nrow) ? rv[q + 2] : 0.f;
+        a3 += (q + 3 < nrow) ? rv[q + 3] : 0.f;
       }
     }
-    if (tl.ad.p != nullptr) {   // Adam on this block's lin.weight row (its weights live in s_wl), two elements in flight
-      for (int e0 = tid; e0 < FQ; e0 += 2 * NT) {
-        const int e1 = min(e0 + NT, FQ - 1), i0 = tl.lin_w + m * FQ + e0, i1 = tl.lin_w + m * FQ + e1;
-        const float g0 = s_glw[e0], g1 = s_glw[e1];
-        float m0 = tl.ad.m[i0], v0 = tl.ad.v[i0], p0 = tl.ad.p[i0], m1 = tl.ad.m[i1], v1 = tl.ad.v[i1], p1 = tl.ad.p[i1];
-        m0 = m0 + tl.ad.one_minus_b1 * (g0 - m0);
-        v0 = v0 * tl.ad.b2 + tl.ad.one_minus_b2 * g0 * g0;
-        tl.ad.p[i0] = p0 - tl.ad.step_size * (m0 / (sqrtf(v0) / tl.ad.sqrt_bc2 + tl.ad.eps));
-        tl.ad.m[i0] = m0;
-        tl.ad.v[i0] = v0;
-        if (e0 + NT < FQ) {
-          m1 = m1 + tl.ad.one_minus_b1 * (g1 - m1);
-          v1 = v1 * tl.ad.b2 + tl.ad.one_minus_b2 * g1 * g1;
-          tl.ad.p[i1] = p1 - tl.ad.step_size * (m1 / (sqrtf(v1) / tl.ad.sqrt_bc2 + tl.ad.eps));
-          tl.ad.m[i1] = m1;
-          tl.ad.v[i1] = v1;
-        }
+    float g = (a0 + a1) + (a2 + a3);
+    g += __shfl_xor(g, 1, 64);
+    g += __shfl_xor(g, 2, 64);
+    if (el_on && part == 0) {
+      tl.grads[ci] = g;
+      if (tl.ad.p) {   // adam_apply with the prefetched state
+        const float mi = cm + tl.ad.one_minus_b1 * (g - cm);
+        const float vi = cv * tl.ad.b2 + tl.ad.one_minus_b2 * g * g;
+        tl.ad.p[ci] = cp - tl.ad.step_size * (mi / (sqrtf(vi) / tl.ad.sqrt_bc2 + tl.ad.eps));
+        tl.ad.m[ci] = mi;
+        tl.ad.v[ci] = vi;
       }
     }
-    STAMP(22);
-    if (last && fast_conv) {   // conv.weight, conv.bias
-#pragma unroll
-      for (int u = 0; u < NCI; ++u) {
-        const int ci = min((tid >> 2) + u * (CNT / 4), tl.lin_w - 1);
-        const float* src = tl.conv_slabs + (long long)part * tl.n_cv + (ci - tl.conv_w);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        if (EARLY_ROWS && conv_regs) {
-#pragma unroll
-          for (int q = 0; q < NRV; q += 4) {
-            a0 += (q < nrow) ? rv[u][q] : 0.f;
-            a1 += (q + 1 < nrow) ? rv[u][q + 1] : 0.f;
-            a2 += (q + 2 < nrow) ? rv[u][q + 2] : 0.f;
-            a3 += (q + 3 < nrow) ? rv[u][q + 3] : 0.f;
-          }
-        } else
-        for (int w = 0; w < nrow; w += 16) {
-          float v[16];
-#pragma unroll
-          for (int q = 0; q < 16; ++q)   // 16 sc1 loads in flight
-            v[q] = __hip_atomic_load(src + (long long)min(w + q, nrow - 1) * 4 * tl.n_cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-          for (int q = 0; q < 16; q += 4) {
-            a0 += (w + q < nrow) ? v[q] : 0.f;
-            a1 += (w + q + 1 < nrow) ? v[q + 1] : 0.f;
-            a2 += (w + q + 2 < nrow) ? v[q + 2] : 0.f;
-            a3 += (w + q + 3 < nrow) ? v[q + 3] : 0.f;
-          }
-        }
-        float g = (a0 + a1) + (a2 + a3);
-        g += __shfl_xor(g, 1, 64);
-        g += __shfl_xor(g, 2, 64);
-        if (part == 0 && (tid >> 2) + u * (CNT / 4) < tl.lin_w) {
-          tl.grads[ci] = g;
-          if (tl.ad.p) {   // adam_apply with the prefetched state
-            const float mi = cm[u] + tl.ad.one_minus_b1 * (g - cm[u]);
-            const float vi = cv[u] * tl.ad.b2 + tl.ad.one_minus_b2 * g * g;
-            tl.ad.p[ci] = cp[u] - tl.ad.step_size * (mi / (sqrtf(vi) / tl.ad.sqrt_bc2 + tl.ad.eps));
-            tl.ad.m[ci] = mi;
-            tl.ad.v[ci] = vi;
-          }
-        }
-      }
-    } else if (last) {   // more conv taps than that: generic loop
-      for (int i = tid; i < tl.lin_w; i += NT) tail_element(tl, i);
-    }
-    if (last) {
-      STAMP_ANY(25);
-    }
+    STAMP_ANY(25);
   }
 }
 
@@ -551,28 +568,29 @@ hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream) {
   }
   const int TB = k.B >= 2048 ? 2 * TBE : TBE;   // (a batch that fills the chip several times over: fewer, fatter blocks)
   const size_t lds = sizeof(float) * ((size_t)TB * k.CT + TB * 64 + 2 * (size_t)k.L * k.Hc + 64);
-  if (TB == TBE) {
-    (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel<TBE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    SLODE_LAUNCH("enc_fwd2", enc_fwd2_kernel<TBE>, dim3((k.B + TB - 1) / TB), dim3(FNT), lds, stream, k.x, k.zloc_w, k.zls_w, k.beff, k.weff, k);
-  } else {
-    (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel<2 * TBE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    SLODE_LAUNCH("enc_fwd2", enc_fwd2_kernel<2 * TBE>, dim3((k.B + TB - 1) / TB), dim3(FNT), lds, stream, k.x, k.zloc_w, k.zls_w, k.beff, k.weff, k);
-  }
+  const bool one = (k.CT & 1) == 0 && k.CT <= 128 * IU && (k.Hc + RB - 1) / RB <= FNT / 64;
+#define SLODE_ENC_FWD2(TT, OO)                                                                                                          \
+  do {                                                                                                                                \
+    (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel<TT, OO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+    SLODE_LAUNCH("enc_fwd2", (enc_fwd2_kernel<TT, OO>), dim3((k.B + TB - 1) / TB), dim3(FNT), lds, stream, k.x, k.zloc_w, k.zls_w, k.beff, k.weff, k); \
+  } while (0)
+  if (TB == TBE) { if (one) SLODE_ENC_FWD2(TBE, true); else SLODE_ENC_FWD2(TBE, false); }
+  else { if (one) SLODE_ENC_FWD2(2 * TBE, true); else SLODE_ENC_FWD2(2 * TBE, false); }
   return hipGetLastError();
 }
 
 hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream) {
+  if (!a.tail) return hipErrorInvalidValue;   // the chain launch always finishes the flat gradient (its only caller is the fused tail)
   FoldK k = make_foldk(a);
   const int JM = k.J <= 14 ? 14 : SLODE_MAX_K + SLODE_MAX_P;
-  const size_t lds = sizeof(float) * ((size_t)k.CT + 8 + 2 * ((size_t)k.FQ + 4) + (size_t)(1 + QCH) * k.F * k.C * JM);
-  const TailK tl = a.tail ? *a.tail : TailK{};
-  const int with_tail = a.tail ? 1 : 0;
-  const int riders = a.tail ? (tl.n_total + 1 - tl.lin_b + CNT - 1) / CNT : 0;
-  const dim3 grid(k.Hc + riders);
+  const size_t lds = sizeof(float) * ((size_t)k.CT + 8 + 2 * ((size_t)FPC * k.n_pool + 4) + 2 * (size_t)FPC * k.C * JM);
+  const TailK tl = *a.tail;
+  const int riders = (tl.n_total + 1 - tl.lin_b + CNT - 1) / CNT;
+  const dim3 grid(k.Hc * ((k.F + FPC - 1) / FPC) + riders);
 #define SLODE_CHAIN(CC, JJ)                                                                                          \
   do {                                                                                                               \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)enc_chain_kernel<CC, JJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    SLODE_LAUNCH("enc_chain", (enc_chain_kernel<CC, JJ>), grid, dim3(CNT), lds, stream, k.gslabs, k.lin_w, (const float*)k.wprime, k, tl, with_tail);                              \
+    SLODE_LAUNCH("enc_chain", (enc_chain_kernel<CC, JJ>), grid, dim3(CNT), lds, stream, k.gslabs, k.lin_w, (const float*)k.wprime, k, tl);                              \
   } while (0)
   if (k.C == 3 && JM == 14) SLODE_CHAIN(3, 14);
   else if (k.C == 4 && JM == 14) SLODE_CHAIN(4, 14);

@@ -263,7 +263,7 @@ static Workspace carve(slode_handle h, const slode_shape& s_in, const slode_layo
   w.glat = take((size_t)s.B * 128);
   w.gslabs2 = take((size_t)w.gsplit * s.L * (s.Hc + 1));
   w.gslabs3 = take((size_t)w.gsplit * s.L * (s.Hc + 1));
-  w.counter = reinterpret_cast<unsigned int*>(take(64));
+  w.counter = reinterpret_cast<unsigned int*>(take(32 * ((SLODE_MAX_F + 1) / 2)));   // one arrival counter per conv-filter pair, 128 B apart
   w.sigtab = take(4 * (size_t)s.C * s.T);
   if (dp5) {
     w.dp_kmax = slode_dopri5_kmax(s);

@@ -91,7 +91,7 @@ if hasattr(lib, "slode_debug_stamps_fold"):
     v = list(buf)
     print("== folded-encoder kernels, workgroup 0 (us)")
     for lab, i, j in (("weff: w' to LDS", 0, 1), ("weff: W_eff rows", 1, 2), ("enc_fwd2: loads", 8, 9), ("enc_fwd2: lin+tanh", 9, 10), ("enc_fwd2:   W_eff stream+FMA (wave 0)", 9, 12), ("enc_fwd2:   wave sums+tanh (wave 0)", 12, 13), ("enc_fwd2:   wait for other waves", 13, 10),
-                      ("enc_fwd2: heads", 10, 11), ("chain: staging", 16, 17), ("chain: (i) lin.w", 17, 18), ("chain: (ii) w' partial", 18, 19),
+                      ("enc_fwd2: heads", 10, 11), ("chain: staging", 16, 17), ("chain: (i) lin.w", 17, 18), ("chain: (ii) on the other waves + barrier", 18, 19),
                       ("chain: conv taps", 19, 20), ("chain: barrier (block 0)", 20, 21), ("chain: Adam pass (block 0)", 21, 22), ("chain: 2nd barrier (block 0)", 22, 23),
                       ("chain: start -> last block enters conv sum", 16, 24), ("chain: last block conv sum + Adam", 24, 25), ("chain: start -> rider 0 start", 16, 26), ("chain: rider 0", 26, 27)):
         if v[i] and v[j]:
