@@ -54,10 +54,12 @@ struct FoldK {
 __device__ __forceinline__ int kappa_of(const FoldK& k, int c, int t) { return k.t_major ? t * k.C + c : c * k.T + t; }
 
 // ---- fold: W_eff, rowsum, b_eff, w' ---------------------------------------------------------------------------------
-constexpr int WPB = 128;   // W_eff outputs per 256-thread block of weff_kernel
+constexpr int WPB = 128;   // W_eff outputs per block of weff_kernel
+constexpr int WFG = 4;     // threads per output (filter groups): 8 waves per CU instead of 4 -- the output loop is latency-bound
+constexpr int WNT = WPB * WFG;
 template <int JM>  // compile-time bound on J = K + P - 1 (14 for every reference config)
 // (pl_*: the pointers of the kernel's first loads as leading arguments -- preloaded into SGPRs at wave launch, see ode_elbo_kernel)
-__global__ void __launch_bounds__(256) weff_kernel(const float* __restrict__ pl_conv_w, const float* __restrict__ pl_lin_w, const FoldK k,
+__global__ void __launch_bounds__(WNT) weff_kernel(const float* __restrict__ pl_conv_w, const float* __restrict__ pl_lin_w, const FoldK k,
                                                    const int stage_rows) {
   __shared__ float s_wp[SLODE_MAX_F * SLODE_MAX_C * JM];
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [F*C*K conv taps][stage_rows ? the block's lin.weight rows : 0]
@@ -66,28 +68,38 @@ __global__ void __launch_bounds__(256) weff_kernel(const float* __restrict__ pl_
   if (blockIdx.x == 0 && tid < 8 && k.counter) k.counter[32 * tid] = 0u;   // arrival counters of this step's chain blocks (one per filter pair, 128 B apart)
   STAMP(0);
   const int n_w = k.Hc * k.CT;
-  const int nb_w = (n_w + WPB - 1) / WPB;
+  const int nb_w = (n_w + WPB - 1) / WPB, nb_rs = (k.Hc + WNT / 64 - 1) / (WNT / 64);
   float* s_cw = smem;
   float* s_lw = smem + ((k.F * C * K + 3) & ~3);
   // Everything this block reads from global memory is fetched in ONE batch: the conv taps, and (W_eff blocks) the lin.weight rows
   // of the hidden units its WPB outputs belong to (2 for C*T >= WPB) -- coalesced, instead of F*JM = 140 strided loads per thread.
   const int e_first = (int)blockIdx.x * WPB, m0 = min(e_first, n_w - 1) / k.CT, m1 = min(e_first + WPB - 1, n_w - 1) / k.CT;
-  for (int i = tid; i < k.F * C * K; i += 256) s_cw[i] = pl_conv_w[i];
-  if (stage_rows && (int)blockIdx.x < nb_w) {
-    const int n_st = (m1 - m0 + 1) * k.FQ;
+  {
+    // (the conv taps and the rows are requested together and only then stored: two loops would be two round trips)
+    const int n_cw = k.F * C * K;
+    const bool rows = stage_rows && (int)blockIdx.x < nb_w;
+    const int n_st = rows ? (m1 - m0 + 1) * k.FQ : 0;
     const float* src = pl_lin_w + (long long)m0 * k.FQ;
-    for (int i0 = tid; i0 < n_st; i0 += 16 * 256) {
-      float v[16];
+    const float cw0 = pl_conv_w[min(tid, n_cw - 1)];
+    float v[8];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) v[q] = src[min(i0 + q * 256, n_st - 1)];
+    for (int q = 0; q < 8; ++q) v[q] = rows ? src[min(tid + q * WNT, n_st - 1)] : 0.f;
+    if (tid < n_cw) s_cw[tid] = cw0;
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
-        if (i0 + q * 256 < n_st) s_lw[i0 + q * 256] = v[q];
+    for (int q = 0; q < 8; ++q)
+      if (tid + q * WNT < n_st) s_lw[tid + q * WNT] = v[q];
+    for (int i = tid + WNT; i < n_cw; i += WNT) s_cw[i] = pl_conv_w[i];
+    for (int i0 = tid + 8 * WNT; i0 < n_st; i0 += 8 * WNT) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = src[min(i0 + q * WNT, n_st - 1)];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (i0 + q * WNT < n_st) s_lw[i0 + q * WNT] = v[q];
     }
   }
   __syncthreads();
   // w'[f][c][j] = (1/P) * sum_{k + p = j} w[f][c][k]   (rows padded to JM, zero beyond J)
-  for (int e = tid; e < k.F * C * JM; e += 256) {
+  for (int e = tid; e < k.F * C * JM; e += WNT) {
     const int j = e % JM, fc = e / JM;
     float s = 0.f;
     for (int p = 0; p < k.P; ++p) {
@@ -101,8 +113,8 @@ __global__ void __launch_bounds__(256) weff_kernel(const float* __restrict__ pl_
   __syncthreads();
   STAMP(1);
   if ((int)blockIdx.x < nb_w) {
-    // WPB = 128 outputs per block, two threads per output (each half of the filters): ~250 blocks fill the 256 CUs
-    const int el = tid & (WPB - 1), fh = tid / WPB, fper = (k.F + 1) / 2;
+    // WPB = 128 outputs per block, WFG threads per output (each a group of the filters): ~250 blocks fill the 256 CUs
+    const int el = tid & (WPB - 1), fh = tid / WPB, fper = (k.F + WFG - 1) / WFG;
     const int e = min((int)blockIdx.x * WPB + el, n_w - 1);
     const int m = e / k.CT, kap = e - m * k.CT;
     int c, t;
@@ -122,15 +134,20 @@ __global__ void __launch_bounds__(256) weff_kernel(const float* __restrict__ pl_
         if (j + 1 < JM) acc1 = fmaf((t - j - 1 >= 0 && t - j - 1 < k.n_pool) ? v[j + 1] : 0.f, wp[j + 1], acc1);
       }
     }
-    __shared__ float s_half[WPB];
-    if (fh == 1) s_half[el] = acc0 + acc1;
+    __shared__ float s_half[(WFG - 1) * WPB];
+    if (fh > 0) s_half[(fh - 1) * WPB + el] = acc0 + acc1;
     __syncthreads();
-    if (fh == 0 && (int)blockIdx.x * WPB + el < n_w) k.weff[e] = (acc0 + acc1) + s_half[el];
+    if (fh == 0 && (int)blockIdx.x * WPB + el < n_w) {
+      float r = acc0 + acc1;
+#pragma unroll
+      for (int g = 1; g < WFG; ++g) r += s_half[(g - 1) * WPB + el];   // fixed order
+      k.weff[e] = r;
+    }
     STAMP(2);
-  } else if ((int)blockIdx.x >= nb_w + (k.Hc + 3) / 4) {
+  } else if ((int)blockIdx.x >= nb_w + nb_rs) {
     // likelihood scales of this step (decoders.py:52-53: softplus(constant_std)) and what the likelihood and its gradient need of them:
     // parameter-only, so once per step here instead of once per trajectory in the ODE/ELBO kernel (same functions: same bits)
-    const int i = ((int)blockIdx.x - nb_w - (k.Hc + 3) / 4) * 256 + tid;
+    const int i = ((int)blockIdx.x - nb_w - nb_rs) * WNT + tid;
     if (i < k.CT) {
       const float sig = softplusf(k.cstd[i]);
       k.sigtab[i] = sig;
@@ -140,7 +157,7 @@ __global__ void __launch_bounds__(256) weff_kernel(const float* __restrict__ pl_
     }
   } else {
     // one wave per hidden unit m: rowsum[m][f] for every f, then b_eff[m]
-    const int m = ((int)blockIdx.x - nb_w) * 4 + (tid >> 6), lane = tid & 63;
+    const int m = ((int)blockIdx.x - nb_w) * (WNT / 64) + (tid >> 6), lane = tid & 63;
     if (m < k.Hc) {
       // all F partial sums advance together so F loads are in flight per pass (a serial f loop costs one HBM round trip per filter)
       float sv[SLODE_MAX_F];
@@ -216,6 +233,7 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
   float* s_hid = s_x + TB * CT;      // [TB][64]
   float* s_hw = s_hid + TB * 64;     // [2][L][Hc]
   float* s_be = s_hw + 2 * L * Hc;   // [64] b_eff
+  float* s_hb = s_be + 64;           // [2][L] head biases
   const int b0 = blockIdx.x * TB;
   STAMP(8);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = NT >> 6;   // wave-uniform => row pointers in SGPRs
@@ -230,19 +248,37 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
     }
   }
   {
-    // raw rows: the block's TB * CT floats are contiguous in memory (dense rows); four loads in flight per thread
+    // raw rows (the block's TB * CT floats are contiguous in memory: dense rows), head weights, b_eff, head biases: every global load of
+    // the prologue is requested before the first LDS store (separate load-store loops are separate round trips)
     const long long base = (long long)b0 * CT, lim = (long long)k.B * CT - 1;
-    for (int e0 = tid; e0 < TB * CT; e0 += 4 * NT) {
-      float v[4];
+    float v[4], hw[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = pl_x[min(base + tid + q * NT, lim)];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = min(tid + q * NT, 2 * L * Hc - 1);
+      hw[q] = (e < L * Hc) ? pl_zloc_w[e] : pl_zls_w[e - L * Hc];
+    }
+    const float bev = pl_beff[min(tid, Hc - 1)];
+    const int hbi = min(max(tid - 64, 0), 2 * L - 1);
+    const float hbv = (hbi < L) ? k.zloc_b[hbi] : k.zls_b[hbi - L];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (tid + q * NT < TB * CT) s_x[tid + q * NT] = v[q];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (tid + q * NT < 2 * L * Hc) s_hw[tid + q * NT] = hw[q];
+    if (tid < Hc) s_be[tid] = bev;
+    if (tid >= 64 && tid < 64 + 2 * L) s_hb[tid - 64] = hbv;
+    for (int e0 = tid + 4 * NT; e0 < TB * CT; e0 += 4 * NT) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = pl_x[min(base + e0 + q * NT, lim)];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (e0 + q * NT < TB * CT) s_x[e0 + q * NT] = v[q];
     }
+    for (int e = tid + 2 * NT; e < 2 * L * Hc; e += NT) s_hw[e] = (e < L * Hc) ? pl_zloc_w[e] : pl_zls_w[e - L * Hc];
   }
-  for (int e = tid; e < 2 * L * Hc; e += NT) s_hw[e] = (e < L * Hc) ? pl_zloc_w[e] : pl_zls_w[e - L * Hc];
-  if (tid < Hc) s_be[tid] = pl_beff[tid];
   __syncthreads();
   STAMP(9);
   if (ONE) {
@@ -313,7 +349,7 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
     acc += __shfl_xor(acc, 4, 64);
     acc += __shfl_xor(acc, 2, 64);
     acc += __shfl_xor(acc, 1, 64);
-    acc += which ? k.zls_b[l] : k.zloc_b[l];
+    acc += s_hb[which * L + l];
     if (l16 == 0 && e0 < TB * L * 2 && b0 + tb < k.B) {
       if (which) k.scale[(long long)(b0 + tb) * L + l] = expf(acc);
       else k.loc[(long long)(b0 + tb) * L + l] = acc;
@@ -331,6 +367,7 @@ constexpr int CNT = 640;    // threads of a chain / rider block
 constexpr int CNT1 = 384;   // ... of which run contraction (i); the other 256 run (ii)
 constexpr int FPC = 2;      // conv filters per chain block
 constexpr int QCH = 32;     // q-chunks of (ii): the half-wave of an (f, c) pair
+constexpr int PERM = 8;     // weights a lane of (ii) holds in registers at a time
 constexpr int NPA = 2;      // Adam passes of a block's lin.weight piece whose state is fetched in the prologue
 static_assert(4 * (FPC * SLODE_MAX_C * SLODE_MAX_K + FPC) <= CNT, "four lanes per conv element in the last block of a filter pair");
 static_assert(SLODE_MAX_HC <= 64, "the last block holds ceil(Hc / 4) <= 16 row values per lane");
@@ -370,14 +407,22 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
     const bool on = tl.ad.p != nullptr && tid + u * CNT < n_lw;
     am[u] = on ? tl.ad.m[i] : 0.f; av[u] = on ? tl.ad.v[i] : 0.f; ap[u] = on ? tl.ad.p[i] : 0.f;
   }
+  const float rs = k.rowsum[m * F + f0 + min(tid, nf - 1)];   // (for the conv.bias column: requested here, used behind the contractions)
   // split-K partials of row m: all of a column's loads in flight at once (a loop of load-then-add costs one L2 / HBM round trip per
   // partial: the GEMM launch wrote them from other CUs), summed in fixed order
-  for (int i = tid; i < GN; i += CNT) s_G[i] = strided_sum(pl_gslabs + (long long)m * GN + i, k.Hc * GN, k.n_gslabs);
-  for (int i = tid; i < n_lw; i += CNT) s_wl[i] = pl_lin_w[(long long)m * FQ + f0 * n_pool + i];
-  for (int i = tid; i < nf * C * JM; i += CNT) {
-    const int j = i % JM, fc = i / JM;
-    s_wp[i] = (j < J) ? pl_wprime[(f0 * C + fc) * J + min(j, J - 1)] : 0.f;
+  {
+    // (row sums, the lin.weight piece and w' are requested together and only then stored: three loops would be three round trips)
+    const float g0 = strided_sum(pl_gslabs + (long long)m * GN + min(tid, GN - 1), k.Hc * GN, k.n_gslabs);
+    const float wl0 = pl_lin_w[(long long)m * FQ + f0 * n_pool + min(tid, n_lw - 1)];
+    const int i = min(tid, nf * C * JM - 1), j = i % JM, fc = i / JM;
+    const float wp0 = (j < J) ? pl_wprime[(f0 * C + fc) * J + min(j, J - 1)] : 0.f;
+    if (tid < GN) s_G[tid] = g0;
+    if (tid < n_lw) s_wl[tid] = wl0;
+    if (tid < nf * C * JM) s_wp[tid] = wp0;
   }
+  for (int i = tid + CNT; i < GN; i += CNT) s_G[i] = strided_sum(pl_gslabs + (long long)m * GN + i, k.Hc * GN, k.n_gslabs);
+  for (int i = tid + CNT; i < n_lw; i += CNT) s_wl[i] = pl_lin_w[(long long)m * FQ + f0 * n_pool + i];
+  static_assert(FPC * SLODE_MAX_C * (SLODE_MAX_K + SLODE_MAX_P) <= CNT, "w' of a filter pair is staged in one pass");
   __syncthreads();
   STAMP(17);
   const float gb = s_G[CT];
@@ -399,8 +444,7 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
     STAMP(18);
   } else {
     // (ii) dLoss/dw'[f][c][j] (this m) = sum_q G[kappa(c, q+j)] * lin.weight[m][f*n_pool + q]: the 32 lanes of a half-wave share (f, c) and
-    // split q; a lane keeps all JM taps in registers and slides a JM-wide window of G along its q range (2 LDS reads per JM FMAs); the
-    // half-wave's partial sums meet in an xor butterfly (fixed order)
+    // split q; the half-wave's partial sums meet in a fixed-order reduction
     const int per = (n_pool + QCH - 1) / QCH;
     for (int e0 = tid - CNT1; e0 < ((nf * C * QCH + 63) & ~63); e0 += CNT - CNT1) {   // wave-uniform trip count
       const bool valid = e0 < nf * C * QCH;
@@ -409,23 +453,32 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
       const int q0 = min(ch * per, n_pool), q1 = valid ? min(n_pool, q0 + per) : q0;
       const float* wl = s_wl + fl * n_pool;
       const float* gp = s_G + c * sC;
-      float acc[JM], win[JM];
+      float acc[JM];
 #pragma unroll
-      for (int j = 0; j < JM; ++j) { acc[j] = 0.f; win[j] = gp[min(q0 + j, T - 1) * sT]; }
-      for (int q = q0; q < q1; ++q) {
-        const float w = wl[q];
+      for (int j = 0; j < JM; ++j) acc[j] = 0.f;
+      // PERM weights and the PERM + JM - 1 samples of G they meet, in registers: PERM * JM FMAs for 2 * PERM + JM - 1 LDS reads, no window to shift
+      for (int qq = q0; qq < q1; qq += PERM) {
+        float wv[PERM], gv[PERM + JM - 1];
 #pragma unroll
-        for (int j = 0; j < JM; ++j) acc[j] = fmaf(win[j], w, acc[j]);
+        for (int i = 0; i < PERM; ++i) wv[i] = wl[min(qq + i, n_pool - 1)];
 #pragma unroll
-        for (int j = 0; j + 1 < JM; ++j) win[j] = win[j + 1];
-        win[JM - 1] = gp[min(q + JM, T - 1) * sT];
+        for (int i = 0; i < PERM + JM - 1; ++i) gv[i] = gp[min(qq + i, T - 1) * sT];
+#pragma unroll
+        for (int i = 0; i < PERM; ++i) wv[i] = (qq + i < q1) ? wv[i] : 0.f;
+#pragma unroll
+        for (int j = 0; j < JM; ++j)
+#pragma unroll
+          for (int i = 0; i < PERM; ++i) acc[j] = fmaf(gv[i + j], wv[i], acc[j]);
       }
+      // half-wave sum: four DPP adds inside the 16-lane rows, then the two rows of the half-wave (one batch of ds_bpermute)
+      float t[JM];
 #pragma unroll
-      for (int j = 0; j < JM; ++j) {
-        float v = acc[j];
+      for (int j = 0; j < JM; ++j) acc[j] = row16_sum(acc[j]);
 #pragma unroll
-        for (int off = QCH / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (valid && ch == 0) s_pw[fc * JM + j] = (j < J) ? v : 0.f;
+      for (int j = 0; j < JM; ++j) t[j] = __shfl_xor(acc[j], 16, 64);
+      if (valid && ch == 0) {
+#pragma unroll
+        for (int j = 0; j < JM; ++j) s_pw[fc * JM + j] = (j < J) ? acc[j] + t[j] : 0.f;
       }
     }
   }
@@ -440,7 +493,7 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
     for (int p = 0; p < k.P; ++p) s += s_pw[fc * JM + kk + p];
     __hip_atomic_store(row + f0 * C * K + e, s / fP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the pair's last block
   }
-  if (tid < nf) __hip_atomic_store(row + F * C * K + f0 + tid, gb * k.rowsum[m * F + f0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < nf) __hip_atomic_store(row + F * C * K + f0 + tid, gb * rs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   STAMP(20);
   // Hand-off of the conv rows to the pair's last block to arrive, without a cache-wide release: the rows are stored with agent-scope (sc1,
   // write-through) stores; EVERY storing wave drains them (explicit s_waitcnt vmcnt(0) below: the compiler does not emit one for a
@@ -553,7 +606,7 @@ int slode_fold_small_count(const slode_shape& s) { return s.Hc + 2 * (s.L * s.Hc
 
 hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream) {
   FoldK k = make_foldk(a);
-  const int nb_w = (k.Hc * k.CT + WPB - 1) / WPB, nb_r = (k.Hc + 3) / 4 + (k.sigtab ? (k.CT + 255) / 256 : 0);
+  const int nb_w = (k.Hc * k.CT + WPB - 1) / WPB, nb_r = (k.Hc + WNT / 64 - 1) / (WNT / 64) + (k.sigtab ? (k.CT + WNT - 1) / WNT : 0);
   // dynamic LDS: conv taps + (when they fit) the lin.weight rows a block's WPB consecutive outputs can touch
   const size_t cw = ((size_t)k.F * k.C * k.K + 3) & ~(size_t)3;
   const size_t max_rows = (size_t)(WPB - 1) / k.CT + 2;   // WPB outputs starting anywhere inside a row of CT
@@ -561,13 +614,13 @@ hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream) {
   const size_t wlds = sizeof(float) * (cw + (stage_rows ? max_rows * (size_t)k.FQ : 0));
   if (k.J <= 14) {
     if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)weff_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
-    SLODE_LAUNCH("weff", (weff_kernel<14>), dim3(nb_w + nb_r), dim3(256), wlds, stream, k.conv_w, k.lin_w, k, stage_rows);
+    SLODE_LAUNCH("weff", (weff_kernel<14>), dim3(nb_w + nb_r), dim3(WNT), wlds, stream, k.conv_w, k.lin_w, k, stage_rows);
   } else {
     if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)weff_kernel<SLODE_MAX_K + SLODE_MAX_P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
-    SLODE_LAUNCH("weff", (weff_kernel<SLODE_MAX_K + SLODE_MAX_P>), dim3(nb_w + nb_r), dim3(256), wlds, stream, k.conv_w, k.lin_w, k, stage_rows);
+    SLODE_LAUNCH("weff", (weff_kernel<SLODE_MAX_K + SLODE_MAX_P>), dim3(nb_w + nb_r), dim3(WNT), wlds, stream, k.conv_w, k.lin_w, k, stage_rows);
   }
   const int TB = k.B >= 2048 ? 2 * TBE : TBE;   // (a batch that fills the chip several times over: fewer, fatter blocks)
-  const size_t lds = sizeof(float) * ((size_t)TB * k.CT + TB * 64 + 2 * (size_t)k.L * k.Hc + 64);
+  const size_t lds = sizeof(float) * ((size_t)TB * k.CT + TB * 64 + 2 * (size_t)k.L * k.Hc + 64 + 2 * (size_t)k.L);
   const bool one = (k.CT & 1) == 0 && k.CT <= 128 * IU && (k.Hc + RB - 1) / RB <= FNT / 64;
 #define SLODE_ENC_FWD2(TT, OO)                                                                                                          \
   do {                                                                                                                                \

@@ -90,6 +90,21 @@ __device__ __forceinline__ float wave_sum16(float (&a)[16], int lane) {
   return r;
 }
 
+// One DPP move of a float (quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140): a VALU
+// operand modifier, no LDS-pipe round trip (ds_bpermute)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row, valid in every lane of the row (fixed order: xor 1, xor 2, half mirror, mirror)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);
+  return v;
+}
+
 // sum_{w < n} p[w * stride] with 16 loads in flight; fixed order (four round-robin partial sums, combined pairwise)
 __device__ __forceinline__ float strided_sum(const float* p, int stride, int n) {
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
