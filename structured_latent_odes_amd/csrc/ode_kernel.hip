@@ -36,8 +36,8 @@ __device__ unsigned long long g_stamps_ode[32];
 __device__ unsigned long long g_stamps_ode_late[32];   // the same phase boundaries for workgroup 1000 (last residency slot of its CU)
 __device__ unsigned long long g_wg_span[2 * 4096];   // [start, end] of every workgroup
 __device__ unsigned int g_wg_hw[2 * 4096];            // [HW_ID, XCC_ID] of every workgroup's wave 0
-#define STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); if (blockIdx.x == 0) g_stamps_ode[i] = t_; if (blockIdx.x == 1000) g_stamps_ode_late[i] = t_; \
-    if ((i) == 0 && blockIdx.x < 4096) { g_wg_span[2 * blockIdx.x] = t_; g_wg_hw[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 4); g_wg_hw[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } if ((i) == 11 && blockIdx.x < 4096) g_wg_span[2 * blockIdx.x + 1] = t_; } } while (0)
+#define STAMP(i) do { if (tid_outer == 0) { const unsigned long long t_ = wall_clock64(); if (vblk == 0) g_stamps_ode[i] = t_; if (vblk == 1000) g_stamps_ode_late[i] = t_; \
+    if ((i) == 0 && vblk < 4096) { g_wg_span[2 * vblk] = t_; g_wg_hw[2 * vblk] = __builtin_amdgcn_s_getreg((31 << 11) | 4); g_wg_hw[2 * vblk + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } if ((i) == 11 && vblk < 4096) g_wg_span[2 * vblk + 1] = t_; } } while (0)
 extern "C" int slode_debug_stamps_ode(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_ode), sizeof(unsigned long long) * 32);
 }
@@ -62,8 +62,8 @@ extern "C" int slode_debug_wg_span(unsigned long long* out, int n) {
 // every co-resident workgroup is busy -- so what it lacks is issue slots and LDS cycles, not priority.  Staggering the START of the
 // co-resident workgroups (slot s idles s x 0.4 .. 2.4 us behind its set-up loads, so that their all-wave phases coincide less) does not
 // help either: the kernel gets longer by about 0.6 x the last slot's delay (27.3 -> 27.2 / 29.0 / 28.6 / 30.1 / 31.8 us).
-#define STAMP(i) do { if (((i) + prio_slot) & 1) { if (threadIdx.x < 64) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); } \
-                      else { if (threadIdx.x < 64) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } } while (0)
+#define STAMP(i) do { if (((i) + prio_slot) & 1) { if (tid_outer < 64) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); } \
+                      else { if (tid_outer < 64) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } } while (0)
 #endif
 
 namespace {
@@ -508,8 +508,12 @@ __host__ __device__ constexpr int ode_max_threads(int S, int T_, int C_, int Q_,
 // nothing but the scalar loss partial is carried in registers from one trajectory to the next (the round-1 looped form kept
 // 2S+2 accumulators per thread live across the loop, spilled, and hipcc placed one spill store ahead of the exec restore of a
 // control-flow join -- wrong gradients; tools/check_spills.py now rejects any kernel that uses scratch).
-template <int S, int H, bool BWD, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1, bool RA = false, bool ONE = false, int ALG = 0>
-__global__ void __launch_bounds__(ode_max_threads(S, T_, C_, Q_, ONE, BWD))
+// PK > 1 (shape-specialised loop-free forms only): PK trajectories share one workgroup of PK * NT threads -- each trajectory keeps its own
+// NT threads (whole waves), its own LDS region and its own slab row, exactly as if it were a workgroup of its own ("virtual workgroup"
+// vblk = blockIdx * PK + trajectory); only the barriers are shared.  The serial wave of trajectory i is the workgroup's wave
+// i * NW + i: the four serial waves sit on four different SIMDs.
+template <int S, int H, bool BWD, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1, bool RA = false, bool ONE = false, int ALG = 0, int PK = 1>
+__global__ void __launch_bounds__(PK > 1 ? PK * ode_threads_for(T_ ? T_ : 1, Q_ ? Q_ : 1, C_ ? C_ : 1, S) : ode_max_threads(S, T_, C_, Q_, ONE, BWD))
 ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ pl_pseg, const float* __restrict__ pl_loc,
                 const float* __restrict__ pl_scale, const float* __restrict__ pl_eps, const float* __restrict__ pl_u,
                 const float* __restrict__ pl_sigtab, const OdeK k) {
@@ -517,8 +521,13 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   // they are PRELOADED into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, Makefile), so the first global loads of the
   // set-up go out at once instead of behind an s_load of the kernel-argument segment -- one of the two serialised cold misses every
   // kernel of the step starts with.
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x;
+  static_assert(PK == 1 || (ONE && T_ > 0), "packed trajectories: shape-specialised loop-free forms only");
+  extern __shared__ __attribute__((aligned(16))) float smem_wg[];
+  constexpr int NWT = PK > 1 ? ode_threads_for(T_ ? T_ : 1, Q_ ? Q_ : 1, C_ ? C_ : 1, S) / 64 : 1;   // waves per trajectory (PK > 1)
+  const int wave_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int traj = PK > 1 ? wave_wg / NWT : 0;
+  const int tid = PK > 1 ? (((wave_wg % NWT) + NWT - (traj % NWT)) % NWT) * 64 + (int)(threadIdx.x & 63) : (int)threadIdx.x;
+  const int vblk = PK > 1 ? (int)blockIdx.x * PK + traj : (int)blockIdx.x, vgrid = (int)gridDim.x * PK;
   const int T = T_ ? T_ : k.T, C = C_ ? C_ : k.C, L = L_ ? L_ : k.L, Q = Q_ ? Q_ : k.Q;
   const int method = M_ >= 0 ? M_ : k.method;
   const int R = M_ >= 0 ? (M_ == SLODE_EULER ? 1 : (M_ == SLODE_MIDPOINT ? 2 : 3)) : k.R;
@@ -529,6 +538,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   const int NT = T_ ? ode_threads_for(T_, Q_, C_, S) : (int)blockDim.x;
   constexpr bool COLDG = ode_cold_global(L_);
   const LdsMap m = lds_map(T, S, H, C, L, Q, n_stage_t, COLDG ? ode_hot_floats(S, H) : k.npar, NT, k.n_aux_lds, ONE, ALG == 3);
+  float* const smem = smem_wg + (PK > 1 ? traj * m.total : 0);
   float* s_ts = smem + m.ts;
   float* s_sig = smem + m.sig;
   float* s_A = smem + m.A;
@@ -588,10 +598,10 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   const cptr wg = (cptr)k.wg, bg = (cptr)k.bg, wd = (cptr)k.wd, bd = (cptr)k.bd;
   // wave 0 carries every serial stretch of a trajectory (latent sample, switching indices, table, both scans): it issues ahead of the
   // bulk waves of the co-resident workgroups
-  const int prio_slot = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 8));   // residency slot on its CU (dispatch order: 256 CUs per pass)
+  const int prio_slot = PK > 1 ? traj : __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 8));   // residency slot on its CU (dispatch order: 256 CUs per pass)
   (void)prio_slot;
-  STAMP(0);
   const int tid_outer = tid;
+  STAMP(0);
   // scoring an externally solved trajectory (dopri5 training, generic instantiation): no solve, nothing flows through a solver here
   const bool ext = (ALG == 3) || ((T_ == 0) && k.x_ext != nullptr);   // ALG 3: shape-specialised scorer (every solver phase is dead code)
 
@@ -652,7 +662,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     if (COLDG && tid < H) v_wt = pl_pseg[k.o_wh + tid * (1 + L)];
     float v_l0 = 0.f, v_l1 = 1.f, v_l2 = 0.f, v_u = 0.f;
     float v_c[SLODE_MAX_C] = {0.f, 0.f, 0.f, 0.f};
-    const int b_first = blockIdx.x;
+    const int b_first = vblk;
     if (b_first < k.B) {
       const int lc = min(tid, L - 1);
       v_l0 = pl_loc[(long long)b_first * L + lc];     // (pure solve: z_in)
@@ -699,7 +709,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   }
   STAMP(13);
   if (BWD) {   // elements no phase owns (e.g. label-head parameters the main loss does not score): zero gradient
-    float* sl = k.slabs + (long long)blockIdx.x * k.slab_stride + 1;
+    float* sl = k.slabs + (long long)vblk * k.slab_stride + 1;
     for (int z = 0; z < k.nz; ++z)
       for (int i = k.zlo[z] + tid; i < k.zhi[z]; i += NT) sl[i] = 0.f;
   }
@@ -724,22 +734,22 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   bool ts_bad = false;
   STAMP(1);
 
-  for (int b = blockIdx.x; b < k.B; b += gridDim.x) {
+  for (int b = vblk; b < k.B; b += vgrid) {
     // Launder the thread id once per trajectory: with it opaque, the compiler cannot hoist the dozens of per-thread
     // address computations of the phases below out of this loop (which only lengthens live ranges and spills).
     int tid = tid_outer;
     if (!ONE) asm volatile("" : "+v"(tid));
     // Every gradient element of the segment has exactly one owning thread per trajectory and goes straight to this workgroup's
     // slab (no LDS copy): written on the workgroup's first trajectory, added to on later ones (same owner, program order).
-    float* const sl1 = k.slabs + (long long)blockIdx.x * k.slab_stride + 1;
-    const bool first_traj = ONE || b == (int)blockIdx.x;
+    float* const sl1 = k.slabs + (long long)vblk * k.slab_stride + 1;
+    const bool first_traj = ONE || b == vblk;
     auto accum = [&](int idx, float v) { float* d = sl1 + idx; *d = first_traj ? v : (*d + v); };
-    if (COLDB && !ONE && b != (int)blockIdx.x) {
+    if (COLDB && !ONE && b != vblk) {
       __syncthreads();   // the previous trajectory's last readers of the work block (its encoder-head block) are done
       stage_cold();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (!ONE && b != (int)blockIdx.x) __syncthreads();   // s_pf / s_uu of this trajectory are in place (first one: the setup barrier)
+    if (!ONE && b != vblk) __syncthreads();   // s_pf / s_uu of this trajectory are in place (first one: the setup barrier)
 
     // ---- P0a: latent sample, log q, log p (mechanistic_cvs.py:125-135, 225-237) -------------------------
     if (tid < L) {
@@ -1210,9 +1220,9 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
             }
           }
           if (BWD) {  // constant_std gradient: thread t owns slab entry (c, t); softplus'(x) = 1 - exp(-softplus(x))
-            float* dst = k.slabs + (long long)blockIdx.x * k.slab_stride + 1 + k.o_cstd + c * T + t;
+            float* dst = k.slabs + (long long)vblk * k.slab_stride + 1 + k.o_cstd + c * T + t;
             const float val = gsig * (use_tab ? t_ds[c] : 1.f - expf(-sig));
-            *dst = (ONE || b == (int)blockIdx.x) ? val : (*dst + val);
+            *dst = (ONE || b == vblk) ? val : (*dst + val);
           }
         }
         loss_acc -= ll;
@@ -1777,8 +1787,8 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
       }
       k.g_pre[(long long)b * 64 + mm] = (g0 + g1) * (1.f - hv * hv);
     }
-    if (!ONE && b + (int)gridDim.x < k.B && tid >= 64 && tid < 128) {   // next trajectory's latent inputs (P0a is long past)
-      const int bn = b + gridDim.x, t1 = tid - 64;
+    if (!ONE && b + vgrid < k.B && tid >= 64 && tid < 128) {   // next trajectory's latent inputs (P0a is long past)
+      const int bn = b + vgrid, t1 = tid - 64;
       if (t1 < L) {
         if (k.loc != nullptr) {
           const float a0 = k.loc[(long long)bn * L + t1], a1 = k.scale[(long long)bn * L + t1], a2 = k.eps[(long long)bn * L + t1];
@@ -1794,7 +1804,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   }  // trajectories
 
   // ---- workgroup epilogue: loss partial, then the LDS gradient segment leaves as one slab ------------------------------
-  float* slab = k.slabs + (long long)blockIdx.x * k.slab_stride;
+  float* slab = k.slabs + (long long)vblk * k.slab_stride;
   if (ts_bad) loss_acc = __builtin_nanf("");
   const float lw = wave_sum(loss_acc);
   if ((tid & 63) == 0) s_red[tid >> 6] = lw;
@@ -1813,9 +1823,9 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   STAMP(11);
 }
 
-template <int S, int H, bool BWD, int T_, int C_, int L_, int Q_, int M_, bool RA, bool ONE, int ALG>
+template <int S, int H, bool BWD, int T_, int C_, int L_, int Q_, int M_, bool RA, bool ONE, int ALG, int PK = 1>
 hipError_t launch_one(const OdeK& k, int grid, int nthreads, size_t lds, hipStream_t stream) {
-  auto fn = ode_elbo_kernel<S, H, BWD, T_, C_, L_, Q_, M_, RA, ONE, ALG>;
+  auto fn = ode_elbo_kernel<S, H, BWD, T_, C_, L_, Q_, M_, RA, ONE, ALG, PK>;
   (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   SLODE_LAUNCH("ode_elbo", fn, dim3(grid), dim3(nthreads), lds, stream, k.stage_t, k.pseg, k.loc ? k.loc : k.z_in, k.loc ? k.scale : nullptr,
                k.eps, k.u, k.sigtab ? k.sigtab : k.cstd, k);
@@ -1984,6 +1994,12 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
     if (a.alg == 2) return launch_one<5, 25, true, 200, 3, 8, 3, SLODE_RK4, false, true, 2>(k, a.grid, nthreads, lds, stream);
     snprintf(err, errlen, "unknown ode kernel variant %d", a.alg);
     return hipErrorInvalidValue;
+  }
+  // packed form: four trajectories per workgroup (metric shape, loop-free, batch a multiple of four)
+  if (a.pack == 4 && one && a.alg == 0 && !a.x_ext && !a.force_generic && s.B % 4 == 0 && 4 * lds <= 160 * 1024 &&
+      s.H == 25 && s.S == 5 && s.T == 200 && s.C == 3 && s.L == 8 && k.Q == 3 && s.method == SLODE_RK4) {
+    if (ra) return launch_one<5, 25, true, 200, 3, 8, 3, SLODE_RK4, true, true, 0, 4>(k, a.grid / 4, nthreads * 4, 4 * lds, stream);
+    return launch_one<5, 25, true, 200, 3, 8, 3, SLODE_RK4, false, true, 0, 4>(k, a.grid / 4, nthreads * 4, 4 * lds, stream);
   }
   // the scorer of BASELINE config[2] as written (proc, dopri5): shape-specialised, solver phases compiled out
   if (static_scorer) {

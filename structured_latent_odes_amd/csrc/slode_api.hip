@@ -108,6 +108,7 @@ int slode_create(slode_handle* out, int device_id) {
   c->ode_loop = getenv("SLODE_ODE_LOOP") != nullptr;
   c->ode_generic = getenv("SLODE_ODE_GENERIC") != nullptr;
   c->ode_alg = getenv("SLODE_ODE_ALG") ? atoi(getenv("SLODE_ODE_ALG")) : 0;
+  c->ode_pack = getenv("SLODE_ODE_PACK") ? atoi(getenv("SLODE_ODE_PACK")) : 0;
   c->ode_grid_cap = getenv("SLODE_ODE_GRID") ? atoi(getenv("SLODE_ODE_GRID")) : 0;
   *out = c;
   return SLODE_OK;
@@ -469,7 +470,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     a.g_loc = w.g_loc; a.g_scale = w.g_scale; a.slabs = w.ode_slabs; a.slab_stride = w.ode_stride; a.grid = w.ode_grid;
     a.backward = bwd ? 1 : 0; a.with_ll = 1;
     a.sigtab = folded ? w.sigtab : nullptr;   // written by the fold launch above
-    a.force_loop = h->ode_loop; a.force_generic = h->ode_generic; a.alg = h->ode_alg;
+    a.force_loop = h->ode_loop; a.force_generic = h->ode_generic; a.alg = h->ode_alg; a.pack = h->ode_pack;
     if (bwd && folded) { a.enc_hid = w.hid; a.g_pre = w.g_pre; a.glat = w.glat; a.g_loc = nullptr; a.g_scale = nullptr; }
     if (dp5) {
       // adaptive solve (per-trajectory controller, accepted steps recorded) -> ONE scorer pass (loss terms, dLoss/dx, every gradient

@@ -50,6 +50,7 @@ struct slode_ctx {
   int ode_loop;           // SLODE_ODE_LOOP: persistent-loop grid even when every trajectory could have its own workgroup
   int ode_generic;        // SLODE_ODE_GENERIC: skip the shape-specialised instantiations
   int ode_alg;            // SLODE_ODE_ALG = 1 / 2: measured A/B arms of the fused kernel (metric shape only; ode_kernel.hip)
+  int ode_pack;           // SLODE_ODE_PACK = 4: four trajectories per ODE workgroup (metric shape)
   int ode_grid_cap;       // SLODE_ODE_GRID = n: at most n workgroups in the persistent-loop grid (tests: several trajectories per workgroup at small B)
 };
 
@@ -282,6 +283,7 @@ struct OdeLaunch {
   const float* x_ext = nullptr;   // [B][T][S]
   float* gx_out = nullptr;        // [B][T][S]
   int force_loop = 0, force_generic = 0, alg = 0;   // handle flags (slode_ctx)
+  int pack = 0;          // 4: four trajectories per workgroup where the shape has such an instantiation (ode_kernel.hip, PK)
 };
 hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, size_t errlen);
 size_t slode_ode_lds_bytes(const slode_shape& s, int nthreads, bool one = false);

@@ -58,7 +58,7 @@ def _rel(a, b):
 
 def _run(c, mode, env, monkeypatch):
     from structured_latent_odes_amd import engine as E
-    for k in ("SLODE_ODE_LOOP", "SLODE_ODE_GRID", "SLODE_ODE_GENERIC", "SLODE_ODE_ALG"):
+    for k in ("SLODE_ODE_LOOP", "SLODE_ODE_GRID", "SLODE_ODE_GENERIC", "SLODE_ODE_ALG", "SLODE_ODE_PACK"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -124,6 +124,14 @@ def test_ab_arms_of_the_metric_shape(alg, monkeypatch):
     also contracts the weight gradients on v_mfma_f32_16x16x4_f32."""
     c = _case("c1_cvs_T200_L8_rk4", "exact")
     _run(c, "exact", {"SLODE_ODE_ALG": str(alg)}, monkeypatch)
+
+
+@pytest.mark.parametrize("mode", ["exact", "reference_adjoint"])
+def test_packed_arm_of_the_metric_shape(mode, monkeypatch):
+    """The measured-and-rejected decomposition of round 3: four trajectories per workgroup of 1024 threads, each on its own
+    waves, LDS region and slab row, sharing only the barriers (SLODE_ODE_PACK=4; B = 12 = three packed workgroups).  Same step."""
+    c = _case("c1_cvs_T200_L8_rk4", mode)
+    _run(c, mode, {"SLODE_ODE_PACK": "4"}, monkeypatch)
 
 
 def test_non_monotone_time_grid_is_rejected():
