@@ -337,22 +337,25 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
   }
   __syncthreads();
   STAMP(10);
-  // heads: 16 lanes per output (which, trajectory, latent dim), each summing every 16th hidden unit; xor butterfly inside the 16 lanes
-  for (int e0 = (tid >> 4); e0 < ((TB * L * 2 + 3) & ~3); e0 += NT >> 4) {   // (wave-uniform trip count: four outputs per wave and pass)
-    const int e = min(e0, TB * L * 2 - 1), l16 = tid & 15;
-    const int which = e / (TB * L), r = e - which * (TB * L);
-    const int tb = r / L, l = r - tb * L;
-    const float* W = s_hw + which * L * Hc + l * Hc;
-    float acc = 0.f;
-    for (int mm = l16; mm < Hc; mm += 16) acc = fmaf(W[mm], s_hid[tb * 64 + mm], acc);
-    acc += __shfl_xor(acc, 8, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 1, 64);
-    acc += s_hb[which * L + l];
-    if (l16 == 0 && e0 < TB * L * 2 && b0 + tb < k.B) {
-      if (which) k.scale[(long long)(b0 + tb) * L + l] = expf(acc);
-      else k.loc[(long long)(b0 + tb) * L + l] = acc;
+  // heads: LPO lanes per output (which, trajectory, latent dim), each summing every LPO-th hidden unit, then an xor butterfly inside the
+  // lane group; LPO = 16 / 4 / 1, the largest that covers all outputs in one pass (short latents: 64 outputs x 16 lanes; L = 50: one each)
+  {
+    const int n_out = TB * L * 2;
+    const int lsh = (n_out * 16 <= NT) ? 4 : ((n_out * 4 <= NT) ? 2 : 0), lpo = 1 << lsh;   // kernel-uniform
+    for (int e0 = (tid >> lsh); e0 < ((n_out + (64 >> lsh) - 1) & ~((64 >> lsh) - 1)); e0 += NT >> lsh) {   // (wave-uniform trip count)
+      const int e = min(e0, n_out - 1), lg = tid & (lpo - 1);
+      const int which = e / (TB * L), r = e - which * (TB * L);
+      const int tb = r / L, l = r - tb * L;
+      const float* W = s_hw + which * L * Hc + l * Hc;
+      float acc = 0.f;
+      for (int mm = lg; mm < Hc; mm += lpo) acc = fmaf(W[mm], s_hid[tb * 64 + mm], acc);
+      if (lsh >= 4) { acc += __shfl_xor(acc, 8, 64); acc += __shfl_xor(acc, 4, 64); }
+      if (lsh >= 2) { acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 1, 64); }
+      acc += s_hb[which * L + l];
+      if (lg == 0 && e0 < n_out && b0 + tb < k.B) {
+        if (which) k.scale[(long long)(b0 + tb) * L + l] = expf(acc);
+        else k.loc[(long long)(b0 + tb) * L + l] = acc;
+      }
     }
   }
   STAMP(11);

@@ -539,7 +539,7 @@ size_t enc_bwd_lds(const EncK& k) {
 hipError_t slode_launch_gemm_tail(const float* g_pre, const float* x, float* gslabs, int Hc, int CT, const float* glat, const float* hid,
                                   float* gslabs_loc, float* gslabs_ls, int L, int B, int splitk, const float* ode_slabs, int ode_stride,
                                   int ode_n, int ode_count, float* ode_part, const float** ode_part_out, int* ode_n_out,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, int zr_rows, int zr_lo, int zr_hi) {
   const int total_splits = splitk * 4;
   int per_wave = (B + total_splits - 1) / total_splits;
   per_wave = (per_wave + 1) & ~1;
@@ -552,7 +552,7 @@ hipError_t slode_launch_gemm_tail(const float* g_pre, const float* x, float* gsl
   *ode_part_out = ode_slabs; *ode_n_out = ode_n;
   if (ode_part && ode_n > 2 * SLODE_REDUCE_GROUPS) {
     const int per = (ode_n + SLODE_REDUCE_GROUPS - 1) / SLODE_REDUCE_GROUPS;
-    ps.rider = Stage1{ode_slabs, ode_stride, ode_n, ode_count, per, ode_part};
+    ps.rider = Stage1{ode_slabs, ode_stride, ode_n, ode_count, per, ode_part, zr_rows, zr_lo, zr_hi};
     ps.rider_bx = (ode_count + 63) / 64;
     rider_x = (ps.rider_bx * SLODE_REDUCE_GROUPS + splitk - 1) / splitk;
     *ode_part_out = ode_part; *ode_n_out = (ode_n + per - 1) / per;

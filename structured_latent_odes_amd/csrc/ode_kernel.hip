@@ -99,6 +99,7 @@ struct OdeK {
   // externally solved trajectories (dopri5 training, generic instantiation only; see OdeLaunch)
   const float* x_ext;
   float* gx_out;
+  int ext_skip;   // scorer: leave the solver-side range [init net | dynamics] of the slab row unwritten (OdeLaunch::ext_skip)
   int Hc;
   // gradient-segment elements no phase of this launch owns (zero gradient: written as zeros once per workgroup), relative to ode_begin
   int nz, zlo[8], zhi[8];
@@ -829,12 +830,16 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
         uj = acc;
       }
     }
-    if (k.n_aux > 0 && tid < k.n_aux * 32) {
+    // (the label heads run on the waves BEHIND wave 0 when the workgroup has them to spare -- the proc shapes: 3 waves, 4 heads -- so that
+    //  wave 0's serial stretch is the two dot products and the switching indices only; they read z (behind the barrier above) and leave
+    //  results that P7 picks up many barriers later)
+    const int aux_t0 = (NT >= 64 + k.n_aux * 32) ? 64 : 0;
+    if (k.n_aux > 0 && tid >= aux_t0 && tid < aux_t0 + k.n_aux * 32) {
       // q(label | z_g) on the replayed z at aux_mult x (mechanistic_proc.py:145-146,334-353): half-wave = head, lane j = hidden unit.  The sums
       // over hidden units are xor-butterflies inside the half-wave (offsets 16..1); every lane of a head then holds its few logits and
       // works out log p and dLoss/dlogit redundantly -- no serial per-head thread (round 2: one thread per head walked U x u_dim
       // dependent FMAs three times over, 5.8 us of the proc trajectory's 30), no exchange, no barrier.
-      const int hd = tid >> 5, j = tid & 31;
+      const int hd = (tid - aux_t0) >> 5, j = tid & 31;
       const slode_aux ax = k.aux[hd];
       const bool on = j < k.U;
       float hvv = 0.f, dv = 0.f;
@@ -1630,12 +1635,14 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
       } else {   // ext: no gradient reaches the dynamics or x0 through this kernel (the elements step (C) owns are zeros)
         if (tid < 32) { s_gu[tid] = 0.f; s_gp0[tid] = 0.f; }
         if (tid >= 64 && tid < 64 + S) s_go[tid - 64] = 0.f;
-        for (int e = tid; e < H * 2 * S; e += NT) {
-          const int j = e / (2 * S), r = e - j * (2 * S);
-          accum((r < S ? k.o_wg + r * H : k.o_wd + (r - S) * H) + j, 0.f);
+        if (!k.ext_skip) {   // (ext_skip: the reduction behind this launch does not read the solver-side range of these rows)
+          for (int e = tid; e < H * 2 * S; e += NT) {
+            const int j = e / (2 * S), r = e - j * (2 * S);
+            accum((r < S ? k.o_wg + r * H : k.o_wd + (r - S) * H) + j, 0.f);
+          }
+          if (tid < H) accum(k.o_wh + tid * (1 + L), 0.f);
+          if (tid >= 64 && tid < 64 + 2 * S) accum((tid - 64) < S ? k.o_bg + (tid - 64) : k.o_bd + (tid - 64 - S), 0.f);
         }
-        if (tid < H) accum(k.o_wh + tid * (1 + L), 0.f);
-        if (tid >= 64 && tid < 64 + 2 * S) accum((tid - 64) < S ? k.o_bg + (tid - 64) : k.o_bd + (tid - 64 - S), 0.f);
       }
       __syncthreads();
       STAMP(17);
@@ -1716,17 +1723,19 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
                                                (__attribute__((address_space(3))) void*)(s_encw + base), 4, 0, 0);
           }
         }
-        for (int e = t1; e < H * L; e += n1) {
-          const int j = e / L, l = e - j * L;
-          accum(k.o_wh + j * (1 + L) + 1 + l, s_gu[j] * s_z[l]);
-          accum(k.o_w1 + e, s_gp0[j] * s_z[l]);
+        if (!(ext && k.ext_skip)) {   // (the scorer of an external solution would write zeros here: init net and dynamics are the reverse sweep's)
+          for (int e = t1; e < H * L; e += n1) {
+            const int j = e / L, l = e - j * L;
+            accum(k.o_wh + j * (1 + L) + 1 + l, s_gu[j] * s_z[l]);
+            accum(k.o_w1 + e, s_gp0[j] * s_z[l]);
+          }
+          for (int e = t1; e < S * H; e += n1) {
+            const int s = e / H, j = e - s * H;
+            accum(k.o_w2 + e, s_go[s] * s_hid0[j]);
+          }
+          if (t1 < H) { accum(k.o_bh + t1, s_gu[t1]); accum(k.o_b1 + t1, s_gp0[t1]); }
+          if (t1 < S) accum(k.o_b2 + t1, s_go[t1]);
         }
-        for (int e = t1; e < S * H; e += n1) {
-          const int s = e / H, j = e - s * H;
-          accum(k.o_w2 + e, s_go[s] * s_hid0[j]);
-        }
-        if (t1 < H) { accum(k.o_bh + t1, s_gu[t1]); accum(k.o_b1 + t1, s_gp0[t1]); }
-        if (t1 < S) accum(k.o_b2 + t1, s_go[t1]);
         if (k.with_ll && t1 < n_headw) {   // decoder head weights: the hsplit partials of P4, fixed order
           const int qc = t1 / S, s = t1 - qc * S, q = qc / C, c = qc - q * C;
           float v = 0.f;
@@ -1919,7 +1928,7 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   k.x_out = a.x_out; k.z_out = a.z_out; k.g_loc = a.g_loc; k.g_scale = a.g_scale; k.slabs = a.slabs;
   k.slab_stride = a.slab_stride; k.backward = a.backward; k.with_ll = a.with_ll;
   k.enc_hid = a.enc_hid; k.g_pre = a.g_pre; k.glat = a.glat; k.Hc = s.Hc;
-  k.x_ext = a.x_ext; k.gx_out = a.gx_out;
+  k.x_ext = a.x_ext; k.gx_out = a.gx_out; k.ext_skip = (a.x_ext && a.ext_skip) ? 1 : 0;
   k.enc_zloc_w = p + lay.zloc_w; k.enc_zls_w = p + lay.zls_w;
 
   const int nthreads = slode_ode_threads(s);

@@ -451,6 +451,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
 
   int n_slabs = w.ode_grid;
   int part_lo = lay->ode_begin, part_hi = lay->n_params;   // flat range the slab rows carry (after the loss slot)
+  int zr_rows = 0, zr_lo = 0, zr_hi = 0;                   // rows [0, zr_rows) carry nothing in slab columns [zr_lo, zr_hi) (dopri5 scorer)
   if (aux_mode) {
     // one workgroup per trajectory up to 2,048 of them, then a loop; on the folded path the kernel also runs the encoder-head backward and
     // its slab rows carry only the label-head range (the fused tail below reduces exactly that)
@@ -472,6 +473,12 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     a.sigtab = folded ? w.sigtab : nullptr;   // written by the fold launch above
     a.force_loop = h->ode_loop; a.force_generic = h->ode_generic; a.alg = h->ode_alg; a.pack = h->ode_pack;
     if (bwd && folded) { a.enc_hid = w.hid; a.g_pre = w.g_pre; a.glat = w.glat; a.g_loc = nullptr; a.g_scale = nullptr; }
+    if (dp5 && bwd && folded && w.ode_grid + w.dp_rows > 2 * SLODE_REDUCE_GROUPS) {
+      // the scorer's rows carry nothing in the solver-side range [init net | dynamics] (the reverse sweep's rows do): the scorer does not
+      // write those zeros and stage 1 of the fused tail (the only reader of the rows) does not read them
+      a.ext_skip = 1;
+      zr_rows = w.ode_grid; zr_lo = 1 + (lay->init_w1 - lay->ode_begin); zr_hi = 1 + (lay->dyn_bd + s->S - lay->ode_begin);
+    }
     if (dp5) {
       // adaptive solve (per-trajectory controller, accepted steps recorded) -> ONE scorer pass (loss terms, dLoss/dx, every gradient
       // that does not flow through the solver, its own share of the latent gradient into g_loc / g_scale) -> reverse mode over the
@@ -509,7 +516,8 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     const float* ode_part = nullptr;
     int ode_pn = 0;
     HIP_TRY(h, slode_launch_gemm_tail(w.g_pre, obs, w.gslabs, s->Hc, (int)CT, w.glat, w.hid, w.gslabs2, w.gslabs3, s->L, s->B, w.gsplit,
-                                      w.ode_slabs, w.ode_stride, n_slabs, (part_hi - part_lo) + 1, w.ode_part, &ode_part, &ode_pn, st));
+                                      w.ode_slabs, w.ode_stride, n_slabs, (part_hi - part_lo) + 1, w.ode_part, &ode_part, &ode_pn, st,
+                                      zr_rows, zr_lo, zr_hi));
     TailK tl{};
     tl.gslabs = w.gslabs; tl.gslabs_loc = w.gslabs2; tl.gslabs_ls = w.gslabs3; tl.conv_slabs = w.conv_slabs;
     tl.ode_part = ode_part; tl.ode_stride = w.ode_stride; tl.ode_n = ode_pn; tl.loss_out = loss_out;

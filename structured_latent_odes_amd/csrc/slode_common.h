@@ -209,7 +209,9 @@ __device__ __forceinline__ void tail_element(const TailK& k, int i) {
 
 // Stage 1 of the slab reduction: [n][stride] -> [G][stride] partial sums.  One 256-thread block = 64 elements x 4 sub-groups; every
 // thread keeps 4 independent loads in flight; summation order is fixed (slab index) => bitwise reproducible.  s_p: 256 floats.
-struct Stage1 { const float* slabs; int stride, n, count, per; float* out; };
+// zr_*: rows [0, zr_rows) carry nothing in columns [zr_lo, zr_hi) (dopri5 training: the scorer's rows and the solver-side range, which only
+// the reverse sweep's rows fill) -- those reads are skipped (4096 x 12.8 KB of zeros at BASELINE config[2])
+struct Stage1 { const float* slabs; int stride, n, count, per; float* out; int zr_rows, zr_lo, zr_hi; };
 __device__ __forceinline__ void slab_stage1_block(const Stage1& f, int bx, int g, float* s_p) {
   const int lane64 = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int e = bx * 64 + lane64;
@@ -218,6 +220,7 @@ __device__ __forceinline__ void slab_stage1_block(const Stage1& f, int bx, int g
   if (e < f.count) {
     const float* p = f.slabs + e;
     int w = w0 + q;
+    if (e >= f.zr_lo && e < f.zr_hi && w < f.zr_rows) w += ((f.zr_rows - w + 3) >> 2) << 2;   // this sub-group's first row that carries the column
     for (; w + 12 < w1; w += 16) {
       a0 += p[(long long)w * f.stride];
       a1 += p[(long long)(w + 4) * f.stride];
@@ -282,6 +285,8 @@ struct OdeLaunch {
   // share of the latent gradient to g_loc / g_scale afterwards)
   const float* x_ext = nullptr;   // [B][T][S]
   float* gx_out = nullptr;        // [B][T][S]
+  int ext_skip = 0;               // 1: the scorer does not write the zeros of the slab row's solver-side range [init net | dynamics] --
+                                  // only when the consumer of the rows (stage 1 of the fused tail, Stage1::zr_*) does not read them
   int force_loop = 0, force_generic = 0, alg = 0;   // handle flags (slode_ctx)
   int pack = 0;          // 4: four trajectories per workgroup where the shape has such an instantiation (ode_kernel.hip, PK)
 };
@@ -352,7 +357,7 @@ hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream);
 hipError_t slode_launch_gemm_tail(const float* g_pre, const float* x, float* gslabs, int Hc, int CT, const float* glat, const float* hid,
                                   float* gslabs_loc, float* gslabs_ls, int L, int B, int splitk, const float* ode_slabs, int ode_stride,
                                   int ode_n, int ode_count, float* ode_part, const float** ode_part_out, int* ode_n_out,
-                                  hipStream_t stream);
+                                  hipStream_t stream, int zr_rows = 0, int zr_lo = 0, int zr_hi = 0);
 int slode_fold_small_count(const slode_shape& s);
 
 struct AuxLaunch {
