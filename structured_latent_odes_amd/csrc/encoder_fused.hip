@@ -222,7 +222,9 @@ __device__ __forceinline__ void enc_group_finish(float (&acc)[NSET][RB * TBE], i
 // ONE: every wave owns at most one group of RB rows and a row is one tile of 128 * IU columns (C*T <= 640, Hc <= 64: every reference
 // shape with T <= 213) -- no loop, and the wave's tile of W_eff is requested BEFORE the observation rows are staged: it does not depend
 // on them and both are cold misses (W_eff was written by the fold launch a moment ago, from other CUs): one round trip instead of two.
-template <int TB, bool ONE>
+// BIGL (latent dim >= 32: the proc family's 50): the 2 * L * Hc head weights are staged in one batch of eight loads per thread and TRANSPOSED
+// ([which][mm][l]: the head threads of consecutive latent dims read consecutive words), one lane per head output.
+template <int TB, bool ONE, bool BIGL>
 __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__ pl_x, const float* __restrict__ pl_zloc_w, const float* __restrict__ pl_zls_w,
                                                        const float* __restrict__ pl_beff, const float* __restrict__ pl_weff, const FoldK k) {
   static_assert(TB % TBE == 0, "sets of four trajectories (wave_sum16 reduces RB x 4 partial sums)");
@@ -251,13 +253,15 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
     // raw rows (the block's TB * CT floats are contiguous in memory: dense rows), head weights, b_eff, head biases: every global load of
     // the prologue is requested before the first LDS store (separate load-store loops are separate round trips)
     const long long base = (long long)b0 * CT, lim = (long long)k.B * CT - 1;
-    float v[4], hw[2];
+    constexpr int NHW = BIGL ? 8 : 2;   // 2 * L * Hc <= 8 * 1024 head weights: one batch (short latents: two loads, then a loop)
+    static_assert(2 * SLODE_MAX_L * SLODE_MAX_HC <= 8 * FNT, "the head weights are staged in one batch of loads");
+    float v[4], hw[NHW];
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = pl_x[min(base + tid + q * NT, lim)];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NHW; ++q) {
       const int e = min(tid + q * NT, 2 * L * Hc - 1);
-      hw[q] = (e < L * Hc) ? pl_zloc_w[e] : pl_zls_w[e - L * Hc];
+      hw[q] = (q * NT < 2 * L * Hc) ? ((e < L * Hc) ? pl_zloc_w[e] : pl_zls_w[e - L * Hc]) : 0.f;   // (kernel-uniform guard)
     }
     const float bev = pl_beff[min(tid, Hc - 1)];
     const int hbi = min(max(tid - 64, 0), 2 * L - 1);
@@ -266,8 +270,19 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
     for (int q = 0; q < 4; ++q)
       if (tid + q * NT < TB * CT) s_x[tid + q * NT] = v[q];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-      if (tid + q * NT < 2 * L * Hc) s_hw[tid + q * NT] = hw[q];
+    for (int q = 0; q < NHW; ++q) {
+      const int e = tid + q * NT;
+      if (e < 2 * L * Hc) {
+        if (BIGL) {
+          const int which = e / (L * Hc), r = e - which * (L * Hc), l = r / Hc, mm = r - l * Hc;
+          s_hw[which * L * Hc + mm * L + l] = hw[q];
+        } else {
+          s_hw[e] = hw[q];
+        }
+      }
+    }
+    if (!BIGL)
+      for (int e = tid + NHW * NT; e < 2 * L * Hc; e += NT) s_hw[e] = (e < L * Hc) ? pl_zloc_w[e] : pl_zls_w[e - L * Hc];
     if (tid < Hc) s_be[tid] = bev;
     if (tid >= 64 && tid < 64 + 2 * L) s_hb[tid - 64] = hbv;
     for (int e0 = tid + 4 * NT; e0 < TB * CT; e0 += 4 * NT) {
@@ -277,21 +292,23 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
       for (int q = 0; q < 4; ++q)
         if (e0 + q * NT < TB * CT) s_x[e0 + q * NT] = v[q];
     }
-    for (int e = tid + 2 * NT; e < 2 * L * Hc; e += NT) s_hw[e] = (e < L * Hc) ? pl_zloc_w[e] : pl_zls_w[e - L * Hc];
   }
   __syncthreads();
   STAMP(9);
   if (ONE) {
     if (wave < ngroups) {
-      float acc[NSET][RB * TBE];   // [set][r][tb] flattened: wave_sum16 reduces each set in place
+      // the wave's tile of W_eff stays in registers while the block's sets of four trajectories pass by, one set at a time (16 partial
+      // sums live, whatever TB is: large batches take 16 trajectories per block and stream W_eff a quarter as often)
+#pragma unroll 1
+      for (int st = 0; st < NSET; ++st) {
+        float acc[1][RB * TBE];   // [r][tb] flattened: wave_sum16 reduces it in place
 #pragma unroll
-      for (int st = 0; st < NSET; ++st)
-#pragma unroll
-        for (int i = 0; i < RB * TBE; ++i) acc[st][i] = 0.f;
-      enc_tile_fma<NSET>(w1, s_x, CT, 2 * lane, acc);
-      __builtin_amdgcn_sched_barrier(0);   // keep the reduction's temporaries out of the load/FMA phase (spills otherwise)
-      STAMP(12);
-      enc_group_finish<NSET>(acc, lane, wave * RB, b0, k, s_be, s_hid);
+        for (int i = 0; i < RB * TBE; ++i) acc[0][i] = 0.f;
+        enc_tile_fma<1>(w1, s_x + st * TBE * CT, CT, 2 * lane, acc);
+        __builtin_amdgcn_sched_barrier(0);   // keep the reduction's temporaries out of the load/FMA phase (spills otherwise)
+        if (st == 0) STAMP(12);
+        enc_group_finish<1>(acc, lane, wave * RB, b0 + st * TBE, k, s_be, s_hid + st * TBE * 64);
+      }
       STAMP(13);
     }
   } else {
@@ -337,8 +354,9 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
   }
   __syncthreads();
   STAMP(10);
-  // heads: LPO lanes per output (which, trajectory, latent dim), each summing every LPO-th hidden unit, then an xor butterfly inside the
-  // lane group; LPO = 16 / 4 / 1, the largest that covers all outputs in one pass (short latents: 64 outputs x 16 lanes; L = 50: one each)
+  // heads: LPO lanes per output (which, trajectory, latent dim; latent dim fastest), each summing every LPO-th hidden unit, then an xor
+  // butterfly inside the lane group; LPO = 16 / 4 / 1, the largest that covers all outputs in one pass (short latents: 64 outputs x 16
+  // lanes; L = 50: one lane each)
   {
     const int n_out = TB * L * 2;
     const int lsh = (n_out * 16 <= NT) ? 4 : ((n_out * 4 <= NT) ? 2 : 0), lpo = 1 << lsh;   // kernel-uniform
@@ -346,9 +364,23 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
       const int e = min(e0, n_out - 1), lg = tid & (lpo - 1);
       const int which = e / (TB * L), r = e - which * (TB * L);
       const int tb = r / L, l = r - tb * L;
-      const float* W = s_hw + which * L * Hc + l * Hc;
-      float acc = 0.f;
-      for (int mm = lg; mm < Hc; mm += lpo) acc = fmaf(W[mm], s_hid[tb * 64 + mm], acc);
+      const float* hd = s_hid + tb * 64;
+      float acc;
+      if (BIGL) {
+        const float* W = s_hw + which * L * Hc + l;
+        float a0 = 0.f, a1 = 0.f;
+        int mm = lg;
+        for (; mm + lpo < Hc; mm += 2 * lpo) {
+          a0 = fmaf(W[mm * L], hd[mm], a0);
+          a1 = fmaf(W[(mm + lpo) * L], hd[mm + lpo], a1);
+        }
+        if (mm < Hc) a0 = fmaf(W[mm * L], hd[mm], a0);
+        acc = a0 + a1;
+      } else {
+        const float* W = s_hw + which * L * Hc + l * Hc;
+        acc = 0.f;
+        for (int mm = lg; mm < Hc; mm += lpo) acc = fmaf(W[mm], hd[mm], acc);
+      }
       if (lsh >= 4) { acc += __shfl_xor(acc, 8, 64); acc += __shfl_xor(acc, 4, 64); }
       if (lsh >= 2) { acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 1, 64); }
       acc += s_hb[which * L + l];
@@ -622,16 +654,19 @@ hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream) {
     if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)weff_kernel<SLODE_MAX_K + SLODE_MAX_P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
     SLODE_LAUNCH("weff", (weff_kernel<SLODE_MAX_K + SLODE_MAX_P>), dim3(nb_w + nb_r), dim3(WNT), wlds, stream, k.conv_w, k.lin_w, k, stage_rows);
   }
-  const int TB = k.B >= 2048 ? 2 * TBE : TBE;   // (a batch that fills the chip several times over: fewer, fatter blocks)
-  const size_t lds = sizeof(float) * ((size_t)TB * k.CT + TB * 64 + 2 * (size_t)k.L * k.Hc + 64 + 2 * (size_t)k.L);
   const bool one = (k.CT & 1) == 0 && k.CT <= 128 * IU && (k.Hc + RB - 1) / RB <= FNT / 64;
-#define SLODE_ENC_FWD2(TT, OO)                                                                                                          \
+  // (a batch that fills the chip several times over: fewer, fatter blocks -- one block per CU at B = 4096)
+  const int TB = (one && k.B >= 4096) ? 4 * TBE : (k.B >= 2048 ? 2 * TBE : TBE);
+  const size_t lds = sizeof(float) * ((size_t)TB * k.CT + TB * 64 + 2 * (size_t)k.L * k.Hc + 64 + 2 * (size_t)k.L);
+#define SLODE_ENC_FWD2(TT, OO, LL)                                                                                                      \
   do {                                                                                                                                \
-    (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel<TT, OO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-    SLODE_LAUNCH("enc_fwd2", (enc_fwd2_kernel<TT, OO>), dim3((k.B + TB - 1) / TB), dim3(FNT), lds, stream, k.x, k.zloc_w, k.zls_w, k.beff, k.weff, k); \
+    (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel<TT, OO, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+    SLODE_LAUNCH("enc_fwd2", (enc_fwd2_kernel<TT, OO, LL>), dim3((k.B + TB - 1) / TB), dim3(FNT), lds, stream, k.x, k.zloc_w, k.zls_w, k.beff, k.weff, k); \
   } while (0)
-  if (TB == TBE) { if (one) SLODE_ENC_FWD2(TBE, true); else SLODE_ENC_FWD2(TBE, false); }
-  else { if (one) SLODE_ENC_FWD2(2 * TBE, true); else SLODE_ENC_FWD2(2 * TBE, false); }
+#define SLODE_ENC_FWD2_L(TT, OO) do { if (k.L >= 32) SLODE_ENC_FWD2(TT, OO, true); else SLODE_ENC_FWD2(TT, OO, false); } while (0)
+  if (TB == 4 * TBE) SLODE_ENC_FWD2_L(4 * TBE, true);
+  else if (TB == TBE) { if (one) SLODE_ENC_FWD2_L(TBE, true); else SLODE_ENC_FWD2_L(TBE, false); }
+  else { if (one) SLODE_ENC_FWD2_L(2 * TBE, true); else SLODE_ENC_FWD2_L(2 * TBE, false); }
   return hipGetLastError();
 }
 
