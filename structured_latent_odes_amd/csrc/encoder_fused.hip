@@ -654,6 +654,7 @@ hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream) {
     if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)weff_kernel<SLODE_MAX_K + SLODE_MAX_P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
     SLODE_LAUNCH("weff", (weff_kernel<SLODE_MAX_K + SLODE_MAX_P>), dim3(nb_w + nb_r), dim3(WNT), wlds, stream, k.conv_w, k.lin_w, k, stage_rows);
   }
+  if (a.skip_enc) return hipGetLastError();
   const bool one = (k.CT & 1) == 0 && k.CT <= 128 * IU && (k.Hc + RB - 1) / RB <= FNT / 64;
   // (a batch that fills the chip several times over: fewer, fatter blocks -- one block per CU at B = 4096)
   const int TB = (one && k.B >= 4096) ? 4 * TBE : (k.B >= 2048 ? 2 * TBE : TBE);

@@ -95,6 +95,8 @@ struct OdeK {
   int slab_stride, backward, with_ll;
   // fused encoder-head backward (folded encoder path): g_pre[b][m] = (1 - hid^2) * (zloc_w^T g_loc + zls_w^T (g_scale * scale))
   const float *enc_hid, *enc_zloc_w, *enc_zls_w;
+  const float *enc_weff, *enc_beff, *enc_zloc_b, *enc_zls_b;   // ENCF: folded encoder weights of this step (fold launch), head biases
+  float* enc_hid_out;                                          // ENCF: saved tanh [B][Hc]
   float *g_pre, *glat;   // g_pre [B][64]; glat [B][128], row = [g_loc (L) | pad to 64 | g_scale * scale (L) | pad]
   // externally solved trajectories (dopri5 training, generic instantiation only; see OdeLaunch)
   const float* x_ext;
@@ -491,6 +493,10 @@ __host__ __device__ constexpr int ode_max_threads(int S, int T_, int C_, int Q_,
   return (S > 5 || (T_ > 0 && T_ <= 128)) ? 768 : 1024;
 }
 
+__host__ __device__ constexpr int ode_block_bound(int S, int T_, int C_, int Q_, bool one, bool bwd, int pk) {
+  return pk > 1 ? pk * ode_threads_for(T_ ? T_ : 1, Q_ ? Q_ : 1, C_ ? C_ : 1, S) : ode_max_threads(S, T_, C_, Q_, one, bwd);
+}
+
 // Kernel algorithm variants (ALG).  The dynamics net never sees the state and its hidden layer is relu(w_t t + u_j(z)): every unit is
 // switched on over a prefix or a suffix of the (monotone) stage-time table, so
 //   ALG 0 (product): forward = piecewise-linear table of the 2S head pre-activations over <= H+1 time segments (one fma per head and
@@ -513,8 +519,13 @@ __host__ __device__ constexpr int ode_max_threads(int S, int T_, int C_, int Q_,
 // NT threads (whole waves), its own LDS region and its own slab row, exactly as if it were a workgroup of its own ("virtual workgroup"
 // vblk = blockIdx * PK + trajectory); only the barriers are shared.  The serial wave of trajectory i is the workgroup's wave
 // i * NW + i: the four serial waves sit on four different SIMDs.
-template <int S, int H, bool BWD, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1, bool RA = false, bool ONE = false, int ALG = 0, int PK = 1>
-__global__ void __launch_bounds__(PK > 1 ? PK * ode_threads_for(T_ ? T_ : 1, Q_ ? Q_ : 1, C_ ? C_ : 1, S) : ode_max_threads(S, T_, C_, Q_, ONE, BWD))
+// ENCF (shape-specialised loop-free forms with a short latent; folded encoder path): the workgroup runs the ENCODER FORWARD of its own
+// trajectory in the set-up -- pre = b_eff + W_eff x (each wave 13 rows of W_eff, its lanes the columns: two batches of register-resident
+// rows, one wave_sum16), tanh, the two head layers -- while the set-up's LDS-DMA is in flight; loc / scale go straight to the LDS slots
+// P0a reads, the saved tanh to LDS (P7's head backward) and to global memory (the head-layer GEMMs).  The enc_fwd2 launch disappears.
+template <int S, int H, bool BWD, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1, bool RA = false, bool ONE = false, int ALG = 0, int PK = 1,
+          bool ENCF = false>
+__global__ void __launch_bounds__(ode_block_bound(S, T_, C_, Q_, ONE, BWD, PK))
 ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ pl_pseg, const float* __restrict__ pl_loc,
                 const float* __restrict__ pl_scale, const float* __restrict__ pl_eps, const float* __restrict__ pl_u,
                 const float* __restrict__ pl_sigtab, const OdeK k) {
@@ -523,6 +534,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   // set-up go out at once instead of behind an s_load of the kernel-argument segment -- one of the two serialised cold misses every
   // kernel of the step starts with.
   static_assert(PK == 1 || (ONE && T_ > 0), "packed trajectories: shape-specialised loop-free forms only");
+  static_assert(!ENCF || (ONE && T_ > 0 && PK == 1 && ALG == 0), "fused encoder forward: shape-specialised loop-free product form only");
   extern __shared__ __attribute__((aligned(16))) float smem_wg[];
   constexpr int NWT = PK > 1 ? ode_threads_for(T_ ? T_ : 1, Q_ ? Q_ : 1, C_ ? C_ : 1, S) / 64 : 1;   // waves per trajectory (PK > 1)
   const int wave_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -595,6 +607,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   int* s_meta = reinterpret_cast<int*>(smem + m.meta);
   float* s_pf = smem + m.pf;      // [3][pad4(L)]: loc | scale | eps of the trajectory about to start (or z_in | - | -)
   float* s_encw = s_st;   // P7: encoder head weights [2][L][Hc] staged over the (then idle) stage buffer
+  float* s_ehid = smem + m.total;   // ENCF: this trajectory's tanh(pre) [64] (the launch adds the 256 bytes)
 
   const cptr wg = (cptr)k.wg, bg = (cptr)k.bg, wd = (cptr)k.wd, bd = (cptr)k.bd;
   // wave 0 carries every serial stretch of a trajectory (latent sample, switching indices, table, both scans): it issues ahead of the
@@ -632,6 +645,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
                                          (__attribute__((address_space(3))) void*)(s_A + n1 + n2 + base), 4, 0, 0);
   };
   float sigr[SLODE_MAX_C] = {1.f, 1.f, 1.f, 1.f};   // ONE: softplus(constant_std[c, t = tid]) stays in registers until P3
+  float e_hw[4] = {0.f, 0.f, 0.f, 0.f}, e_hb = 0.f;   // ENCF: this lane's head weights and bias, from the set-up's loads to the head layers
   {
     const int n_ts = n_stage_t, n_par = k.npar, n_sig = (!ONE && k.with_ll) ? C * T : 0;
     {
@@ -666,12 +680,64 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     const int b_first = vblk;
     if (b_first < k.B) {
       const int lc = min(tid, L - 1);
-      v_l0 = pl_loc[(long long)b_first * L + lc];     // (pure solve: z_in)
+      if (!ENCF) v_l0 = pl_loc[(long long)b_first * L + lc];     // (pure solve: z_in)
       if (pl_scale != nullptr) {
-        v_l1 = pl_scale[(long long)b_first * L + lc];
+        if (!ENCF) v_l1 = pl_scale[(long long)b_first * L + lc];
         v_l2 = pl_eps[(long long)b_first * L + lc];
       }
       if (pl_u != nullptr) v_u = pl_u[(long long)b_first * k.nu + min(tid, k.nu - 1)];
+    }
+    // ENCF: the encoder forward of this trajectory (see the template comment).  Everything it reads from global memory is requested
+    // here, beside the set-up loads; its results are finished behind the set-up barrier.
+    constexpr int ERW = 13;                       // rows of W_eff per wave (4 waves: Hc <= 52, checked by the launcher)
+    constexpr int ECT = (C_ ? C_ : 1) * (T_ ? T_ : 1), ENU = (ECT + 127) / 128;
+    float e_acc[16], e_be = 0.f;
+    if (ENCF) {
+      static_assert(!ENCF || ode_threads_for(T_ ? T_ : 1, Q_ ? Q_ : 1, C_ ? C_ : 1, S) == 256, "fused encoder forward: four waves");
+      static_assert(!ENCF || ((ECT & 1) == 0 && 2 * (L_ ? L_ : 1) * 16 <= 256), "fused encoder forward: even C*T, 16 lanes per head output");
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, Hc = k.Hc;
+      const float* xrow = k.obs + (long long)min(b_first, k.B - 1) * ECT;   // dense row, memory order = the column order of W_eff
+      f32x2 xv[ENU];
+#pragma unroll
+      for (int u = 0; u < ENU; ++u) xv[u] = *reinterpret_cast<const f32x2*>(xrow + min(2 * lane + 128 * u, ECT - 2));
+      {   // head weights (16 lanes per output: lane l16 takes hidden units l16 + 16 q), b_eff of the row this lane will finish, head bias
+        const int o = tid >> 4, l16 = tid & 15, which = o / L, l = o - which * L;
+        const float* W = (which ? k.enc_zls_w : k.enc_zloc_w) + l * Hc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e_hw[q] = W[min(l16 + 16 * q, Hc - 1)];
+        e_hb = which ? k.enc_zls_b[l] : k.enc_zloc_b[l];
+        e_be = k.enc_beff[min(wv * ERW + ((lane >> 2) & 15), Hc - 1)];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) e_acc[r] = 0.f;
+      const float* wbase = k.enc_weff + (long long)(wv * ERW) * ECT;
+      constexpr int EB0 = 5;   // rows per batch: 5 x ENU float2 = 50 registers in flight, one batch at a time (the kernel's budget is 128)
+#pragma unroll
+      for (int r0 = 0; r0 < ERW; r0 += EB0) {
+        f32x2 w[EB0][ENU];
+#pragma unroll
+        for (int r = 0; r < EB0; ++r)
+#pragma unroll
+          for (int u = 0; u < ENU; ++u) {
+            const int row = min(wv * ERW + r0 + r, Hc - 1) - wv * ERW;   // (rows past Hc: a valid address, never used)
+            w[r][u] = (r0 + r < ERW) ? *reinterpret_cast<const f32x2*>(wbase + (long long)row * ECT + min(2 * lane + 128 * u, ECT - 2)) : f32x2{0.f, 0.f};
+          }
+#pragma unroll
+        for (int r = 0; r < EB0; ++r)
+#pragma unroll
+          for (int u = 0; u < ENU; ++u) {
+            if (r0 + r < ERW) {
+              const bool in = 2 * lane + 128 * u < ECT;
+              const float wx = in ? w[r][u].x : 0.f, wy = in ? w[r][u].y : 0.f;
+              e_acc[r0 + r] = fmaf(wy, xv[u].y, fmaf(wx, xv[u].x, e_acc[r0 + r]));
+            }
+          }
+        // the next batch's loads must not be issued over this batch's registers: its sums are finished ahead of a compiler barrier
+        // for memory operations (a scheduling barrier alone is not enough: the loads are clustered before the scheduler runs)
+#pragma unroll
+        for (int r = 0; r < EB0; ++r)
+          if (r0 + r < ERW) asm volatile("" : "+v"(e_acc[r0 + r]) : : "memory");
+      }
     }
     if (ONE && k.with_ll) {   // (with the per-step table: the scale itself instead of its parameter)
       const float* src = pl_sigtab;   // the table, or constant_std itself when there is none
@@ -697,7 +763,19 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     if (!ONE) {   // persistent-loop form: softplus(constant_std) once per workgroup, kept in LDS
       for (int i = tid; i < n_sig; i += NT) s_sig[i] = k.sigtab ? k.sigtab[i] : softplusf(k.cstd[i]);
     }
-    if (tid < L) { s_pf[tid] = v_l0; s_pf[pad4(L) + tid] = v_l1; s_pf[2 * pad4(L) + tid] = v_l2; }
+    if (tid < L) {
+      if (!ENCF) { s_pf[tid] = v_l0; s_pf[pad4(L) + tid] = v_l1; }
+      s_pf[2 * pad4(L) + tid] = v_l2;
+    }
+    if (ENCF) {   // rows of this wave: one halving butterfly leaves the sum of row (lane >> 2) & 15 in every lane; tanh; saved
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, idx = (lane >> 2) & 15, mrow = wv * ERW + idx;
+      const float v = wave_sum16(e_acc, lane);
+      const float hv = tanhf(v + e_be);
+      if ((lane & 3) == 0 && idx < ERW && mrow < k.Hc) {
+        s_ehid[mrow] = hv;
+        if (b_first < k.B) k.enc_hid_out[(long long)b_first * k.Hc + mrow] = hv;
+      }
+    }
     if (tid < k.nu) s_uu[tid] = v_u;
     if (COLDG && tid < 32) s_wt[tid] = v_wt;
     if (ONE && k.with_ll) {
@@ -717,6 +795,19 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   __syncthreads();
   STAMP(14);
   if (!COLDG && tid < 32) s_wt[tid] = (tid < H) ? s_par[k.o_wh + tid * (1 + L)] : 0.f;  // time column of dynamics_hidden (col 0)
+  if (ENCF) {   // head layers (models/encoder_conv.py:49-51): 16 lanes per output, xor butterfly inside the lane group
+    const int o = tid >> 4, l16 = tid & 15, which = o / L, l = o - which * L;
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = fmaf((l16 + 16 * q < k.Hc) ? e_hw[q] : 0.f, s_ehid[min(l16 + 16 * q, k.Hc - 1)], acc);
+    acc += __shfl_xor(acc, 8, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 1, 64);
+    acc += e_hb;
+    if (l16 == 0 && o < 2 * L) s_pf[which * pad4(L) + l] = which ? expf(acc) : acc;
+    __syncthreads();
+  }
 
   float loss_acc = 0.f;   // the only value a thread carries from one trajectory to the next
   static_assert(H < 32, "the hidden units and the constant-1 bias unit share one 32-lane group");
@@ -1779,7 +1870,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
       // encoder heads + tanh, backward (models/encoder_conv.py:48-51): thread <-> hidden unit.  s_gzl / s_gpl[L..] are next
       // written in P0a and s_encw (= the stage buffer) in P1, both behind the barrier at the top of the loop
       const int mm = tid - 64, Hc = k.Hc;
-      const float hv = k.enc_hid[(long long)b * Hc + mm];
+      const float hv = ENCF ? s_ehid[mm] : k.enc_hid[(long long)b * Hc + mm];
       float g0 = 0.f, g1 = 0.f;
       if (k.stage_encw) {
 #pragma unroll 5
@@ -1832,9 +1923,9 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   STAMP(11);
 }
 
-template <int S, int H, bool BWD, int T_, int C_, int L_, int Q_, int M_, bool RA, bool ONE, int ALG, int PK = 1>
+template <int S, int H, bool BWD, int T_, int C_, int L_, int Q_, int M_, bool RA, bool ONE, int ALG, int PK = 1, bool ENCF = false>
 hipError_t launch_one(const OdeK& k, int grid, int nthreads, size_t lds, hipStream_t stream) {
-  auto fn = ode_elbo_kernel<S, H, BWD, T_, C_, L_, Q_, M_, RA, ONE, ALG, PK>;
+  auto fn = ode_elbo_kernel<S, H, BWD, T_, C_, L_, Q_, M_, RA, ONE, ALG, PK, ENCF>;
   (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   SLODE_LAUNCH("ode_elbo", fn, dim3(grid), dim3(nthreads), lds, stream, k.stage_t, k.pseg, k.loc ? k.loc : k.z_in, k.loc ? k.scale : nullptr,
                k.eps, k.u, k.sigtab ? k.sigtab : k.cstd, k);
@@ -1854,6 +1945,12 @@ hipError_t launch_sh(const OdeK& k, int grid, int nthreads, size_t lds, bool bwd
 }
 
 }  // namespace
+
+// shapes whose loop-free backward kernel has an instantiation that runs the encoder forward itself (ENCF): the metric shape
+bool slode_ode_can_fuse_encoder(const slode_shape& s, bool bwd, int grid) {
+  const int Q = s.likelihood == SLODE_GAUSS ? 1 : 3;
+  return bwd && grid == s.B && s.H == 25 && s.S == 5 && s.T == 200 && s.C == 3 && s.L == 8 && Q == 3 && s.method == SLODE_RK4 && s.Hc <= 52;
+}
 
 int slode_ode_threads(const slode_shape& s) {
   return ode_threads_for(s.T, s.likelihood == SLODE_GAUSS ? 1 : 3, s.C, s.S);
@@ -1929,7 +2026,8 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   k.slab_stride = a.slab_stride; k.backward = a.backward; k.with_ll = a.with_ll;
   k.enc_hid = a.enc_hid; k.g_pre = a.g_pre; k.glat = a.glat; k.Hc = s.Hc;
   k.x_ext = a.x_ext; k.gx_out = a.gx_out; k.ext_skip = (a.x_ext && a.ext_skip) ? 1 : 0;
-  k.enc_zloc_w = p + lay.zloc_w; k.enc_zls_w = p + lay.zls_w;
+  k.enc_zloc_w = p + lay.zloc_w; k.enc_zls_w = p + lay.zls_w; k.enc_zloc_b = p + lay.zloc_b; k.enc_zls_b = p + lay.zls_b;
+  k.enc_weff = a.enc_weff; k.enc_beff = a.enc_beff; k.enc_hid_out = a.enc_hid_out;
 
   const int nthreads = slode_ode_threads(s);
   const bool bwd = a.backward != 0;
@@ -2003,6 +2101,15 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
     if (a.alg == 2) return launch_one<5, 25, true, 200, 3, 8, 3, SLODE_RK4, false, true, 2>(k, a.grid, nthreads, lds, stream);
     snprintf(err, errlen, "unknown ode kernel variant %d", a.alg);
     return hipErrorInvalidValue;
+  }
+  // fused encoder forward (metric shape, loop-free, folded encoder path): the caller skipped the enc_fwd2 launch
+  if (a.enc_fuse) {
+    if (!slode_ode_can_fuse_encoder(s, bwd, a.grid) || a.alg != 0 || a.x_ext || a.force_generic || a.force_loop || a.pack) {
+      snprintf(err, errlen, "ode kernel: the fused encoder forward has no instantiation for this launch");
+      return hipErrorInvalidValue;
+    }
+    if (ra) return launch_one<5, 25, true, 200, 3, 8, 3, SLODE_RK4, true, true, 0, 1, true>(k, a.grid, nthreads, lds + 256, stream);
+    return launch_one<5, 25, true, 200, 3, 8, 3, SLODE_RK4, false, true, 0, 1, true>(k, a.grid, nthreads, lds + 256, stream);
   }
   // packed form: four trajectories per workgroup (metric shape, loop-free, batch a multiple of four)
   if (a.pack == 4 && one && a.alg == 0 && !a.x_ext && !a.force_generic && s.B % 4 == 0 && 4 * lds <= 160 * 1024 &&

@@ -108,6 +108,7 @@ int slode_create(slode_handle* out, int device_id) {
   c->ode_loop = getenv("SLODE_ODE_LOOP") != nullptr;
   c->ode_generic = getenv("SLODE_ODE_GENERIC") != nullptr;
   c->ode_alg = getenv("SLODE_ODE_ALG") ? atoi(getenv("SLODE_ODE_ALG")) : 0;
+  c->enc_fuse = getenv("SLODE_ENC_FUSE") ? atoi(getenv("SLODE_ENC_FUSE")) : 1;
   c->ode_pack = getenv("SLODE_ODE_PACK") ? atoi(getenv("SLODE_ODE_PACK")) : 0;
   c->ode_grid_cap = getenv("SLODE_ODE_GRID") ? atoi(getenv("SLODE_ODE_GRID")) : 0;
   *out = c;
@@ -433,6 +434,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
   const bool folded = !h->no_fold && obs_strides[0] == CT && (t_major || c_major) && (s->C == 3 || s->C == 4);
   FoldLaunch fl{};
   hipError_t e;
+  bool enc_fused = false;
   if (folded) {
     fl.s = *s; fl.lay = *lay; fl.params = params; fl.x = obs; fl.t_major = t_major ? 1 : 0;
     fl.weff = w.weff; fl.rowsum = w.rowsum; fl.wprime = w.wprime; fl.beff = w.beff; fl.loc = w.loc; fl.scale = w.scale; fl.hid = w.hid;
@@ -440,6 +442,10 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     fl.gslabs = w.gslabs; fl.n_gslabs = w.gsplit; fl.g_lin_w = grads ? grads + lay->lin_w : nullptr; fl.conv_slabs = w.conv_slabs;
     fl.counter = w.counter;
     fl.sigtab = aux_mode ? nullptr : w.sigtab;
+    // the loop-free ODE kernel of the metric shape runs the encoder forward of its own trajectories (ode_kernel.hip, ENCF): fold only
+    enc_fused = !aux_mode && !dp5 && bwd && h->enc_fuse && !h->ode_loop && !h->ode_generic && h->ode_alg == 0 && !h->ode_pack && !x_out &&
+                slode_ode_can_fuse_encoder(*s, bwd, w.ode_grid);
+    fl.skip_enc = enc_fused ? 1 : 0;
     e = slode_launch_fold_fwd(fl, st);
     HIP_TRY(h, e);
   } else {
@@ -473,6 +479,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     a.sigtab = folded ? w.sigtab : nullptr;   // written by the fold launch above
     a.force_loop = h->ode_loop; a.force_generic = h->ode_generic; a.alg = h->ode_alg; a.pack = h->ode_pack;
     if (bwd && folded) { a.enc_hid = w.hid; a.g_pre = w.g_pre; a.glat = w.glat; a.g_loc = nullptr; a.g_scale = nullptr; }
+    if (enc_fused) { a.enc_fuse = 1; a.enc_weff = w.weff; a.enc_beff = w.beff; a.enc_hid_out = w.hid; }
     if (dp5 && bwd && folded && w.ode_grid + w.dp_rows > 2 * SLODE_REDUCE_GROUPS) {
       // the scorer's rows carry nothing in the solver-side range [init net | dynamics] (the reverse sweep's rows do): the scorer does not
       // write those zeros and stage 1 of the fused tail (the only reader of the rows) does not read them

@@ -50,6 +50,7 @@ struct slode_ctx {
   int ode_loop;           // SLODE_ODE_LOOP: persistent-loop grid even when every trajectory could have its own workgroup
   int ode_generic;        // SLODE_ODE_GENERIC: skip the shape-specialised instantiations
   int ode_alg;            // SLODE_ODE_ALG = 1 / 2: measured A/B arms of the fused kernel (metric shape only; ode_kernel.hip)
+  int enc_fuse;           // SLODE_ENC_FUSE (default 1): encoder forward inside the ODE kernel where an instantiation exists
   int ode_pack;           // SLODE_ODE_PACK = 4: four trajectories per ODE workgroup (metric shape)
   int ode_grid_cap;       // SLODE_ODE_GRID = n: at most n workgroups in the persistent-loop grid (tests: several trajectories per workgroup at small B)
 };
@@ -288,11 +289,15 @@ struct OdeLaunch {
   int ext_skip = 0;               // 1: the scorer does not write the zeros of the slab row's solver-side range [init net | dynamics] --
                                   // only when the consumer of the rows (stage 1 of the fused tail, Stage1::zr_*) does not read them
   int force_loop = 0, force_generic = 0, alg = 0;   // handle flags (slode_ctx)
+  int enc_fuse = 0;      // 1: the kernel runs the encoder forward of its trajectories itself (ENCF; slode_ode_can_fuse_encoder), from
+  const float *enc_weff = nullptr, *enc_beff = nullptr;   // the fold launch's W_eff [Hc][C*T] / b_eff [Hc]; obs must be dense rows (sb == C*T)
+  float* enc_hid_out = nullptr;                          // saved tanh [B][Hc]
   int pack = 0;          // 4: four trajectories per workgroup where the shape has such an instantiation (ode_kernel.hip, PK)
 };
 hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, size_t errlen);
 size_t slode_ode_lds_bytes(const slode_shape& s, int nthreads, bool one = false);
 int slode_ode_threads(const slode_shape& s);
+bool slode_ode_can_fuse_encoder(const slode_shape& s, bool bwd, int grid);
 
 struct EncLaunch {
   slode_shape s;
@@ -346,6 +351,7 @@ struct FoldLaunch {
   unsigned int* counter = nullptr;   // zeroed by the fold kernel; arrivals of the chain blocks
   float* sigtab = nullptr;           // [4][C*T] likelihood-scale table of this step (see OdeLaunch::sigtab), written by extra fold blocks
   const TailK* tail = nullptr;       // chain launch also finishes the whole flat gradient (+ loss, + optional Adam)
+  int skip_enc = 0;                  // 1: fold only (the ODE kernel runs the encoder forward itself)
 };
 hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream);
 hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream);
