@@ -58,7 +58,7 @@ def _rel(a, b):
 
 def _run(c, mode, env, monkeypatch):
     from structured_latent_odes_amd import engine as E
-    for k in ("SLODE_ODE_LOOP", "SLODE_ODE_GRID", "SLODE_ODE_GENERIC", "SLODE_ODE_ALG", "SLODE_ODE_PACK"):
+    for k in ("SLODE_ODE_LOOP", "SLODE_ODE_GRID", "SLODE_ODE_GENERIC", "SLODE_ODE_ALG", "SLODE_ODE_PACK", "SLODE_ENC_FUSE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -132,6 +132,18 @@ def test_packed_arm_of_the_metric_shape(mode, monkeypatch):
     waves, LDS region and slab row, sharing only the barriers (SLODE_ODE_PACK=4; B = 12 = three packed workgroups).  Same step."""
     c = _case("c1_cvs_T200_L8_rk4", mode)
     _run(c, mode, {"SLODE_ODE_PACK": "4"}, monkeypatch)
+
+
+@pytest.mark.parametrize("mode", ["exact", "reference_adjoint"])
+def test_metric_shape_with_the_separate_encoder_launch(mode, monkeypatch):
+    """The metric shape's loop-free kernel runs the encoder forward of its own trajectory by default (ENCF, ode_kernel.hip);
+    SLODE_ENC_FUSE=0 restores the separate enc_fwd2 launch.  Both score the same step: each against the oracle, and the two losses agree
+    to fp32 summation order (the folded product is summed in a different order: wave-per-13-rows against wave-per-4-rows)."""
+    c = _case("c1_cvs_T200_L8_rk4", mode)
+    a = _run(c, mode, {"SLODE_ENC_FUSE": "0"}, monkeypatch)
+    b = _run(c, mode, {}, monkeypatch)
+    assert abs(a[0].item() - b[0].item()) <= 2e-6 * abs(b[0].item())
+    assert _rel(a[1], b[1]) < 2e-5
 
 
 def test_non_monotone_time_grid_is_rejected():
