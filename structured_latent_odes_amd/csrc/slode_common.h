@@ -70,28 +70,6 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// Sixteen wave-wide sums for the price of 17 shuffles (instead of 96): a halving butterfly over lane bits 5..2 leaves ONE of the
-// sixteen values per lane, two more exchanges finish it.  Returns sum over the wave of a[(lane >> 2) & 15] (fixed order).
-template <int HALF, int OFF>
-__device__ __forceinline__ void wave_halve(float (&a)[16], int lane) {   // compile-time indices only (register arrays)
-  const bool hi = (lane & OFF) != 0;
-#pragma unroll
-  for (int v = 0; v < HALF; ++v) {
-    const float keep = hi ? a[v + HALF] : a[v], send = hi ? a[v] : a[v + HALF];
-    a[v] = keep + __shfl_xor(send, OFF, 64);
-  }
-}
-__device__ __forceinline__ float wave_sum16(float (&a)[16], int lane) {
-  wave_halve<8, 32>(a, lane);
-  wave_halve<4, 16>(a, lane);
-  wave_halve<2, 8>(a, lane);
-  wave_halve<1, 4>(a, lane);
-  float r = a[0];
-  r += __shfl_xor(r, 2, 64);
-  r += __shfl_xor(r, 1, 64);
-  return r;
-}
-
 // One DPP move of a float (quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140): a VALU
 // operand modifier, no LDS-pipe round trip (ds_bpermute)
 template <int CTRL>
@@ -105,6 +83,42 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_f<0x141>(v);
   v += dpp_f<0x140>(v);
   return v;
+}
+
+// Sixteen wave-wide sums for the price of 15 exchanges (instead of 96 shuffles): a halving butterfly over lane bits 5..2 leaves ONE of
+// the sixteen values per lane, two more exchanges finish it.  Returns sum over the wave of a[(lane >> 2) & 15] (fixed order).  No
+// exchange touches the LDS pipe (round 3; until then 17 ds_bpermute): the two cross-row levels are gfx950's v_permlane32_swap /
+// v_permlane16_swap -- one instruction hands each half (each row parity) the other's operand -- the levels inside a 16-lane row are
+// DPP moves (row_ror:8; row_half_mirror, which pairs lane i with 7 - i: any pairing of the low with the high half of a group serves a
+// sum), the last two quad_perm adds.
+__device__ __forceinline__ float wave_sum16(float (&a)[16], int lane) {
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {   // lanes 0..31 keep a[v], lanes 32..63 keep a[v + 8]
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[v]), __float_as_uint(a[v + 8]), false, false);
+    a[v] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {   // even rows keep a[v], odd rows a[v + 4]
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[v]), __float_as_uint(a[v + 4]), false, false);
+    a[v] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const bool hi = (lane & 8) != 0;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const float keep = hi ? a[v + 2] : a[v], send = hi ? a[v] : a[v + 2];
+      a[v] = keep + dpp_f<0x128>(send);   // row_ror:8
+    }
+  }
+  {
+    const bool hi = (lane & 4) != 0;
+    const float keep = hi ? a[1] : a[0], send = hi ? a[0] : a[1];
+    a[0] = keep + dpp_f<0x141>(send);     // row_half_mirror
+  }
+  float r = a[0];
+  r += dpp_f<0x4E>(r);   // quad_perm [2,3,0,1]
+  r += dpp_f<0xB1>(r);   // quad_perm [1,0,3,2]
+  return r;
 }
 
 // sum_{w < n} p[w * stride] with 16 loads in flight; fixed order (four round-robin partial sums, combined pairwise)
