@@ -381,8 +381,8 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
         acc = 0.f;
         for (int mm = lg; mm < Hc; mm += lpo) acc = fmaf(W[mm], hd[mm], acc);
       }
-      if (lsh >= 4) { acc += __shfl_xor(acc, 8, 64); acc += __shfl_xor(acc, 4, 64); }
-      if (lsh >= 2) { acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 1, 64); }
+      if (lsh >= 4) acc = row16_sum(acc);   // (DPP: the 16 lanes of an output are one row; the quads of the 4-lane form likewise)
+      else if (lsh >= 2) { acc += dpp_f<0xB1>(acc); acc += dpp_f<0x4E>(acc); }
       acc += s_hb[which * L + l];
       if (lg == 0 && e0 < n_out && b0 + tb < k.B) {
         if (which) k.scale[(long long)(b0 + tb) * L + l] = expf(acc);

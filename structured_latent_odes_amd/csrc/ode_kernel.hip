@@ -800,10 +800,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     float acc = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc = fmaf((l16 + 16 * q < k.Hc) ? e_hw[q] : 0.f, s_ehid[min(l16 + 16 * q, k.Hc - 1)], acc);
-    acc += __shfl_xor(acc, 8, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 1, 64);
+    acc = row16_sum(acc);   // (four DPP adds: the 16 lanes of an output are one DPP row)
     acc += e_hb;
     if (l16 == 0 && o < 2 * L) s_pf[which * pad4(L) + l] = which ? expf(acc) : acc;
     __syncthreads();

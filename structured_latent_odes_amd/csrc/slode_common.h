@@ -64,11 +64,6 @@ __device__ __forceinline__ float sigmoidf_fast(float x) {
 // torch.nn.Softplus(beta=1, threshold=20): models/decoders.py:52
 __device__ __forceinline__ float softplusf(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
 
 // One DPP move of a float (quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140): a VALU
 // operand modifier, no LDS-pipe round trip (ds_bpermute)
@@ -83,6 +78,15 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_f<0x141>(v);
   v += dpp_f<0x140>(v);
   return v;
+}
+// sum over the wave, valid in every lane, without the LDS pipe (six ds_bpermute until round 3): the four DPP adds of a row, then gfx950's
+// v_permlane16_swap / v_permlane32_swap hand every row the sum of its neighbour row, every half the sum of the other half.  Fixed order.
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
 // Sixteen wave-wide sums for the price of 15 exchanges (instead of 96 shuffles): a halving butterfly over lane bits 5..2 leaves ONE of
