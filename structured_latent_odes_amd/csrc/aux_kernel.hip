@@ -32,11 +32,7 @@ constexpr int AUX_QMAX = 8;    // label columns of one head
 // head's latent sample goes through a few LDS words written and read by the same wave (in program order: no barrier), and every
 // gradient element has ONE owner lane that carries it in a register across the workgroup's trajectories -- the slab row is written
 // once, at the end.  The only workgroup barriers are the two around the encoder-head backward (it needs every head's latent gradient).
-__device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+__device__ __forceinline__ float half_sum(float v) { return half_wave_sum(v); }   // (DPP + v_permlane16_swap: slode_common.h)
 
 __global__ void __launch_bounds__(128) aux_kernel(const AuxK k) {
   __shared__ float s_z[SLODE_MAX_AUX][AUX_ZMAX];

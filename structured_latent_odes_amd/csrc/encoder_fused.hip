@@ -505,15 +505,12 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
 #pragma unroll
           for (int i = 0; i < PERM; ++i) acc[j] = fmaf(gv[i + j], wv[i], acc[j]);
       }
-      // half-wave sum: four DPP adds inside the 16-lane rows, then the two rows of the half-wave (one batch of ds_bpermute)
-      float t[JM];
+      // half-wave sum: four DPP adds inside the 16-lane rows, then the two rows of the half-wave (v_permlane16_swap)
 #pragma unroll
-      for (int j = 0; j < JM; ++j) acc[j] = row16_sum(acc[j]);
-#pragma unroll
-      for (int j = 0; j < JM; ++j) t[j] = __shfl_xor(acc[j], 16, 64);
+      for (int j = 0; j < JM; ++j) acc[j] = half_wave_sum(acc[j]);
       if (valid && ch == 0) {
 #pragma unroll
-        for (int j = 0; j < JM; ++j) s_pw[fc * JM + j] = (j < J) ? acc[j] + t[j] : 0.f;
+        for (int j = 0; j < JM; ++j) s_pw[fc * JM + j] = (j < J) ? acc[j] : 0.f;
       }
     }
   }
@@ -600,8 +597,8 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
       }
     }
     float g = (a0 + a1) + (a2 + a3);
-    g += __shfl_xor(g, 1, 64);
-    g += __shfl_xor(g, 2, 64);
+    g += dpp_f<0xB1>(g);   // the element's four lanes are one quad: quad_perm [1,0,3,2], [2,3,0,1]
+    g += dpp_f<0x4E>(g);
     if (el_on && part == 0) {
       tl.grads[ci] = g;
       if (tl.ad.p) {   // adam_apply with the prefetched state

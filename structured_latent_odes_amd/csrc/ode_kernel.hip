@@ -952,9 +952,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
         lg[q] = 0.f; go[q] = 0.f;
         w2c[q] = (on && q < ax.u_dim) ? cp0[k.o_aux_w2[hd] - sh_aux + min(q, ax.u_dim - 1) * k.U + j] : 0.f;
         if (q < ax.u_dim) {   // (uniform per half-wave)
-          float v = w2c[q] * hvv;
-#pragma unroll
-          for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+          const float v = half_wave_sum(w2c[q] * hvv);
           lg[q] = v + cp0[k.o_aux_b2[hd] - sh_aux + q];
         }
       }
@@ -1763,7 +1761,16 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           if (!RA) gz = fmaf(s_par[k.o_wh + j * (1 + L) + 1 + lc], s_gu[j], gz);   // reference_adjoint: z is not an adjoint parameter
           gz = fmaf(s_par[k.o_w1 + j * L + lc], s_gp0[j], gz);
         }
-        for (int off = Lp; off < 64; off <<= 1) gz += __shfl_xor(gz, off, 64);
+        // the `parts` lane groups' partial sums (lane bits >= log2(Lp)): DPP inside a row, v_permlane swaps across rows and halves
+        if (Lp <= 8) gz += dpp_f<0x128>(gz);   // row_ror:8
+        if (Lp <= 16) {
+          const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(gz), __float_as_uint(gz), false, false);
+          gz = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+        if (Lp <= 32) {
+          const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(gz), __float_as_uint(gz), false, false);
+          gz = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
         if (tid < L) {
           gz += s_gzl[l];
           for (int hd = 0; hd < k.n_aux; ++hd) {

@@ -79,6 +79,13 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_f<0x140>(v);
   return v;
 }
+// sum over each half-wave (lanes 0..31, lanes 32..63), valid in every lane of the half: the row's four DPP adds, then v_permlane16_swap
+// hands every row the sum of the other row of its half
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v = row16_sum(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 // sum over the wave, valid in every lane, without the LDS pipe (six ds_bpermute until round 3): the four DPP adds of a row, then gfx950's
 // v_permlane16_swap / v_permlane32_swap hand every row the sum of its neighbour row, every half the sum of the other half.  Fixed order.
 __device__ __forceinline__ float wave_sum(float v) {
