@@ -362,15 +362,24 @@ __device__ __forceinline__ void radj_stage_grads(int method, float hb, const flo
 // Affine recurrence y_{k+1} = A[i(k)] * y_k + v[j(k)], k = 0..T-2, results stored back over v, executed by ONE wave.
 //   forward (REV=false): i = k,       j = k+1, y_0 = v[0]      (x_{n+1} = A_n x_n + b_n, b_n pre-stored in v[n+1])
 //   reverse (REV=true):  i = T-2-k,   j = i,   y_0 = v[T-1]    (lambda_i = A_i lambda_{i+1} + g_i)
-// Affine maps compose, so the T-1 long dependency chain is cut into NC = 64/S chunks handled by lanes (chunk, s):
-// compose the chunk's maps (registers), scan the NC composed maps across chunks in log2(NC) shuffle steps, replay the chunk.
+// Affine maps compose, so the T-1 long dependency chain is cut into chunks handled by lanes (component s, chunk c): compose the chunk's
+// maps (registers), scan the composed maps across a component's chunks, replay the chunk.  Lane = 8 s + c: the EIGHT chunks of a
+// component are half a DPP row, so the Kogge-Stone steps are row_shr:1 / 2 / 4 moves on the VALU (until round 3: lane = c S + s, twelve
+// chunks, and every step a pair of ds_bpermute at lane distance d S -- ten dependent LDS-pipe round trips per scan); what a move drags
+// in from the neighbouring component's half-row lands on lanes c < d, which ignore it.
+constexpr int SCAN_NCH = 8;   // chunks per component and wave
+template <int D>
+__device__ __forceinline__ float scan_shr(float v) {   // value of the lane D places down the row (0 past the row's start)
+  return dpp_f<0x110 + D>(v);
+}
 template <int S, bool REV>
 __device__ __forceinline__ void wave_affine_scan(const float* __restrict__ s_A, float* __restrict__ s_v, int T, int lane) {
-  constexpr int NC = 64 / S;
+  static_assert(S <= 8, "one half-row of eight chunks per state component");
+  constexpr int NC = SCAN_NCH;
   constexpr int CLMAX = 17;  // steps per lane per pass (2 x CLMAX registers): one pass up to T = NC * 17 + 1; longer grids take several
   const int nsteps = T - 1;
-  const int c = lane / S, s = min(lane - c * S, S - 1);
-  const bool lane_on = c < NC;
+  const int c = lane & (NC - 1), s = min(lane >> 3, S - 1);
+  const bool lane_on = (lane >> 3) < S;
   float carry = lane_on ? s_v[(REV ? (T - 1) : 0) * S + s] : 0.f;
   for (int base = 0; base < nsteps; base += NC * CLMAX) {
     const int left = nsteps - base;
@@ -393,16 +402,12 @@ __device__ __forceinline__ void wave_affine_scan(const float* __restrict__ s_A, 
       Q = fmaf(Ar[q], Q, vr[q]);
       P *= Ar[q];
     }
-    // inclusive scan of the composed maps over chunks (Kogge-Stone): afterwards (P, Q) maps the pass's start state to the END of chunk c
-#pragma unroll
-    for (int d = 1; d < NC; d <<= 1) {
-      const float Pp = __shfl_up(P, d * S, 64), Qp = __shfl_up(Q, d * S, 64);
-      if (c >= d) {
-        Q = fmaf(P, Qp, Q);
-        P *= Pp;
-      }
-    }
-    const float Pe = __shfl_up(P, S, 64), Qe = __shfl_up(Q, S, 64);
+    // inclusive scan of the composed maps over the component's chunks (Kogge-Stone): afterwards (P, Q) maps the pass's start state to
+    // the END of chunk c
+    { const float Pp = scan_shr<1>(P), Qp = scan_shr<1>(Q); if (c >= 1) { Q = fmaf(P, Qp, Q); P *= Pp; } }
+    { const float Pp = scan_shr<2>(P), Qp = scan_shr<2>(Q); if (c >= 2) { Q = fmaf(P, Qp, Q); P *= Pp; } }
+    { const float Pp = scan_shr<4>(P), Qp = scan_shr<4>(Q); if (c >= 4) { Q = fmaf(P, Qp, Q); P *= Pp; } }
+    const float Pe = scan_shr<1>(P), Qe = scan_shr<1>(Q);
     float y = (c == 0) ? carry : fmaf(Pe, carry, Qe);   // state at the start of this lane's chunk
 #pragma unroll
     for (int q = 0; q < CLMAX; ++q) {
@@ -414,23 +419,25 @@ __device__ __forceinline__ void wave_affine_scan(const float* __restrict__ s_A, 
         s_v[(REV ? i : i + 1) * S + s] = y;
       }
     }
-    carry = __shfl(y, (NC - 1) * S + s, 64);
+    carry = __shfl(y, (lane & ~(NC - 1)) + NC - 1, 64);   // the component's last chunk
   }
 }
 
-// The same recurrence on ALL waves of the workgroup (forward scan: nothing else runs beside it).  NW * NC chunks of <= 8 steps (the block
-// has at least roundup64(T) threads), lanes (chunk, s): compose the chunk's maps, Kogge-Stone over the wave's chunks, the waves' total
-// maps through LDS (s_xw[NW][2][S]) and one barrier, then every lane applies the totals of the waves before its own and replays its
-// chunk.  Contains a barrier: every thread of the workgroup calls it.  The caller's next barrier publishes the results.
+// The same recurrence on ALL waves of the workgroup (forward scan: nothing else runs beside it).  NW * 8 chunks of <= 8 steps per
+// component (the block has at least roundup64(T) threads), lanes (s, chunk): compose the chunk's maps, Kogge-Stone over the wave's
+// chunks of the component (DPP, as above), the waves' total maps through LDS (s_xw[NW][2][S]) and one barrier, then every lane applies
+// the totals of the waves before its own and replays its chunk.  Contains a barrier: every thread of the workgroup calls it.  The
+// caller's next barrier publishes the results.
 template <int S, bool REV, int CLMAX = 8>
 __device__ __forceinline__ void block_affine_scan(const float* __restrict__ s_A, float* __restrict__ s_v, int T, int tid, int NT,
                                                   float* __restrict__ s_xw) {
-  constexpr int NC = 64 / S;   // (CLMAX: registers per lane; the shape-specialised kernels pass their exact chunk length)
+  static_assert(S <= 8, "one half-row of eight chunks per state component");
+  constexpr int NC = SCAN_NCH;   // (CLMAX: registers per lane; the shape-specialised kernels pass their exact chunk length)
   const int NW = NT >> 6, wave = tid >> 6, lane = tid & 63;
   const int nsteps = T - 1, nch = NW * NC;
-  const int CL = (nsteps + nch - 1) / nch;   // <= 64 / NC <= CLMAX
-  const int c = lane / S, s = min(lane - c * S, S - 1);
-  const bool lane_on = c < NC;
+  const int CL = (nsteps + nch - 1) / nch;   // <= 8 <= CLMAX (NT >= roundup64(T): nch = NT / 8 >= nsteps / 8)
+  const int c = lane & (NC - 1), s = min(lane >> 3, S - 1);
+  const bool lane_on = (lane >> 3) < S;
   const int k0 = (wave * NC + c) * CL;
   const float y0 = s_v[(REV ? (T - 1) : 0) * S + s];
   float Ar[CLMAX], vr[CLMAX];
@@ -449,19 +456,15 @@ __device__ __forceinline__ void block_affine_scan(const float* __restrict__ s_A,
     Q = fmaf(Ar[q], Q, vr[q]);
     P *= Ar[q];
   }
-#pragma unroll
-  for (int d = 1; d < NC; d <<= 1) {   // inclusive scan over the wave's chunks
-    const float Pp = __shfl_up(P, d * S, 64), Qp = __shfl_up(Q, d * S, 64);
-    if (c >= d) {
-      Q = fmaf(P, Qp, Q);
-      P *= Pp;
-    }
-  }
-  if (c == NC - 1) {   // the wave's total map
+  // inclusive scan over the wave's chunks of the component
+  { const float Pp = scan_shr<1>(P), Qp = scan_shr<1>(Q); if (c >= 1) { Q = fmaf(P, Qp, Q); P *= Pp; } }
+  { const float Pp = scan_shr<2>(P), Qp = scan_shr<2>(Q); if (c >= 2) { Q = fmaf(P, Qp, Q); P *= Pp; } }
+  { const float Pp = scan_shr<4>(P), Qp = scan_shr<4>(Q); if (c >= 4) { Q = fmaf(P, Qp, Q); P *= Pp; } }
+  if (lane_on && c == NC - 1) {   // the wave's total map
     s_xw[(wave * 2 + 0) * S + s] = P;
     s_xw[(wave * 2 + 1) * S + s] = Q;
   }
-  const float Pe = __shfl_up(P, S, 64), Qe = __shfl_up(Q, S, 64);
+  const float Pe = scan_shr<1>(P), Qe = scan_shr<1>(Q);
   __syncthreads();
   float y = y0;   // state at the start of this wave's stretch
   for (int w = 0; w < wave; ++w) y = fmaf(s_xw[(w * 2 + 0) * S + s], y, s_xw[(w * 2 + 1) * S + s]);
@@ -1244,7 +1247,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     // ---- P2: forward scan x_{n+1} = A_n x_n + b_n (the only serial part of the solve) -------------------
     if (!ext) {
       constexpr int NTc = T_ ? ode_threads_for(T_ ? T_ : 1, Q_ ? Q_ : 1, C_ ? C_ : 1, S) : 64;
-      constexpr int CLc = T_ ? ((T_ - 1) + (NTc / 64) * (64 / S) - 1) / ((NTc / 64) * (64 / S)) : 8;   // steps per lane of the forward scan
+      constexpr int CLc = T_ ? ((T_ - 1) + (NTc / 64) * SCAN_NCH - 1) / ((NTc / 64) * SCAN_NCH) : 8;   // steps per lane of the forward scan
       block_affine_scan<S, false, (CLc < 8 ? CLc : 8)>(s_A, s_x, T, tid, NT, s_ct);   // (the chunk-sum buffer of P6 carries the waves' total maps)
     } else {   // score the adaptive solver's trajectory instead
       const float* xe = k.x_ext + (long long)b * T * S;
