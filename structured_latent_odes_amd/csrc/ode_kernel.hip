@@ -372,11 +372,17 @@ template <int D>
 __device__ __forceinline__ float scan_shr(float v) {   // value of the lane D places down the row (0 past the row's start)
   return dpp_f<0x110 + D>(v);
 }
-template <int S, bool REV>
+// steps per lane and pass of the one-wave scan (2 x this many registers): a grid length known at compile time gets the fewest passes
+// of <= 26 steps and no more unrolled iterations than it needs (T = 200: one pass of 25; T = 300: two of 19; T = 100: one of 13)
+__host__ __device__ constexpr int wave_scan_cl(int T_) {
+  if (T_ <= 0) return 17;
+  const int n = T_ - 1, passes = (n + SCAN_NCH * 26 - 1) / (SCAN_NCH * 26);
+  return (n + SCAN_NCH * passes - 1) / (SCAN_NCH * passes);
+}
+template <int S, bool REV, int CLMAX = 17>
 __device__ __forceinline__ void wave_affine_scan(const float* __restrict__ s_A, float* __restrict__ s_v, int T, int lane) {
   static_assert(S <= 8, "one half-row of eight chunks per state component");
-  constexpr int NC = SCAN_NCH;
-  constexpr int CLMAX = 17;  // steps per lane per pass (2 x CLMAX registers): one pass up to T = NC * 17 + 1; longer grids take several
+  constexpr int NC = SCAN_NCH;   // (CLMAX steps per lane per pass: one pass up to T = NC * CLMAX + 1; longer grids take several)
   const int nsteps = T - 1;
   const int c = lane & (NC - 1), s = min(lane >> 3, S - 1);
   const bool lane_on = (lane >> 3) < S;
@@ -1365,7 +1371,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
       __syncthreads();
       STAMP(6);
       // ---- P4: adjoint scan (wave 0) || head-weight gradients (waves >= 1) ------------------------------
-      if (!ext && tid < 64) wave_affine_scan<S, true>(s_A, s_lam, T, tid);
+      if (!ext && tid < 64) wave_affine_scan<S, true, wave_scan_cl(T_)>(s_A, s_lam, T, tid);
       if (k.with_ll) {
         const int e = tid - hg_base;
         if (e >= 0 && e < n_headw * hsplit) {
