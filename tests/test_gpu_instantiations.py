@@ -146,6 +146,27 @@ def test_metric_shape_with_the_separate_encoder_launch(mode, monkeypatch):
     assert _rel(a[1], b[1]) < 2e-5
 
 
+def test_fused_encoder_forward_reads_either_dense_layout():
+    """The metric shape's kernel reads its trajectory's observation row in MEMORY order for the fused encoder forward (the fold launch lays
+    W_eff's columns out the same way): a [B,C,T]-contiguous batch must score the same step as the native [B,T,C]-contiguous one."""
+    from structured_latent_odes_amd import engine as E
+    c = _case("c1_cvs_T200_L8_rk4", "exact")
+    dev = torch.device("cuda:0")
+    eng = E.Engine(E.cvs_spec(**c["kw"]), c["T"], dev)
+    eng.set_times(c["times"])
+    flat = eng.pack(c["p"])
+    u_d, eps_d = c["u"].to(dev).contiguous(), c["eps"].to(dev).contiguous()
+    outs = []
+    for obs_d in (c["obs"].permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1), c["obs"].contiguous().to(dev)):
+        loss, grads = torch.zeros(1, device=dev), torch.zeros(eng.n_params, device=dev)
+        eng.workspace(B).fill_(float("nan"))
+        eng.elbo_step(flat, obs_d, u_d, eps_d, loss, grads=grads)
+        outs.append((loss.clone(), grads.clone()))
+    assert abs(outs[0][0].item() - c["want_loss"].item()) / abs(c["want_loss"].item()) < 1e-5
+    assert abs(outs[0][0].item() - outs[1][0].item()) <= 2e-6 * abs(outs[0][0].item())
+    assert _rel(outs[1][1], outs[0][1]) < 2e-5
+
+
 def test_non_monotone_time_grid_is_rejected():
     """torchdiffeq raises on a grid that is not strictly monotone; so does the host side, and the kernel turns the loss into NaN."""
     from structured_latent_odes_amd import engine as E
