@@ -265,15 +265,30 @@ def main():
     import glob
     import hashlib
     sha = hashlib.sha1(open(os.path.join(ROOT, "structured_latent_odes_amd", "csrc", "ode_kernel.hip"), "rb").read()).hexdigest()
-    traffic, issue, rocprof_us = None, None, None
+    traffic, issue, rocprof_us, traffic_all = None, None, None, {}
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_traffic.json")), reverse=True):
         try:
             d = json.load(open(path))
             if d.get("source_sha1_ode_kernel_hip") == sha and dom in d:
                 traffic = d[dom].get("hbm_bytes_per_launch")
+                traffic_all = {k: v.get("hbm_bytes_per_launch") for k, v in d.items() if isinstance(v, dict)}
                 break
         except Exception:
             pass
+    # the launches beside the dominant kernel: each with its algorithmic FLOP count (kernel_flops: SURVEY 8d split over the launches),
+    # its own clock, and -- when the PMC pass was taken on this source -- its measured HBM bytes.  All of them sit far below both
+    # roofs: they are launch- and latency-bound, which is what the two fractions say.
+    pmc_name = {"weff": "fold", "enc_fwd2": "enc_fwd", "enc_bwd_lin": "gemm", "enc_chain": "chain"}
+    kf1 = kernel_flops(shape1)
+    side = []
+    for kn, us in kern_us.items():
+        if kn == dom:
+            continue
+        fl = kf1.get(kn, 0) * B_PER_GPU + (2 * 10 * 3 * 14 * 50 * T if kn == "weff" else 0)   # (the fold itself: Hc*C*T*F*(K+P-1) MACs per step)
+        hb = traffic_all.get(pmc_name.get(kn, kn))
+        side.append({"kernel": kn, "us": us, "algorithmic_flops_per_launch": fl, "tflops": fl / (us * 1e-6) / 1e12,
+                     "frac_fp32": fl / (us * 1e-6) / 1e12 / PEAK_FP32, "hbm_bytes_per_launch": hb,
+                     "hbm_gb_s": (hb / (us * 1e-6) / 1e9) if hb else None, "frac_hbm": (hb / (us * 1e-6) / 1e9 / PEAK_HBM) if hb else None})
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_ode_elbo_ab.json")), reverse=True):
         try:
             d = json.load(open(path))
@@ -315,6 +330,7 @@ def main():
                      "frac_on_rocprof_clock": (flops_launch / (rocprof_us * 1e-6) / 1e12 / PEAK_FP32) if rocprof_us else None,
                      "issue_roofline": issue, "algorithmic_flops_per_launch": flops_launch, "kernel_us": kern_us,
                      "kernels_sum_us": sum(kern_us.values()), "tail_us": sum(v for k, v in kern_us.items() if k != dom),
+                     "side_launches": side,
                      "step_frac_fp32": step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32,
                      "step_frac_hbm": (bytes_per_traj * B_PER_GPU / (ms_per_step * 1e-3)) / 1e9 / PEAK_HBM,
                      "note": "intensity ~850 FLOP/B => compute side of the ridge; fp32 vector peak == fp32 MFMA peak (157.3 TF)"},
