@@ -20,7 +20,10 @@
 //     suffix sums of G evaluated at each unit's switching index.
 //   * every gradient element has ONE owner thread and goes straight to the workgroup's slab row (no LDS accumulators, nothing but the
 //     loss partial carried in registers across trajectories); slab rows are summed in fixed order by the tail => bitwise reproducible.
-//   * folded ELBO step: the encoder heads + tanh backward (g_pre, glat) run here too (P7 / last block of the trajectory).
+//   * folded ELBO step: the encoder heads + tanh backward (g_pre, glat) run here too (P7 / last block of the trajectory), and -- metric
+//     shape, loop-free form (ENCF) -- the encoder FORWARD of the workgroup's own trajectory in the set-up: the step has no encoder launch.
+//   * no cross-lane exchange touches the LDS pipe: DPP moves inside 16-lane rows (the affine scans put a state component's eight chunks
+//     into half a row), v_permlane16_swap / v_permlane32_swap across rows and halves (slode_common.h).
 //   * long latents (L >= 32, shape-specialised): only the parameters the solver phases re-read live in LDS; the rest is staged in the
 //     idle work block for P0 and read from global memory in P7 (ode_cold_global) -- 4 workgroups per CU instead of 2.
 #include "slode_common.h"
