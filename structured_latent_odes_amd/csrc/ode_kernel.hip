@@ -628,6 +628,18 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   (void)prio_slot;
   const int tid_outer = tid;
   STAMP(0);
+#ifndef SLODE_STAMPS
+  if (ENCF) {
+    // Set-up of the fused form: issue priority = residency slot, the YOUNGEST workgroup of the CU first.  The set-up is a queue of W_eff
+    // loads through one L1 and the CU arbitrates oldest-first, so the last slot's requests used to trail (set-up 5.6 / 10.6 us for a
+    // first- / last-slot workgroup) and the kernel ends when that workgroup does.  Measured: 54.4 -> 53.8 us per step; keeping the slot
+    // priority through P0 as well (wave 0's serial stretch) instead of the rotation: 55.5.  The rotation resumes at the next boundary.
+    if (prio_slot >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio_slot == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio_slot == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+  }
+#endif
   // scoring an externally solved trajectory (dopri5 training, generic instantiation): no solve, nothing flows through a solver here
   const bool ext = (ALG == 3) || ((T_ == 0) && k.x_ext != nullptr);   // ALG 3: shape-specialised scorer (every solver phase is dead code)
 
