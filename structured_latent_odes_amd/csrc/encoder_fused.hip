@@ -62,33 +62,58 @@ template <int JM>  // compile-time bound on J = K + P - 1 (14 for every referenc
 __global__ void __launch_bounds__(WNT) weff_kernel(const float* __restrict__ pl_conv_w, const float* __restrict__ pl_lin_w, const FoldK k,
                                                    const int stage_rows) {
   __shared__ float s_wp[SLODE_MAX_F * SLODE_MAX_C * JM];
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [F*C*K conv taps][stage_rows ? the block's lin.weight rows : 0]
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [stage_rows ? the block's lin.weight rows : 0]
   const int tid = threadIdx.x, J = k.J, C = k.C, K = k.K;
   const float fP = (float)k.P;
   if (blockIdx.x == 0 && tid < 8 && k.counter) k.counter[32 * tid] = 0u;   // arrival counters of this step's chain blocks (one per filter pair, 128 B apart)
   STAMP(0);
   const int n_w = k.Hc * k.CT;
   const int nb_w = (n_w + WPB - 1) / WPB, nb_rs = (k.Hc + WNT / 64 - 1) / (WNT / 64);
-  float* s_cw = smem;
-  float* s_lw = smem + ((k.F * C * K + 3) & ~3);
+  float* s_lw = smem;
   // Everything this block reads from global memory is fetched in ONE batch: the conv taps, and (W_eff blocks) the lin.weight rows
   // of the hidden units its WPB outputs belong to (2 for C*T >= WPB) -- coalesced, instead of F*JM = 140 strided loads per thread.
   const int e_first = (int)blockIdx.x * WPB, m0 = min(e_first, n_w - 1) / k.CT, m1 = min(e_first + WPB - 1, n_w - 1) / k.CT;
   {
-    // (the conv taps and the rows are requested together and only then stored: two loops would be two round trips)
-    const int n_cw = k.F * C * K;
+    // Everything the block needs from global memory is requested in one batch and only then stored: the lin.weight rows, and -- per
+    // thread -- the (up to P) conv taps under its own w' entry, so that w' needs no staged copy of the taps and no barrier of its own:
+    //   w'[f][c][j] = (1/P) * sum_{k + p = j} w[f][c][k]   (rows padded to JM, zero beyond J)
     const bool rows = stage_rows && (int)blockIdx.x < nb_w;
     const int n_st = rows ? (m1 - m0 + 1) * k.FQ : 0;
     const float* src = pl_lin_w + (long long)m0 * k.FQ;
-    const float cw0 = pl_conv_w[min(tid, n_cw - 1)];
+    const int n_wp = k.F * C * JM;
+    const int e = min(tid, n_wp - 1), j = e % JM, fc = e / JM;
+    float tp[SLODE_MAX_P];
+#pragma unroll
+    for (int p = 0; p < SLODE_MAX_P; ++p) {
+      const int kk = j - p;
+      const bool on = p < k.P && j < J && kk >= 0 && kk < K;
+      tp[p] = on ? pl_conv_w[fc * K + min(max(kk, 0), K - 1)] : 0.f;
+    }
     float v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = rows ? src[min(tid + q * WNT, n_st - 1)] : 0.f;
-    if (tid < n_cw) s_cw[tid] = cw0;
+    if (tid < n_wp) {
+      float sw = 0.f;
+#pragma unroll
+      for (int p = 0; p < SLODE_MAX_P; ++p) sw += tp[p];
+      sw = sw / fP;
+      s_wp[tid] = sw;
+      if (blockIdx.x == 0 && j < J) k.wprime[fc * J + j] = sw;
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q)
       if (tid + q * WNT < n_st) s_lw[tid + q * WNT] = v[q];
-    for (int i = tid + WNT; i < n_cw; i += WNT) s_cw[i] = pl_conv_w[i];
+    for (int e2 = tid + WNT; e2 < n_wp; e2 += WNT) {   // (more than 512 entries: long-tap shapes)
+      const int j2 = e2 % JM, fc2 = e2 / JM;
+      float sw = 0.f;
+      for (int p = 0; p < k.P; ++p) {
+        const int kk = j2 - p;
+        if (j2 < J && kk >= 0 && kk < K) sw += pl_conv_w[fc2 * K + kk];
+      }
+      sw = sw / fP;
+      s_wp[e2] = sw;
+      if (blockIdx.x == 0 && j2 < J) k.wprime[fc2 * J + j2] = sw;
+    }
     for (int i0 = tid + 8 * WNT; i0 < n_st; i0 += 8 * WNT) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = src[min(i0 + q * WNT, n_st - 1)];
@@ -96,19 +121,6 @@ __global__ void __launch_bounds__(WNT) weff_kernel(const float* __restrict__ pl_
       for (int q = 0; q < 8; ++q)
         if (i0 + q * WNT < n_st) s_lw[i0 + q * WNT] = v[q];
     }
-  }
-  __syncthreads();
-  // w'[f][c][j] = (1/P) * sum_{k + p = j} w[f][c][k]   (rows padded to JM, zero beyond J)
-  for (int e = tid; e < k.F * C * JM; e += WNT) {
-    const int j = e % JM, fc = e / JM;
-    float s = 0.f;
-    for (int p = 0; p < k.P; ++p) {
-      const int kk = j - p;
-      if (j < J && kk >= 0 && kk < K) s += s_cw[fc * K + kk];
-    }
-    s = s / fP;
-    s_wp[e] = s;
-    if (blockIdx.x == 0 && j < J) k.wprime[fc * J + j] = s;
   }
   __syncthreads();
   STAMP(1);
@@ -639,11 +651,10 @@ int slode_fold_small_count(const slode_shape& s) { return s.Hc + 2 * (s.L * s.Hc
 hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream) {
   FoldK k = make_foldk(a);
   const int nb_w = (k.Hc * k.CT + WPB - 1) / WPB, nb_r = (k.Hc + WNT / 64 - 1) / (WNT / 64) + (k.sigtab ? (k.CT + WNT - 1) / WNT : 0);
-  // dynamic LDS: conv taps + (when they fit) the lin.weight rows a block's WPB consecutive outputs can touch
-  const size_t cw = ((size_t)k.F * k.C * k.K + 3) & ~(size_t)3;
+  // dynamic LDS: (when they fit) the lin.weight rows a block's WPB consecutive outputs can touch
   const size_t max_rows = (size_t)(WPB - 1) / k.CT + 2;   // WPB outputs starting anywhere inside a row of CT
-  const int stage_rows = (cw + max_rows * (size_t)k.FQ) * sizeof(float) <= 96 * 1024 ? 1 : 0;
-  const size_t wlds = sizeof(float) * (cw + (stage_rows ? max_rows * (size_t)k.FQ : 0));
+  const int stage_rows = (max_rows * (size_t)k.FQ) * sizeof(float) <= 96 * 1024 ? 1 : 0;
+  const size_t wlds = sizeof(float) * (stage_rows ? max_rows * (size_t)k.FQ : 4);
   if (k.J <= 14) {
     if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)weff_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
     SLODE_LAUNCH("weff", (weff_kernel<14>), dim3(nb_w + nb_r), dim3(WNT), wlds, stream, k.conv_w, k.lin_w, k, stage_rows);
