@@ -125,8 +125,10 @@ __global__ void __launch_bounds__(WNT) weff_kernel(const float* __restrict__ pl_
   __syncthreads();
   STAMP(1);
   if ((int)blockIdx.x < nb_w) {
-    // WPB = 128 outputs per block, WFG threads per output (each a group of the filters): ~250 blocks fill the 256 CUs
-    const int el = tid & (WPB - 1), fh = tid / WPB, fper = (k.F + WFG - 1) / WFG;
+    // WPB = 128 outputs per block, WFG = 4 threads per output (each a group of the filters): ~250 blocks fill the 256 CUs.  The four
+    // threads of an output are one quad: their partial sums meet in two DPP adds (fixed order), no LDS, no barrier.
+    static_assert(WFG == 4, "the filter groups of an output are the lanes of a quad");
+    const int el = tid >> 2, fh = tid & 3, fper = (k.F + WFG - 1) / WFG;
     const int e = min((int)blockIdx.x * WPB + el, n_w - 1);
     const int m = e / k.CT, kap = e - m * k.CT;
     int c, t;
@@ -146,15 +148,10 @@ __global__ void __launch_bounds__(WNT) weff_kernel(const float* __restrict__ pl_
         if (j + 1 < JM) acc1 = fmaf((t - j - 1 >= 0 && t - j - 1 < k.n_pool) ? v[j + 1] : 0.f, wp[j + 1], acc1);
       }
     }
-    __shared__ float s_half[(WFG - 1) * WPB];
-    if (fh > 0) s_half[(fh - 1) * WPB + el] = acc0 + acc1;
-    __syncthreads();
-    if (fh == 0 && (int)blockIdx.x * WPB + el < n_w) {
-      float r = acc0 + acc1;
-#pragma unroll
-      for (int g = 1; g < WFG; ++g) r += s_half[(g - 1) * WPB + el];   // fixed order
-      k.weff[e] = r;
-    }
+    float r = acc0 + acc1;
+    r += dpp_f<0xB1>(r);   // quad_perm [1,0,3,2]
+    r += dpp_f<0x4E>(r);   // quad_perm [2,3,0,1]
+    if (fh == 0 && (int)blockIdx.x * WPB + el < n_w) k.weff[e] = r;
     STAMP(2);
   } else if ((int)blockIdx.x >= nb_w + nb_rs) {
     // likelihood scales of this step (decoders.py:52-53: softplus(constant_std)) and what the likelihood and its gradient need of them:
