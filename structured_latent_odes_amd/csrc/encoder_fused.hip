@@ -264,9 +264,10 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
     const long long base = (long long)b0 * CT, lim = (long long)k.B * CT - 1;
     constexpr int NHW = BIGL ? 8 : 2;   // 2 * L * Hc <= 8 * 1024 head weights: one batch (short latents: two loads, then a loop)
     static_assert(2 * SLODE_MAX_L * SLODE_MAX_HC <= 8 * FNT, "the head weights are staged in one batch of loads");
-    float v[4], hw[NHW];
+    constexpr int NXB = TB >= 16 ? 8 : 4;   // observation loads in flight per thread (16 trajectories x C*T: one batch of eight)
+    float v[NXB], hw[NHW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = pl_x[min(base + tid + q * NT, lim)];
+    for (int q = 0; q < NXB; ++q) v[q] = (q < 4 || q * NT < TB * CT) ? pl_x[min(base + tid + q * NT, lim)] : 0.f;
 #pragma unroll
     for (int q = 0; q < NHW; ++q) {
       const int e = min(tid + q * NT, 2 * L * Hc - 1);
@@ -276,7 +277,7 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
     const int hbi = min(max(tid - 64, 0), 2 * L - 1);
     const float hbv = (hbi < L) ? k.zloc_b[hbi] : k.zls_b[hbi - L];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NXB; ++q)
       if (tid + q * NT < TB * CT) s_x[tid + q * NT] = v[q];
 #pragma unroll
     for (int q = 0; q < NHW; ++q) {
@@ -294,7 +295,7 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
       for (int e = tid + NHW * NT; e < 2 * L * Hc; e += NT) s_hw[e] = (e < L * Hc) ? pl_zloc_w[e] : pl_zls_w[e - L * Hc];
     if (tid < Hc) s_be[tid] = bev;
     if (tid >= 64 && tid < 64 + 2 * L) s_hb[tid - 64] = hbv;
-    for (int e0 = tid + 4 * NT; e0 < TB * CT; e0 += 4 * NT) {
+    for (int e0 = tid + NXB * NT; e0 < TB * CT; e0 += 4 * NT) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = pl_x[min(base + e0 + q * NT, lim)];
 #pragma unroll
@@ -366,7 +367,39 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
   // heads: LPO lanes per output (which, trajectory, latent dim; latent dim fastest), each summing every LPO-th hidden unit, then an xor
   // butterfly inside the lane group; LPO = 16 / 4 / 1, the largest that covers all outputs in one pass (short latents: 64 outputs x 16
   // lanes; L = 50: one lane each)
-  {
+  if (BIGL) {
+    // long latents: the two head layers are one [TB <= 16 trajectories x Hc] . [Hc x 2L] product on the f32 matrix cores
+    // (v_mfma_f32_16x16x4_f32, exact fp32): wave w takes output columns 16 w .. 16 w + 15 of the 2 L, ceil(Hc / 4) k-steps, one LDS read per
+    // operand and k-step (the transposed head weights make the B operand's 16 lanes consecutive words).  A[m][k]: lane (m = lane & 15,
+    // k = lane >> 4); B[k][n]: lane (n = lane & 15, k = lane >> 4); D[m][n]: register r of lane l is (m = 4 (l >> 4) + r, n = l & 15).
+    static_assert(!BIGL || TB <= 16, "one 16-row tile of trajectories");
+    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+    const int n_cols = 2 * L, n_tiles = (n_cols + 15) >> 4;
+    for (int tile = wave; tile < n_tiles; tile += nw) {
+      const int mrow = lane & 15, kq = lane >> 4;
+      const int n = min(tile * 16 + (lane & 15), n_cols - 1), which = n / L, l = n - which * L;
+      const float* Wn = s_hw + which * L * Hc + l;
+      f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < (Hc + 3) >> 2; ++ks) {
+        const int mm = 4 * ks + kq, mc = min(mm, Hc - 1);
+        const float a = (mm < Hc && mrow < TB) ? s_hid[min(mrow, TB - 1) * 64 + mc] : 0.f;
+        const float bq = (mm < Hc) ? Wn[mc * L] : 0.f;
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, d, 0, 0, 0);
+      }
+      const float bias = s_hb[which * L + l];
+      if (tile * 16 + (lane & 15) < n_cols) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int tb = 4 * (lane >> 4) + r;
+          if (tb < TB && b0 + tb < k.B) {
+            const float acc = d[r] + bias;
+            if (which) k.scale[(long long)(b0 + tb) * L + l] = expf(acc);
+            else k.loc[(long long)(b0 + tb) * L + l] = acc;
+          }
+        }
+      }
+    }
+  } else {
     const int n_out = TB * L * 2;
     const int lsh = (n_out * 16 <= NT) ? 4 : ((n_out * 4 <= NT) ? 2 : 0), lpo = 1 << lsh;   // kernel-uniform
     for (int e0 = (tid >> lsh); e0 < ((n_out + (64 >> lsh) - 1) & ~((64 >> lsh) - 1)); e0 += NT >> lsh) {   // (wave-uniform trip count)
