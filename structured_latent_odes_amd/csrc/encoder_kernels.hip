@@ -442,20 +442,26 @@ constexpr int KP = 16;  // batch-pairs (K = 2 each) whose operands a wave loads 
 // With ones_col != 0 the right-hand matrix gets one extra all-ones column (index FQ): output column FQ = sum_b g_pre[b][m], and the
 // slabs have FQ + 1 columns per row (folded encoder path: g_beff comes for free).
 struct GemmProb { const float* A; int lda; const float* X; float* slabs; int M, N, ntiles; };   // A: [B][lda], rows m < 64 used
-struct GemmProbs { GemmProb p[3]; int n_gemm_x; Stage1 rider; int rider_bx; };   // rider: stage-1 slab reduction in extra blocks
+struct GemmProbs { GemmProb p[3]; int n_gemm_x; Stage1 rider; int rider_bx; int splitk_grid; };   // rider: stage-1 slab reduction in extra blocks; splitk_grid > 0: one-dimensional grid [products (tile, split) | riders]
 // pl_A0 / pl_X0 = ps.p[0].A / .X (the big product's operands) as leading, SGPR-preloaded arguments (see ode_elbo_kernel)
 __global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restrict__ pl_A0, const float* __restrict__ pl_X0, const GemmProbs ps, int B,
                                                           int per_wave, int ones_col) {
   __shared__ float s_part[4 * 32 * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if ((int)blockIdx.x >= ps.n_gemm_x) {   // rider blocks: (bx, group) = stage 1 of the ODE-slab reduction, independent of the GEMMs
-    const int r = ((int)blockIdx.x - ps.n_gemm_x) * gridDim.y + blockIdx.y;
+  // One-dimensional grid, the products' blocks FIRST: they are dispatched to CUs of their own before the rider blocks fill in (with the
+  // riders interleaved in dispatch order the two kinds delayed each other: products alone 5.3 us, riders alone 4.7, together 6.6).
+  // (The layer-by-layer path launches the same kernel two-dimensional without riders: both index forms are handled.)
+  const int n_prod = ps.n_gemm_x * ps.splitk_grid;
+  const int blk = ps.splitk_grid ? (int)blockIdx.x : -1;
+  if (blk >= n_prod) {   // rider blocks: (bx, group) = stage 1 of the ODE-slab reduction, independent of the GEMMs
+    const int r = blk - n_prod;
     const int bx = r % ps.rider_bx, g = r / ps.rider_bx;
     if (g < SLODE_REDUCE_GROUPS) slab_stage1_block(ps.rider, bx, g, s_part);
     return;
   }
-  // up to three independent products share the launch (column tiles laid end to end along blockIdx.x)
-  int tile = (int)blockIdx.x;
+  const int by = ps.splitk_grid ? blk / ps.n_gemm_x : (int)blockIdx.y;
+  // up to three independent products share the launch (column tiles laid end to end)
+  int tile = ps.splitk_grid ? blk - by * ps.n_gemm_x : (int)blockIdx.x;
   const int which = tile < ps.p[0].ntiles ? 0 : (tile < ps.p[0].ntiles + ps.p[1].ntiles ? 1 : 2);
   tile -= which == 0 ? 0 : (which == 1 ? ps.p[0].ntiles : ps.p[0].ntiles + ps.p[1].ntiles);
   const GemmProb p = which == 0 ? ps.p[0] : (which == 1 ? ps.p[1] : ps.p[2]);
@@ -464,7 +470,7 @@ __global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restric
   float* __restrict__ slabs = p.slabs;
   const int Hc = p.M, FQ = p.N, lda = p.lda;
   const int i0 = tile * 32;
-  const int ks = blockIdx.y * 4 + wave;
+  const int ks = by * 4 + wave;
   const int bbeg = ks * per_wave, bend = min(B, bbeg + per_wave);
   const int col = lane & 31, kh = lane >> 5;
   const bool col_ok = i0 + col < FQ;
@@ -500,7 +506,7 @@ __global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restric
     s_part[(wave * 32 + 16 + r) * 64 + lane] = acc1[r];
   }
   __syncthreads();
-  float* slab = slabs + (long long)blockIdx.y * Hc * NO;
+  float* slab = slabs + (long long)by * Hc * NO;
   for (int e = tid; e < 32 * 64; e += 256) {
     const int reg = e >> 6, ln = e & 63;
     const float v = (s_part[(0 * 32 + reg) * 64 + ln] + s_part[(1 * 32 + reg) * 64 + ln]) +
@@ -557,7 +563,9 @@ hipError_t slode_launch_gemm_tail(const float* g_pre, const float* x, float* gsl
     rider_x = (ps.rider_bx * SLODE_REDUCE_GROUPS + splitk - 1) / splitk;
     *ode_part_out = ode_part; *ode_n_out = (ode_n + per - 1) / per;
   }
-  SLODE_LAUNCH("enc_bwd_lin", enc_bwd_lin_kernel, dim3(ps.n_gemm_x + rider_x, splitk), dim3(256), 0, stream, ps.p[0].A, ps.p[0].X, ps, B, per_wave, 1);
+  ps.splitk_grid = splitk;
+  const int n_rider = ps.rider_bx * (rider_x ? SLODE_REDUCE_GROUPS : 0);
+  SLODE_LAUNCH("enc_bwd_lin", enc_bwd_lin_kernel, dim3(ps.n_gemm_x * splitk + n_rider), dim3(256), 0, stream, ps.p[0].A, ps.p[0].X, ps, B, per_wave, 1);
   return hipGetLastError();
 }
 
