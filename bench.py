@@ -160,11 +160,25 @@ def kernel_clocks(eng, calls, n=40):
     return {k: acc[k] / n for k in order}
 
 
-def roofline_of(kern_us, shape, B):
+def roofline_of(kern_us, shape, B, variants=None):
+    """Dominant kernel, its algorithmic FLOPs per launch (SURVEY 8d's per-trajectory count x B) and TFLOP/s on its own clock.  Where the
+    ODE kernel also runs the encoder forward (ENCF: no encoder launch in the step) the reference's encoder-forward count is part of what
+    the launch computes and is credited -- `variants` (a dict, filled in place) then carries the same clock under the two narrower
+    counts as well, so the attribution is visible: the solver / ELBO phases alone, and those plus the folded mat-vec the kernel actually
+    executes for the encoder (2 Hc C T instead of the reference's conv + pool + flatten-linear)."""
     kf = kernel_flops(shape)
     dom = max(kern_us, key=kern_us.get)
     fl = kf.get(dom, 0) * B
-    if dom == "ode_elbo" and "enc_fwd2" not in kern_us and "enc_fwd" not in kern_us:
+    fused_enc = dom == "ode_elbo" and "enc_fwd2" not in kern_us and "enc_fwd" not in kern_us
+    if variants is not None and dom == "ode_elbo":
+        sec = kern_us[dom] * 1e-6
+        variants["solver_and_elbo_phases_only"] = {"flops_per_launch": fl, "frac": fl / sec / 1e12 / PEAK_FP32}
+        if fused_enc:
+            ex = fl + 2 * 50 * shape["C"] * shape["T"] * B
+            variants["with_encoder_as_executed_folded_matvec"] = {"flops_per_launch": ex, "frac": ex / sec / 1e12 / PEAK_FP32}
+            ref = fl + kf["enc_fwd2"] * B
+            variants["with_encoder_at_reference_count"] = {"flops_per_launch": ref, "frac": ref / sec / 1e12 / PEAK_FP32}
+    if fused_enc:
         fl += kf["enc_fwd2"] * B   # the step has no encoder launch: the ODE kernel ran the encoder forward of its trajectories itself (ENCF)
     achieved = fl / (kern_us[dom] * 1e-6) / 1e12
     return dom, fl, achieved
@@ -257,7 +271,8 @@ def main():
     else:   # N > 1: the step is two entry points around the collective
         calls = [lambda: eng.elbo_step(flat, obs_d, u_d, eps_d, svi.loss, svi.grads), lambda: opt.step(svi.gbuf[:flat.numel()])]
     kern_us = kernel_clocks(eng, calls, n=40)
-    dom, flops_launch, achieved = roofline_of(kern_us, shape1, B_PER_GPU)
+    frac_variants = {}
+    dom, flops_launch, achieved = roofline_of(kern_us, shape1, B_PER_GPU, frac_variants)
     step_flops = 3 * sum(flops_fwd(shape1).values()) * B_PER_GPU
     bytes_per_traj = 4 * (3 * T + sum(Z_SPLIT) + 2)     # algorithmic HBM bytes: obs once + eps + labels = 2,440 B
 
@@ -323,6 +338,10 @@ def main():
         "final_loss_per_traj": final_loss / (world * B_PER_GPU),
         "roofline": {"bound": "fp32_valu", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32, "traffic": traffic,
+                     "frac_by_flop_count": frac_variants,
+                     "frac_note": "frac = SURVEY 8d's algorithmic count of everything the launch computes (the fused kernel also runs the "
+                                  "encoder forward, credited at the reference's operation count); frac_by_flop_count gives the same clock under "
+                                  "the narrower counts; step_frac_fp32 (whole step, fixed count) is the figure to compare across rounds",
                      "pipe": "fp32 VALU (the dominant kernel issues no MFMA; on gfx950 the f32 MFMA peak equals the f32 vector peak, 157.3 TF)",
                      "clock": "the dispatch's own begin->end device timestamps (hipExtLaunchKernelGGL start/stop events), average of 40 "
                               "launches in this run: the quantity rocprofv3 --kernel-trace reports",
@@ -335,6 +354,32 @@ def main():
                      "step_frac_hbm": (bytes_per_traj * B_PER_GPU / (ms_per_step * 1e-3)) / 1e9 / PEAK_HBM,
                      "note": "intensity ~850 FLOP/B => compute side of the ridge; fp32 vector peak == fp32 MFMA peak (157.3 TF)"},
     }
+
+    # ---- one continuous leg of the metric step, >= 2 s of back-to-back enqueues with ONE synchronize at the end: long enough for an
+    # outside sampler (the driver's gpu_busy) to see the steady state the K-step blocks above measure
+    if world == 1:
+        n_sus = int(min(400000, max(1000, 2.6 / (ms_per_step * 1e-3))))
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        sync()
+        sus = time.perf_counter() - t0
+        out["sustained"] = {"seconds": sus, "steps": n_sus, "traj_per_s": B_PER_GPU * n_sus / sus, "ms_per_step": 1e3 * sus / n_sus}
+
+    # ---- the same step with the reference's DEFAULT gradients (adjoint_solver=True: torchdiffeq.odeint_adjoint's) ----------------------
+    if world == 1:
+        other_mode = "exact" if args.grad_mode == "reference_adjoint" else "reference_adjoint"
+        kw2 = dict(cvs_kw, adjoint_solver=(other_mode == "reference_adjoint"))
+        cfg2, model2, _, obs2, u2, eps2, _, _ = build_case("cvs", False, B_PER_GPU, T, kw2, dev, seed=1234 + rank)
+        b2 = model2._bind()
+        svi2 = ELBOStep(b2.engine, b2.flat, FlatAdam(b2.engine, b2.flat, lr=cfg2.learning_rate))
+        step2 = lambda: svi2.step_async(obs2, eps=eps2, u=u2)
+        prewarm(step2, sync, blocks=12, n=50)
+        ms2 = 1e3 * statistics.median(timed_blocks(step2, sync, args.steps, 9, 1, dev)) / args.steps
+        out["value_" + other_mode] = B_PER_GPU / (ms2 * 1e-3)
+        out["ms_per_step_" + other_mode] = ms2
+        out["value_" + args.grad_mode] = value
 
     # ---- the reference's whole minibatch (training_cvs.py:147-157): main SVI step, auxiliary SVI step, Adam after each ----------------
     if world == 1 and not args.no_run_batch:
@@ -353,7 +398,31 @@ def main():
         main_nofuse = lambda: eng.elbo_step(flat, obs_d, u_d, eps_d, nograd[-1:], nograd[:eng.n_params])
         t_main_noadam = 1e3 * statistics.median(timed_blocks(main_nofuse, sync, K, 9, 1, dev)) / K
         aux_kern = kernel_clocks(eng, [aux_step], n=20)
+        # ... and through the reference's own call: run_batch(batch, losses) (training_cvs.py:147-157) on a device-resident batch dict with
+        # the two SVI objects the entry point builds -- labels handed over as the loader yields them, noise drawn in the kernels, one
+        # C-ABI call per SVI.step and the .item() the API demands (a host synchronisation per step, twice per minibatch)
+        from structured_latent_odes_amd.svi import SVI, Adam, Trace_ELBO
+        from structured_latent_odes_amd.training import run_batch
+        popt = Adam({"lr": cfg.learning_rate, "betas": (0.9, 0.999)})
+        popt._flat = opt                                      # (the FlatAdam the timed steps above already use: same state, same step counts)
+        losses = [SVI(model.model, model.guide, popt, loss=Trace_ELBO(num_particles=1)),
+                  SVI(model.model_meta, model.guide_meta, popt, loss=Trace_ELBO(num_particles=1))]
+        batch = dict(observations=obs_d, **labels_d)
+        api = lambda: run_batch(batch, losses)
+        api_main = lambda: losses[0].step(**batch)
+        for _ in range(50):
+            api()
+        t_api = 1e3 * statistics.median(timed_blocks(api, sync, K, 9, 1, dev)) / K
+        t_api_main = 1e3 * statistics.median(timed_blocks(api_main, sync, K, 9, 1, dev)) / K
+        # the same two steps enqueued without the per-step .item(): what the API's synchronisation costs
+        api_async = lambda: (losses[0].step_async(**batch), losses[1].step_async(**batch))
+        t_api_async = 1e3 * statistics.median(timed_blocks(api_async, sync, K, 9, 1, dev)) / K
         out["run_batch"] = {"main_ms": t_main, "aux_ms": t_aux, "adam_ms": t_adam, "total_ms": t_both,
+                            "api_ms": t_api, "api_main_step_ms": t_api_main, "api_without_item_sync_ms": t_api_async,
+                            "traj_per_s_api_run_batch": B_PER_GPU / (t_api * 1e-3),
+                            "api_note": "api_ms: training.run_batch(batch, losses) = SVI.step(**batch) twice, each ONE slode_svi_step call (label "
+                                        "tensors as the loader yields them, noise drawn in-kernel) + the .item() the reference API returns; "
+                                        "api_without_item_sync_ms: the same calls through step_async (no host sync); total_ms: pre-made eps / u",
                             "main_without_adam_ms": t_main_noadam, "traj_per_s_full_run_batch": B_PER_GPU / (t_both * 1e-3),
                             "aux_kernel_us": aux_kern,
                             "note": "main / aux: one SVI step each with Adam applied by the last kernel of the step (what training runs); "

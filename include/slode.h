@@ -29,11 +29,12 @@
 extern "C" {
 #endif
 
-#define SLODE_VERSION 100 /* 0.1.0 */
+#define SLODE_VERSION 110 /* 0.1.1: slode_svi_step, slode_rng_*, slode_grad_* */
 
 #define SLODE_MAX_GROUPS 4
 #define SLODE_MAX_HEADS 3
 #define SLODE_MAX_AUX 4
+#define SLODE_MAX_LABELS 4 /* label tensors of one minibatch (proc: aR, aS, C12, C6) */
 
 typedef enum slode_status {
   SLODE_OK = 0,
@@ -236,6 +237,73 @@ int slode_aux_step(slode_handle h, const slode_shape* s, const slode_layout* lay
                    const int64_t obs_strides[3], const float* u, const float* eps, float* loss_out, float* grads, void* workspace,
                    size_t workspace_bytes, int64_t n_total, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
                    float adam_eps, int64_t step, void* stream);
+
+/* ---- one SVI.step(**batch) as ONE call (training_cvs.py:147-157: `losses[i].step(**d)`) ------------------------------------------------
+ * The minibatch as the reference's loader and batch_to_device hand it over (training_cvs.py:18-27, training_proc.py:25-33,
+ * training_challenge.py:27-33): the observation tensor with its strides and the label tensors ONE BY ONE -- dense [B, width] each, in the
+ * order in which the model concatenates them into u (cvs: iext, rtpr; proc: aR, aS, C12, C6; challenge: symptoms, shedding) -- no host-side
+ * concatenation.  eps == NULL: the reparameterisation noise of the guide's sample sites (mechanistic_cvs.py:225-237 `pyro.sample(...,
+ * dist.Normal(loc, scale).to_event(1))`; model_meta :256-262 for the auxiliary loss) is drawn INSIDE the kernels from the handle's
+ * counter-based generator (slode_rng_seed); eps != NULL ([B, L], the explicit-noise parity path) is used as is. */
+typedef struct slode_batch {
+  const float* obs;            /* logical [B, C, T] */
+  int64_t obs_strides[3];      /* element strides */
+  int32_t n_labels;            /* 0: no labels (shapes without conditional priors / label heads) */
+  int32_t label_width[SLODE_MAX_LABELS];
+  const float* labels[SLODE_MAX_LABELS];
+  const float* eps;            /* [B, L] or NULL */
+} slode_batch;
+/* Adam hyper-parameters and state for the update applied by the step's last kernel (NULL: gradient only) */
+typedef struct slode_adam {
+  int64_t n_total;             /* floats in params / exp_avg / exp_avg_sq (>= lay->n_params) */
+  float *exp_avg, *exp_avg_sq;
+  float lr, beta1, beta2, eps;
+  int64_t step;                /* 1-based */
+} slode_adam;
+typedef enum slode_svi_kind { SLODE_SVI_MAIN = 0 /* SVI(model, guide) */, SLODE_SVI_AUX = 1 /* SVI(model_meta, guide_meta) */ } slode_svi_kind;
+/* = slode_elbo_step / slode_elbo_adam_step (kind MAIN) or slode_aux_step (kind AUX) on a slode_batch.  grads == NULL: loss only
+ * (SVI.evaluate_loss); adam != NULL: the update is applied by the final reduction kernel (grads must be given).  times / stage_t are
+ * ignored for kind AUX. */
+int slode_svi_step(slode_handle h, const slode_shape* s, const slode_layout* lay, int kind, float* params, const float* times,
+                   const float* stage_t, const slode_batch* batch, float* loss_out, float* grads, void* workspace, size_t workspace_bytes,
+                   const slode_adam* adam, void* stream);
+
+/* ---- data parallel with the small payload (one collective per step) -----------------------------------------------------
+ * The encoder's chain rule is linear in G = g_pre^T [X | 1] (and the head layers' gradients in glat^T [hid | 1]): a rank only has to
+ * contribute its shard's G, its head-layer products and its ODE-half gradient row with the loss scalar --
+ *   payload = [G: Hc x (C T + 1) | G_loc: L x (Hc + 1) | G_ls: L x (Hc + 1) | loss | gradient of flat range [ode_begin, n_params)]
+ * (kind AUX: the row holds [loss | label-head range]), slode_grad_payload_floats floats (34,204 = 137 KB at BASELINE config[1] / [3]
+ * against the 96,463 of [flat gradient | loss]).  One step on N ranks =
+ *   slode_grad_partial (fold, [encoder,] ODE / aux kernel, split-K products, pack)  ->  SUM all-reduce of `payload` (RCCL; the caller's,
+ *   torch.distributed.all_reduce in svi.py)  ->  slode_grad_apply (chain rule, final reduction, Adam) on every rank.
+ * Both calls must use the SAME workspace with no other step on it in between (the fold's w' / row sums stay there).  Folded encoder
+ * path only (dense [B,T,C] or [B,C,T] observations): otherwise SLODE_EINVAL, and the caller reduces the flat gradient of slode_svi_step
+ * instead.  Replaces, like slode_svi_step, `losses[i].step(**d)` of training_cvs.py:152 on each rank of a data-parallel job. */
+size_t slode_grad_payload_floats(const slode_shape* s, const slode_layout* lay, int kind);
+int slode_grad_partial(slode_handle h, const slode_shape* s, const slode_layout* lay, int kind, const float* params, const float* times,
+                       const float* stage_t, const slode_batch* batch, float* payload, void* workspace, size_t workspace_bytes, void* stream);
+/* obs_strides: the batch's observation strides (they select the fold's column order).  loss_out[0] = the payload's loss slot (the global
+ * -ELBO after the all-reduce); grads[0, n_params) written; adam != NULL: update applied by the same launch. */
+int slode_grad_apply(slode_handle h, const slode_shape* s, const slode_layout* lay, int kind, float* params, const int64_t obs_strides[3],
+                     const float* payload, float* loss_out, float* grads, void* workspace, size_t workspace_bytes, const slode_adam* adam,
+                     void* stream);
+
+/* The handle's noise generator (replaces torch's global generator behind `rsample`): Philox-4x32-10 keyed by `seed`; the draw of
+ * (drawing call n, trajectory b, latent index l) is word l & 3 -> Box-Muller of block [b + first_trajectory | l >> 2 | n] -- stateless,
+ * so results do not depend on the grid or on how a global batch is sharded (data parallel: every rank passes the global index of its
+ * shard's first trajectory).  slode_rng_seed resets the call counter n to 0; every step / evaluate call with eps == NULL uses the
+ * current n and then increments it.  slode_rng_get reads (seed, first_trajectory, n) -- checkpoint / resume. */
+int slode_rng_seed(slode_handle h, uint64_t seed, int64_t first_trajectory);
+int slode_rng_set_counter(slode_handle h, uint64_t n);
+int slode_rng_get(slode_handle h, uint64_t* seed, int64_t* first_trajectory, uint64_t* n);
+/* The noise drawing call `n` would use for B trajectories of latent dim L, without running a step: eps_out[B, L] (NULL to skip) and the
+ * raw Philox words raw_out[B, ceil(L / 4), 4] (uint32; NULL to skip).  Tests, and callers that want the explicit-eps path to reproduce
+ * an in-kernel draw. */
+int slode_rng_normal(slode_handle h, uint64_t n, int32_t B, int32_t L, float* eps_out, uint32_t* raw_out, void* stream);
+
+/* torch.normal(loc, scale) of the eval-side callers (recon / classifier / pred_inputs: models/mechanistic_cvs.py:285, 300, 309):
+ * z_out[B, L] = loc + scale * eps with eps from the handle's generator (one drawing call: uses the current counter n, then n + 1). */
+int slode_sample_normal(slode_handle h, int32_t B, int32_t L, const float* loc, const float* scale, float* z_out, void* stream);
 
 /* torch.optim.Adam step as pyro.optim.Adam applies it per parameter (training_cvs.py:226-227): in-place on flat
  * buffers.  step = 1-based step count. */

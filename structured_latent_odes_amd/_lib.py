@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SLODE_LIB_PATH") or os.path.join(_HERE, "libslode.so")  # env override: diagnostics only
 
-MAX_GROUPS, MAX_HEADS, MAX_AUX = 4, 3, 4
+MAX_GROUPS, MAX_HEADS, MAX_AUX, MAX_LABELS = 4, 3, 4, 4
 AUX_KINDS = {"sigmoid": 0, "softmax": 1, "expexp": 2}
 EULER, MIDPOINT, RK4, DOPRI5 = 0, 1, 2, 3
 ALD, GAUSS = 0, 1
@@ -40,11 +40,27 @@ class Layout(C.Structure):
         ("cstd", C.c_int32), ("ode_end", C.c_int32), ("n_params", C.c_int32)]
 
 
+class Batch(C.Structure):
+    """slode_batch: one minibatch as the loader yields it -- observations with strides, the label tensors one by one, optional eps."""
+    _fields_ = [("obs", C.c_void_p), ("obs_strides", C.c_int64 * 3), ("n_labels", C.c_int32), ("label_width", C.c_int32 * MAX_LABELS),
+                ("labels", C.c_void_p * MAX_LABELS), ("eps", C.c_void_p)]
+
+
+class AdamArgs(C.Structure):
+    """slode_adam"""
+    _fields_ = [("n_total", C.c_int64), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("lr", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int64)]
+
+
+SVI_MAIN, SVI_AUX = 0, 1
+
 EXPORTS = ["slode_version", "slode_create", "slode_destroy", "slode_last_error", "slode_layout_init",
            "slode_num_stage_times", "slode_workspace_bytes", "slode_stage_times", "slode_encoder_conv_fwd",
            "slode_encoder_conv_bwd", "slode_ode_solve_fwd", "slode_ode_solve_bwd", "slode_decode_heads",
            "slode_elbo_step", "slode_adam_step", "slode_profile_enable", "slode_profile_read", "slode_dynamics_eval", "slode_elbo_adam_step", "slode_aux_step", "slode_adam_region",
-           "slode_initialize_state", "slode_prior_nets", "slode_label_heads", "slode_dopri5_step_counts", "slode_decode_heads_bwd"]
+           "slode_initialize_state", "slode_prior_nets", "slode_label_heads", "slode_dopri5_step_counts", "slode_decode_heads_bwd",
+           "slode_svi_step", "slode_rng_seed", "slode_rng_set_counter", "slode_rng_get", "slode_rng_normal", "slode_sample_normal",
+           "slode_grad_payload_floats", "slode_grad_partial", "slode_grad_apply"]
 
 _lib = None
 
@@ -97,6 +113,16 @@ def load():
     lib.slode_dopri5_step_counts.argtypes = [VP, P(Shape), P(Layout), VP, C.c_size_t, VP, VP]
     lib.slode_profile_enable.argtypes = [VP, C.c_int]
     lib.slode_profile_read.argtypes = [VP, C.c_int, P(C.c_char_p), P(C.c_float)]
+    lib.slode_svi_step.argtypes = [VP, P(Shape), P(Layout), C.c_int, VP, VP, VP, P(Batch), VP, VP, VP, C.c_size_t, P(AdamArgs), VP]
+    lib.slode_rng_seed.argtypes = [VP, C.c_uint64, C.c_int64]
+    lib.slode_rng_set_counter.argtypes = [VP, C.c_uint64]
+    lib.slode_rng_get.argtypes = [VP, P(C.c_uint64), P(C.c_int64), P(C.c_uint64)]
+    lib.slode_rng_normal.argtypes = [VP, C.c_uint64, C.c_int32, C.c_int32, VP, VP, VP]
+    lib.slode_sample_normal.argtypes = [VP, C.c_int32, C.c_int32, VP, VP, VP, VP]
+    lib.slode_grad_payload_floats.argtypes = [P(Shape), P(Layout), C.c_int]
+    lib.slode_grad_payload_floats.restype = C.c_size_t
+    lib.slode_grad_partial.argtypes = [VP, P(Shape), P(Layout), C.c_int, VP, VP, VP, P(Batch), VP, VP, C.c_size_t, VP]
+    lib.slode_grad_apply.argtypes = [VP, P(Shape), P(Layout), C.c_int, VP, I64P, VP, VP, VP, VP, C.c_size_t, P(AdamArgs), VP]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here == the ABI in include/slode.h is not fully exported
     _lib = lib

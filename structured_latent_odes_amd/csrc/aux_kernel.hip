@@ -22,9 +22,12 @@ struct AuxK {
   // fused encoder-head backward (folded encoder path): see ode_elbo_kernel
   const float *enc_hid, *enc_zloc_w, *enc_zls_w;
   float *g_pre, *glat;
+  RngK rng;       // on: the group latents' noise is drawn here (Philox, slode_common.h)
+  LabelSrc lab;   // n > 0: label columns from separate tensors
 };
 
-constexpr int AUX_ZMAX = 16;   // latent dims of one label head (slode_api.hip: check_shape)
+// AUX_ZMAX (template parameter): latent dims one label head may read -- the lane's row of the hidden layer and its gradient live in
+// registers: 16 for every reference config (z_*_dim 1..10), 64 (= SLODE_MAX_L) for wider heads (slode_launch_aux picks)
 constexpr int AUX_QMAX = 8;    // label columns of one head
 
 // Half-wave (32 lanes) = one label head, lane j = hidden unit j; a workgroup = the n_aux heads of one trajectory at a time.  Everything a
@@ -34,6 +37,7 @@ constexpr int AUX_QMAX = 8;    // label columns of one head
 // once, at the end.  The only workgroup barriers are the two around the encoder-head backward (it needs every head's latent gradient).
 __device__ __forceinline__ float half_sum(float v) { return half_wave_sum(v); }   // (DPP + v_permlane16_swap: slode_common.h)
 
+template <int AUX_ZMAX>
 __global__ void __launch_bounds__(128) aux_kernel(const AuxK k) {
   __shared__ float s_z[SLODE_MAX_AUX][AUX_ZMAX];
   __shared__ float s_gl[SLODE_MAX_L], s_gs[SLODE_MAX_L];   // dLoss/dloc, dLoss/dscale * scale of the current trajectory
@@ -62,8 +66,8 @@ __global__ void __launch_bounds__(128) aux_kernel(const AuxK k) {
   float loss_acc = 0.f;
   if (tid < L) { s_gl[tid] = 0.f; s_gs[tid] = 0.f; }   // latent dims outside every head keep a zero gradient
   // encoder head weights of hidden unit mm = tid (fused encoder-head backward): in registers from the start when the latent is short
-  constexpr int ZW = 16;
-  const bool zw_regs = k.g_pre != nullptr && L <= ZW;
+  constexpr int ZW = AUX_ZMAX > 16 ? 1 : 16;   // (the wide instantiation spends its registers on the heads' rows: weights from memory)
+  const bool zw_regs = AUX_ZMAX <= 16 && k.g_pre != nullptr && L <= ZW;
   float zw0[ZW], zw1[ZW];
 #pragma unroll
   for (int l = 0; l < ZW; ++l) {
@@ -79,13 +83,13 @@ __global__ void __launch_bounds__(128) aux_kernel(const AuxK k) {
     if (head_on && j < zd) {
       const long long i = (long long)b * L + ax.z_off + j;
       const float loc = k.loc[i];
-      sc = k.scale[i]; e = k.eps[i];
+      sc = k.scale[i]; e = slode_eps_at(k.rng, k.eps, b, L, ax.z_off + j);
       const float z = fmaf(sc, e, loc);
       const float zq = (z - loc) / sc;
       loss_acc += logf(sc) + 0.91893853320467274178f + 0.5f * zq * zq;
       s_z[hd][j] = z;
     }
-    float yv = (head_on && j < ud) ? k.u[(long long)b * k.nu + ax.u_off + j] : 0.f;   // lane q holds label column q
+    float yv = (head_on && j < ud) ? slode_label_at(k.lab, k.u, k.nu, b, ax.u_off + j) : 0.f;   // lane q holds label column q
     const float enc_hv = (k.g_pre != nullptr && k.backward && tid < k.Hc) ? k.enc_hid[(long long)b * k.Hc + tid] : 0.f;   // in flight until the end
     // ---- hidden layer (Softplus) ----
     float pre = b1v;
@@ -245,8 +249,12 @@ hipError_t slode_launch_aux(const AuxLaunch& a, hipStream_t stream) {
   k.row_floats = 1 + (a.compact ? lay.cstd - lay.aux_w1[0] : lay.ode_end - lay.ode_begin);
   k.loc = a.loc; k.scale = a.scale; k.eps = a.eps; k.u = a.u;
   k.g_loc = a.g_loc; k.g_scale = a.g_scale; k.slabs = a.slabs; k.slab_stride = a.slab_stride; k.backward = a.backward;
+  k.rng = a.rng; k.lab = a.lab;
   k.enc_hid = a.enc_hid; k.enc_zloc_w = a.params + lay.zloc_w; k.enc_zls_w = a.params + lay.zls_w; k.g_pre = a.g_pre; k.glat = a.glat;
   const int nthreads = s.n_aux <= 2 ? 64 : 128;
-  SLODE_LAUNCH("aux", aux_kernel, dim3(a.grid), dim3(nthreads), 0, stream, k);
+  int zmax = 0;
+  for (int q = 0; q < s.n_aux; ++q) zmax = s.aux[q].z_dim > zmax ? s.aux[q].z_dim : zmax;
+  if (zmax <= 16) SLODE_LAUNCH("aux", aux_kernel<16>, dim3(a.grid), dim3(nthreads), 0, stream, k);
+  else SLODE_LAUNCH("aux", aux_kernel<SLODE_MAX_L>, dim3(a.grid), dim3(nthreads), 0, stream, k);
   return hipGetLastError();
 }

@@ -44,6 +44,8 @@ struct DpK {
   int kmax;
   float rtol, atol;
   int max_steps;
+  RngK rng;          // on: eps is drawn here (Philox, slode_common.h) and written to eps_out for the scorer and the reverse sweep
+  float* eps_out;
 };
 
 // reduce-scatter over the 8 lanes of a trajectory: lane g returns the group's sum of v[g] (halving butterfly, 4 + 2 + 1 shuffles)
@@ -338,7 +340,12 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
     const long long i = bb * L + l;
     float zl = 0.f;
     if (live) {
-      zl = k.z ? k.z[i] : fmaf(k.scale[i], k.eps[i], k.loc[i]);
+      if (k.z) zl = k.z[i];
+      else {
+        const float e = slode_eps_at(k.rng, k.eps, bb, L, l);
+        if (k.rng.on && k.eps_out) k.eps_out[i] = e;
+        zl = fmaf(k.scale[i], e, k.loc[i]);
+      }
       if (k.z_out) k.z_out[i] = zl;
     }
     s_z[slot * L + l] = zl;
@@ -974,7 +981,9 @@ hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, co
   DpK k;
   k.B = s.B; k.T = s.T; k.L = s.L; k.times = times; k.z = z; k.x = x;
   k.loc = k.scale = k.eps = nullptr; k.z_out = nullptr; k.rec = nullptr; k.nrec = nullptr; k.kmax = 0;
-  if (rec) { k.loc = rec->loc; k.scale = rec->scale; k.eps = rec->eps; k.z_out = rec->z_out; k.rec = rec->rec; k.nrec = rec->nrec; k.kmax = rec->kmax; }
+  k.rng = RngK{}; k.eps_out = nullptr;
+  if (rec) { k.loc = rec->loc; k.scale = rec->scale; k.eps = rec->eps; k.z_out = rec->z_out; k.rec = rec->rec; k.nrec = rec->nrec; k.kmax = rec->kmax;
+             k.rng = rec->rng; k.eps_out = rec->eps_out; }
   k.w1 = p + lay.init_w1; k.b1 = p + lay.init_b1; k.w2 = p + lay.init_w2; k.b2 = p + lay.init_b2;
   k.wh = p + lay.dyn_wh; k.bh = p + lay.dyn_bh; k.wg = p + lay.dyn_wg; k.bg = p + lay.dyn_bg; k.wd = p + lay.dyn_wd; k.bd = p + lay.dyn_bd;
   k.rtol = s.rtol > 0.f ? s.rtol : 1e-7f;

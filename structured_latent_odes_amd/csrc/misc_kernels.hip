@@ -330,6 +330,60 @@ hipError_t slode_launch_dynamics_eval(const slode_shape& s, const slode_layout& 
   return hipGetLastError();
 }
 
+// The noise of one drawing call, materialised (slode_rng_normal): the same device function the step kernels call
+__global__ void rng_fill_kernel(const RngK r, int B, int L, float* __restrict__ eps_out, unsigned int* __restrict__ raw,
+                                const float* __restrict__ loc, const float* __restrict__ scale) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nb = (L + 3) >> 2;
+  if (eps_out && i < (long long)B * L) {
+    const long long b = i / L;
+    const float e = slode_rng_normal(r, b, (int)(i - b * L));
+    eps_out[i] = loc ? fmaf(scale[i], e, loc[i]) : e;   // (loc given: the sample z = loc + scale * eps, torch.normal(loc, scale))
+  }
+  if (raw && i < (long long)B * nb) {
+    const long long b = i / nb;
+    unsigned int x[4];
+    philox4x32_10((unsigned int)(b + r.b0), (unsigned int)(i - b * nb), r.c2, r.c3, r.k0, r.k1, x);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) raw[4 * i + q] = x[q];
+  }
+}
+hipError_t slode_launch_rng_fill(const RngK& r, int B, int L, float* eps_out, unsigned int* raw, hipStream_t stream, const float* loc,
+                                 const float* scale) {
+  const long long n = (long long)B * L;
+  hipLaunchKernelGGL(rng_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, r, B, L, eps_out, raw, loc, scale);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) pack_payload_kernel(const float* __restrict__ gslabs, const float* __restrict__ gslabs_loc,
+                                                           const float* __restrict__ gslabs_ls, int gsplit, int n_g, int n_h,
+                                                           const float* __restrict__ ode_part, int ode_stride, int ode_n, int ode_count,
+                                                           float* __restrict__ out, int o_loc, int o_ls, int o_ode, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  float v = 0.f;
+  if (i < n_g) v = strided_sum(gslabs + i, n_g, gsplit);
+  else if (i >= o_loc && i < o_loc + n_h) v = strided_sum(gslabs_loc + (i - o_loc), n_h, gsplit);
+  else if (i >= o_ls && i < o_ls + n_h) v = strided_sum(gslabs_ls + (i - o_ls), n_h, gsplit);
+  else if (i >= o_ode && i < o_ode + ode_count) {
+    if (i == o_ode) {   // the loss: the same double-precision fixed-order sum the tail uses (tail_loss)
+      double acc = 0.0;
+      for (int w = 0; w < ode_n; ++w) acc += (double)ode_part[(long long)w * ode_stride];
+      v = (float)acc;
+    } else {
+      v = strided_sum(ode_part + (i - o_ode), ode_stride, ode_n);
+    }
+  }
+  out[i] = v;
+}
+hipError_t slode_launch_pack_payload(const float* gslabs, const float* gslabs_loc, const float* gslabs_ls, int gsplit, int Hc, int CT, int L,
+                                     const float* ode_part, int ode_stride, int ode_n, int ode_count, float* out, int o_loc, int o_ls, int o_ode,
+                                     int total, hipStream_t stream) {
+  SLODE_LAUNCH("pack_payload", pack_payload_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, gslabs, gslabs_loc, gslabs_ls, gsplit,
+               Hc * (CT + 1), L * (Hc + 1), ode_part, ode_stride, ode_n, ode_count, out, o_loc, o_ls, o_ode, total);
+  return hipGetLastError();
+}
+
 hipError_t slode_launch_adam_k(int64_t n, const float* g, const AdamHost& a, hipStream_t stream) {
   SLODE_LAUNCH("adam", adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (long long)n, g, make_adamk(&a));
   return hipGetLastError();

@@ -108,6 +108,8 @@ struct OdeK {
   int Hc;
   // gradient-segment elements no phase of this launch owns (zero gradient: written as zeros once per workgroup), relative to ode_begin
   int nz, zlo[8], zhi[8];
+  RngK rng;       // on: the guide's noise is drawn here (Philox, slode_common.h) instead of read from eps
+  LabelSrc lab;   // n > 0: label columns from the loader's separate tensors instead of the dense u matrix
 };
 
 struct LdsMap {  // offsets in floats
@@ -651,7 +653,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   // top of every later trajectory (the block is overwritten from P0c on)
   auto stage_cold = [&]() {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), NW = NT >> 6, lane = tid & 63;
-    const int n1 = k.o_b1, n2 = H * (1 + L), n3 = k.npar - k.o_aux_w1[0];
+    const int n1 = k.o_b1, n2 = H * (1 + L), n3 = k.n_aux > 0 ? k.npar - k.o_aux_w1[0] : 0;   // (no label heads in this launch: nothing to stage)
     const float* g1 = pl_pseg;
     const float* g2 = pl_pseg + k.o_wh;
     const float* g3 = pl_pseg + k.o_aux_w1[0];
@@ -707,9 +709,9 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
       if (!ENCF) v_l0 = pl_loc[(long long)b_first * L + lc];     // (pure solve: z_in)
       if (pl_scale != nullptr) {
         if (!ENCF) v_l1 = pl_scale[(long long)b_first * L + lc];
-        v_l2 = pl_eps[(long long)b_first * L + lc];
+        v_l2 = k.rng.on ? slode_rng_normal(k.rng, b_first, lc) : pl_eps[(long long)b_first * L + lc];
       }
-      if (pl_u != nullptr) v_u = pl_u[(long long)b_first * k.nu + min(tid, k.nu - 1)];
+      if (pl_u != nullptr) v_u = k.lab.n ? slode_label_at(k.lab, pl_u, k.nu, b_first, min(tid, k.nu - 1)) : pl_u[(long long)b_first * k.nu + min(tid, k.nu - 1)];
     }
     // ENCF: the encoder forward of this trajectory (see the template comment).  Everything it reads from global memory is requested
     // here, beside the set-up loads; its results are finished behind the set-up barrier.
@@ -958,7 +960,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
       if (on) {
         float pre = cp0[k.o_aux_b1[hd] - sh_aux + j];
         if (COLDG && !COLDB) {
-          float rw[16];   // (a head reads at most 16 latent dims: check_shape)
+          float rw[16];   // (a head reads at most 16 latent dims: slode_launch_ode dispatches this instantiation only then)
 #pragma unroll
           for (int l = 0; l < 16; ++l) rw[l] = cpar[k.o_aux_w1[hd] + j * ax.z_dim + min(l, ax.z_dim - 1)];
 #pragma unroll
@@ -1919,13 +1921,13 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
       const int bn = b + vgrid, t1 = tid - 64;
       if (t1 < L) {
         if (k.loc != nullptr) {
-          const float a0 = k.loc[(long long)bn * L + t1], a1 = k.scale[(long long)bn * L + t1], a2 = k.eps[(long long)bn * L + t1];
+          const float a0 = k.loc[(long long)bn * L + t1], a1 = k.scale[(long long)bn * L + t1], a2 = slode_eps_at(k.rng, k.eps, bn, L, t1);
           s_pf[t1] = a0; s_pf[pad4(L) + t1] = a1; s_pf[2 * pad4(L) + t1] = a2;
         } else {
           s_pf[t1] = k.z_in[(long long)bn * L + t1];
         }
       }
-      if (k.u != nullptr && t1 < k.nu) s_uu[t1] = k.u[(long long)bn * k.nu + t1];
+      if (k.u != nullptr && t1 < k.nu) s_uu[t1] = slode_label_at(k.lab, k.u, k.nu, bn, t1);
     }
     STAMP(10);
     if (ONE) break;
@@ -2056,6 +2058,9 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   k.x_ext = a.x_ext; k.gx_out = a.gx_out; k.ext_skip = (a.x_ext && a.ext_skip) ? 1 : 0;
   k.enc_zloc_w = p + lay.zloc_w; k.enc_zls_w = p + lay.zls_w; k.enc_zloc_b = p + lay.zloc_b; k.enc_zls_b = p + lay.zls_b;
   k.enc_weff = a.enc_weff; k.enc_beff = a.enc_beff; k.enc_hid_out = a.enc_hid_out;
+  k.rng = a.rng; k.lab = a.lab;
+  if (k.lab.n > 0 && !k.u) k.u = k.lab.p[0];   // (non-null = "this launch has labels"; the reads go through the accessor)
+  if (k.rng.on && !k.eps) k.eps = k.loc;       // (never dereferenced: a valid address for the preloaded argument)
 
   const int nthreads = slode_ode_threads(s);
   const bool bwd = a.backward != 0;
@@ -2097,8 +2102,17 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   // which launches take a long-latent shape-specialised instantiation (cold parameters in global memory, ode_cold_global) -- decided
   // here, ONCE, for the LDS size and for the dispatch below
   const bool shape_c2 = s.H == 25 && s.S == 8 && s.T == 100 && s.C == 4 && s.L == 50 && k.Q == 3;
-  const bool static_scorer = a.x_ext && !a.force_generic && a.alg == 0 && !ra && shape_c2 && s.method == SLODE_EULER && (!bwd || one);
-  const bool static_c2 = !a.x_ext && !a.force_generic && a.alg == 0 && shape_c2 && s.method == SLODE_RK4;
+  bool aux16 = true;   // the scorer's cold-parameter path keeps a label head's weight row in 16 registers
+  for (int q = 0; q < s.n_aux; ++q) aux16 = aux16 && s.aux[q].z_dim <= 16;
+  const bool static_scorer = a.x_ext && !a.force_generic && a.alg == 0 && !ra && shape_c2 && aux16 && s.method == SLODE_EULER && (!bwd || one);
+  bool static_c2 = !a.x_ext && !a.force_generic && a.alg == 0 && shape_c2 && s.method == SLODE_RK4;
+  if (static_c2) {
+    // its cold parameter ranges [priors | W_1], W_z and the label heads are staged in the idle work block A | x | lam | st during P0
+    // (COLDB): they must fit (they do for the reference's proc config: 4713 of 4768 floats); another split of the same dims may not
+    const LdsMap mc = lds_map(s.T, s.S, s.H, s.C, s.L, k.Q, k.nt, ode_hot_floats(s.S, s.H), nthreads, k.n_aux_lds, one);
+    const int cold = k.o_b1 + s.H * (1 + s.L) + (k.n_aux > 0 ? k.npar - k.o_aux_w1[0] : 0);
+    if (cold > 3 * mc.ax + mc.stn || k.o_b1 < 0) static_c2 = false;
+  }
   const int npar_lds = (static_scorer || static_c2) ? ode_hot_floats(s.S, s.H) : k.npar;
   const size_t lds = sizeof(float) * (size_t)lds_map(s.T, s.S, s.H, s.C, s.L, k.Q, k.nt, npar_lds, nthreads, k.n_aux_lds, one).total;
   {

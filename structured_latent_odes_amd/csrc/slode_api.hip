@@ -68,11 +68,6 @@ static const char* check_shape(const slode_shape* s) {
     if (x.kind < SLODE_AUX_SIGMOID || x.kind > SLODE_AUX_EXPEXP) return "unknown aux head kind";
     if (x.z_off < 0 || x.z_dim < 1 || x.z_off + x.z_dim > s->L) return "aux head latent range outside [0, L)";
     if (x.u_off < 0 || x.u_dim < 1 || x.u_dim > 8 || x.u_off + x.u_dim > s->n_u) return "aux head label range outside [0, n_u) or wider than 8";
-    if (x.z_dim > 16) return "aux head reads more than 16 latent dims";
-    for (int a2 = 0; a2 < a; ++a2) {
-      const slode_aux& o = s->aux[a2];
-      if (x.z_off < o.z_off + o.z_dim && o.z_off < x.z_off + x.z_dim) return "aux heads read overlapping latent ranges";
-    }
   }
   if (s->grad_mode != SLODE_GRAD_EXACT && s->grad_mode != SLODE_GRAD_REFERENCE_ADJOINT) return "grad_mode must be SLODE_GRAD_EXACT or SLODE_GRAD_REFERENCE_ADJOINT";
   return nullptr;
@@ -103,6 +98,7 @@ int slode_create(slode_handle* out, int device_id) {
   c->err[0] = 0;
   c->profile = 0; c->ev_ready = 0; c->clk.n = 0;
   c->adam_lo2 = c->adam_hi2 = 0; c->adam_delta2 = 0;
+  c->rng_seed = 0; c->rng_counter = 0; c->rng_b0 = 0;
   // diagnostics and test hooks: the environment is read here, once per handle, never at launch time
   c->no_fold = getenv("SLODE_NO_FOLD") != nullptr;   // force the layer-by-layer encoder kernels
   c->ode_loop = getenv("SLODE_ODE_LOOP") != nullptr;
@@ -192,7 +188,7 @@ struct Workspace {
   float *weff, *rowsum, *wprime, *beff, *gslabs, *conv_slabs, *glat, *gslabs2, *gslabs3;  // folded encoder path
   unsigned int* counter;
   // dopri5 training: solution, dLoss/dx, external latent gradient, latent sample, step records
-  float *dp_x, *dp_gx, *dp_gz, *dp_z, *dp_rec, *dp_snap;
+  float *dp_x, *dp_gx, *dp_gz, *dp_z, *dp_rec, *dp_snap, *dp_eps;
   float* sigtab;   // [4][C*T] likelihood-scale table of the step (OdeLaunch::sigtab)
   int* dp_nrec;
   int dp_kmax, dp_rows;
@@ -217,6 +213,15 @@ static int ode_grid_for(slode_handle h, const slode_shape& s) {
   else if (h && h->ode_grid_cap > 0 && g > h->ode_grid_cap) g = h->ode_grid_cap;
   if (g > s.B) g = s.B;
   return (int)g;
+}
+
+// the Philox key / counter words of drawing call n on this handle (slode_common.h: RngK)
+static RngK rng_of(const slode_ctx* h, uint64_t n) {
+  RngK r{};
+  r.k0 = (unsigned int)h->rng_seed; r.k1 = (unsigned int)(h->rng_seed >> 32);
+  r.c2 = (unsigned int)n; r.c3 = (unsigned int)(n >> 32);
+  r.b0 = h->rng_b0; r.on = 1;
+  return r;
 }
 
 static size_t align_up(size_t v) { return (v + 63) & ~(size_t)63; }  // in floats: 256-byte alignment
@@ -276,9 +281,39 @@ static Workspace carve(slode_handle h, const slode_shape& s_in, const slode_layo
     w.dp_nrec = reinterpret_cast<int*>(take((size_t)s.B));
     w.dp_rec = take((size_t)w.dp_kmax * s.B * (s.S + 2));
     w.dp_snap = take((size_t)s.B * s.H * 4 * s.S);   // running sums parked at the hidden units' switching times (dopri5_kernel.hip)
+    w.dp_eps = take((size_t)s.B * s.L);              // the noise the forward kernel drew (eps == NULL), for the scorer and the reverse sweep
   }
   w.bytes = o * sizeof(float);
   return w;
+}
+
+// Data-parallel payload (slode_grad_partial -> all-reduce -> slode_grad_apply): everything the chain rule + tail need of the batch,
+// [G = g_pre^T [X | 1]: Hc x (CT + 1)] [glat_loc^T [hid | 1]: L x (Hc + 1)] [glat_ls^T [hid | 1]: L x (Hc + 1)] [loss | ODE-half row],
+// each piece starting on a 16-byte boundary.  The chain rule is linear in G, so reducing G over the ranks and chain-ruling once gives the
+// gradient of the global batch: 34 k floats instead of the 96 k of the flat gradient at the metric shape.
+struct PayloadMap { int g_loc, g_ls, ode, total; };
+static PayloadMap payload_map(const slode_shape& s, int part_floats) {
+  auto a4 = [](int v) { return (v + 3) & ~3; };
+  PayloadMap m;
+  m.g_loc = a4(s.Hc * (s.C * s.T + 1));
+  m.g_ls = m.g_loc + a4(s.L * (s.Hc + 1));
+  m.ode = m.g_ls + a4(s.L * (s.Hc + 1));
+  m.total = m.ode + a4(part_floats + 1);
+  return m;
+}
+
+static int batch_labels(slode_handle h, const slode_shape* s, const slode_batch* batch, LabelSrc* lab) {
+  if (batch->n_labels < 0 || batch->n_labels > SLODE_MAX_LABELS) return fail(h, SLODE_EINVAL, "n_labels out of range [0, %d]", SLODE_MAX_LABELS);
+  lab->n = batch->n_labels;
+  int cols = 0;
+  for (int i = 0; i < batch->n_labels; ++i) {
+    if (!batch->labels[i] || batch->label_width[i] < 1) return fail(h, SLODE_EINVAL, "label tensor %d is NULL or has width < 1", i);
+    lab->p[i] = batch->labels[i]; lab->off[i] = cols; cols += batch->label_width[i];
+  }
+  for (int i = batch->n_labels; i <= SLODE_MAX_LABELS; ++i) lab->off[i] = cols;
+  if (batch->n_labels > 0 && cols != s->n_u)
+    return fail(h, SLODE_EINVAL, "the label tensors have %d columns in all, the shape's n_u is %d", cols, s->n_u);
+  return SLODE_OK;
 }
 
 static const char* check_common(slode_handle h, const slode_shape* s, const slode_layout* lay, const void* params) {
@@ -409,13 +444,36 @@ struct AdamArgs { float *p, *m, *v; float lr, b1, b2, eps; int64_t step, n; };
 static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, const float* times,
                           const float* stage_t, const float* obs, const int64_t obs_strides[3], const float* u, const float* eps,
                           float* loss_out, float* grads, float* x_out, float* z_out, void* workspace, size_t workspace_bytes,
-                          void* stream, const AdamArgs* adam, int aux_mode = 0) {
+                          void* stream, const AdamArgs* adam, int aux_mode = 0, const LabelSrc* labels = nullptr, int phase = 0,
+                          float* payload = nullptr) {
+  // phase 0: the whole step.  Data parallel with the small payload (slode_grad_partial / slode_grad_apply): phase 1 = everything up to the
+  // split-K products, then the partials packed into `payload` = [G | G_loc | G_ls | loss | ODE-half row]; phase 2 = chain rule + tail
+  // (+ Adam) from the (all-reduced) payload.
   const char* why = check_common(h, s, lay, params);
   if (why) return fail(h, SLODE_EINVAL, "%s", why);
-  if ((!aux_mode && (!times || !stage_t)) || !obs || !obs_strides || !eps || !loss_out || !workspace)
+  if (phase == 2) {
+    if (!obs_strides || !payload || !grads || !workspace) return fail(h, SLODE_EINVAL, "a required pointer is NULL");
+  } else if ((!aux_mode && (!times || !stage_t)) || !obs || !obs_strides || (!loss_out && phase == 0) || !workspace || (phase == 1 && !payload))
     return fail(h, SLODE_EINVAL, "a required pointer is NULL");
-  if (aux_mode && (s->n_aux < 1 || !u)) return fail(h, SLODE_EINVAL, "the auxiliary loss needs label heads (n_aux >= 1) and labels u");
-  if (s->n_groups > 0 && !u) return fail(h, SLODE_EINVAL, "u is NULL but the shape has conditional prior groups");
+  // eps == NULL: this call draws the guide's noise inside its kernels -- call number rng_counter of the handle's Philox stream
+  RngK rng{};
+  if (!eps && phase != 2) rng = rng_of(h, h->rng_counter++);
+  LabelSrc lab{};
+  if (labels) lab = *labels;
+  if (lab.n > 0) u = u ? u : lab.p[0];   // (non-null = "labels present"; the kernels read through the accessor)
+  if (aux_mode && (s->n_aux < 1 || (!u && phase != 2))) return fail(h, SLODE_EINVAL, "the auxiliary loss needs label heads (n_aux >= 1) and labels u");
+  if (aux_mode) {
+    // aux_kernel only: every head owns the latent-gradient slots of the dims it reads (one writer per slot).  The reference's heads read
+    // disjoint groups (z_iext / z_rtpr, z_aR / z_aS / z_C12 / z_C6, ...); the main step, the solves and the eval-side entry points
+    // have no such limit and are not affected.  Heads wider than 16 dims take the kernel's wide instantiation.
+    for (int a = 0; a < s->n_aux; ++a)
+      for (int a2 = 0; a2 < a; ++a2) {
+        const slode_aux &x = s->aux[a], &o = s->aux[a2];
+        if (x.z_off < o.z_off + o.z_dim && o.z_off < x.z_off + x.z_dim)
+          return fail(h, SLODE_EINVAL, "slode_aux_step: label heads %d and %d read overlapping latent ranges", a2, a);
+      }
+  }
+  if (s->n_groups > 0 && !u && phase != 2) return fail(h, SLODE_EINVAL, "u is NULL but the shape has conditional prior groups");
   const bool dp5 = !aux_mode && s->method == SLODE_DOPRI5;
   if (dp5 && !(s->H == 25 && (s->S == 5 || s->S == 8)))
     return fail(h, SLODE_EINVAL, "dopri5 kernels are instantiated for (S,H) in {(5,25),(8,25)}");
@@ -424,7 +482,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
   Workspace w = carve(h, *s, *lay, workspace);
   if (workspace_bytes < w.bytes) return fail(h, SLODE_ENOSPC, "workspace %zu B < required %zu B", workspace_bytes, w.bytes);
   hipStream_t st = (hipStream_t)stream;
-  const bool bwd = grads != nullptr;
+  const bool bwd = grads != nullptr || phase == 1;
   ClockScope clock_scope(h, true);
 
   // Folded encoder (encoder_fused.hip) when every trajectory's C*T observations are one dense block; else layer by layer.
@@ -435,7 +493,14 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
   FoldLaunch fl{};
   hipError_t e;
   bool enc_fused = false;
-  if (folded) {
+  if (phase != 0 && !folded)
+    return fail(h, SLODE_EINVAL, "slode_grad_partial / slode_grad_apply need the folded encoder path (dense [B,T,C] or [B,C,T] observations, C in {3,4})");
+  if (phase == 2) {   // no forward work: the fold launch of phase 1 left w' / rowsum / the zeroed arrival counters in this workspace
+    fl.s = *s; fl.lay = *lay; fl.params = params; fl.x = obs; fl.t_major = t_major ? 1 : 0;
+    fl.weff = w.weff; fl.rowsum = w.rowsum; fl.wprime = w.wprime; fl.beff = w.beff; fl.loc = w.loc; fl.scale = w.scale; fl.hid = w.hid;
+    fl.g_loc = w.g_loc; fl.g_scale = w.g_scale; fl.g_pre = w.g_pre; fl.small_slabs = w.small_slabs; fl.small_stride = w.small_stride;
+    fl.g_lin_w = grads + lay->lin_w; fl.conv_slabs = w.conv_slabs; fl.counter = w.counter;
+  } else if (folded) {
     fl.s = *s; fl.lay = *lay; fl.params = params; fl.x = obs; fl.t_major = t_major ? 1 : 0;
     fl.weff = w.weff; fl.rowsum = w.rowsum; fl.wprime = w.wprime; fl.beff = w.beff; fl.loc = w.loc; fl.scale = w.scale; fl.hid = w.hid;
     fl.g_loc = w.g_loc; fl.g_scale = w.g_scale; fl.g_pre = w.g_pre; fl.small_slabs = w.small_slabs; fl.small_stride = w.small_stride;
@@ -458,11 +523,21 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
   int n_slabs = w.ode_grid;
   int part_lo = lay->ode_begin, part_hi = lay->n_params;   // flat range the slab rows carry (after the loss slot)
   int zr_rows = 0, zr_lo = 0, zr_hi = 0;                   // rows [0, zr_rows) carry nothing in slab columns [zr_lo, zr_hi) (dopri5 scorer)
-  if (aux_mode) {
+  if (phase == 2) {
+    if (aux_mode) { part_lo = lay->aux_w1[0]; part_hi = lay->cstd; }
+  } else if (aux_mode) {
     // one workgroup per trajectory up to 2,048 of them, then a loop; on the folded path the kernel also runs the encoder-head backward and
     // its slab rows carry only the label-head range (the fused tail below reduces exactly that)
     AuxLaunch al{*s, *lay, params, w.loc, w.scale, eps, u, w.g_loc, w.g_scale, w.ode_slabs, w.ode_stride,
                  w.ode_grid < 2048 ? w.ode_grid : 2048, bwd ? 1 : 0};
+    al.rng = rng; al.lab = lab;
+    // compact rows carry the flat range [aux_w1[0], cstd): every label-head tensor must lie inside it (a caller-made layout may not)
+    bool aux_contig = lay->aux_w1[0] <= lay->cstd;
+    for (int a = 0; a < s->n_aux; ++a) {
+      const int hi = s->aux[a].kind == SLODE_AUX_EXPEXP ? lay->aux_c[a] + 1 : lay->aux_b2[a] + s->aux[a].u_dim;
+      aux_contig = aux_contig && lay->aux_w1[a] >= lay->aux_w1[0] && hi <= lay->cstd;
+    }
+    if (bwd && folded && !aux_contig) return fail(h, SLODE_EINVAL, "slode_aux_step: the label heads must lie in [aux_w1[0], cstd) of the layout (slode_layout_init's order)");
     if (bwd && folded) {
       al.compact = 1; al.enc_hid = w.hid; al.g_pre = w.g_pre; al.glat = w.glat; al.g_loc = nullptr; al.g_scale = nullptr;
       part_lo = lay->aux_w1[0]; part_hi = lay->cstd;
@@ -476,11 +551,28 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     a.u = u; a.eps = eps; a.loc = w.loc; a.scale = w.scale; a.x_out = x_out; a.z_out = z_out;
     a.g_loc = w.g_loc; a.g_scale = w.g_scale; a.slabs = w.ode_slabs; a.slab_stride = w.ode_stride; a.grid = w.ode_grid;
     a.backward = bwd ? 1 : 0; a.with_ll = 1;
+    a.rng = rng; a.lab = lab;
     a.sigtab = folded ? w.sigtab : nullptr;   // written by the fold launch above
     a.force_loop = h->ode_loop; a.force_generic = h->ode_generic; a.alg = h->ode_alg; a.pack = h->ode_pack;
     if (bwd && folded) { a.enc_hid = w.hid; a.g_pre = w.g_pre; a.glat = w.glat; a.g_loc = nullptr; a.g_scale = nullptr; }
     if (enc_fused) { a.enc_fuse = 1; a.enc_weff = w.weff; a.enc_beff = w.beff; a.enc_hid_out = w.hid; }
-    if (dp5 && bwd && folded && w.ode_grid + w.dp_rows > 2 * SLODE_REDUCE_GROUPS) {
+    // ext_skip assumes slode_layout_init's order: the ten solver-side tensors tile [init_w1, dyn_bd + S) exactly and nothing else (prior
+    // nets, decoder heads, label heads, constant_std) lies inside; a caller-made layout that does not keeps the zeros written and read
+    bool solver_contig = lay->init_b1 == lay->init_w1 + s->H * s->L && lay->init_w2 == lay->init_b1 + s->H && lay->init_b2 == lay->init_w2 + s->S * s->H &&
+                         lay->dyn_wh == lay->init_b2 + s->S && lay->dyn_bh == lay->dyn_wh + s->H * (1 + s->L) && lay->dyn_wg == lay->dyn_bh + s->H &&
+                         lay->dyn_bg == lay->dyn_wg + s->S * s->H && lay->dyn_wd == lay->dyn_bg + s->S && lay->dyn_bd == lay->dyn_wd + s->S * s->H;
+    {
+      const int lo = lay->init_w1, hi = lay->dyn_bd + s->S;
+      auto inside = [&](int off) { return off >= lo && off < hi; };
+      for (int g = 0; g < s->n_groups; ++g)
+        solver_contig = solver_contig && !inside(lay->ploc_w[g]) && !inside(lay->ploc_b[g]) && !inside(lay->pls_w[g]) && !inside(lay->pls_b[g]);
+      for (int q = 0; q < (s->likelihood == SLODE_GAUSS ? 1 : 3); ++q) solver_contig = solver_contig && !inside(lay->head_w[q]);
+      for (int a2 = 0; a2 < s->n_aux; ++a2)
+        solver_contig = solver_contig && !inside(lay->aux_w1[a2]) && !inside(lay->aux_b1[a2]) && !inside(lay->aux_w2[a2]) && !inside(lay->aux_b2[a2]) &&
+                        (s->aux[a2].kind != SLODE_AUX_EXPEXP || (!inside(lay->aux_w3[a2]) && !inside(lay->aux_b3[a2]) && !inside(lay->aux_c[a2])));
+      solver_contig = solver_contig && !inside(lay->cstd);
+    }
+    if (dp5 && bwd && folded && solver_contig && w.ode_grid + w.dp_rows > 2 * SLODE_REDUCE_GROUPS) {
       // the scorer's rows carry nothing in the solver-side range [init net | dynamics] (the reverse sweep's rows do): the scorer does not
       // write those zeros and stage 1 of the fused tail (the only reader of the rows) does not read them
       a.ext_skip = 1;
@@ -492,6 +584,10 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
       // records: solver-side gradients as extra slab rows, the latent gradient through the solver added to g_loc / g_scale -> the
       // unfused encoder tail below
       DopriRec rc{w.loc, w.scale, eps, w.dp_z, bwd ? w.dp_rec : nullptr, w.dp_nrec, w.dp_kmax};
+      if (rng.on) {   // the forward kernel draws the noise once and materialises it: the scorer and the reverse sweep read the same values
+        rc.rng = rng; rc.eps_out = w.dp_eps;
+        a.rng = RngK{}; a.eps = w.dp_eps; eps = w.dp_eps;
+      }
       HIP_TRY(h, slode_launch_dopri5(*s, *lay, params, times, nullptr, w.dp_x, st, &rc));
       a.x_ext = w.dp_x;
       if (bwd) {
@@ -511,6 +607,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     }
   }
 
+  if (phase != 0 && !(bwd && folded)) return fail(h, SLODE_EINVAL, "the payload split needs a backward step on the folded encoder path");
   if (bwd && folded) {
     // Fused tail.  The ODE kernel (auxiliary step: the aux kernel; dopri5: its reverse sweep) has already run the encoder heads + tanh
     // backward (g_pre, glat): two launches remain --
@@ -522,14 +619,27 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     }
     const float* ode_part = nullptr;
     int ode_pn = 0;
-    HIP_TRY(h, slode_launch_gemm_tail(w.g_pre, obs, w.gslabs, s->Hc, (int)CT, w.glat, w.hid, w.gslabs2, w.gslabs3, s->L, s->B, w.gsplit,
-                                      w.ode_slabs, w.ode_stride, n_slabs, (part_hi - part_lo) + 1, w.ode_part, &ode_part, &ode_pn, st,
-                                      zr_rows, zr_lo, zr_hi));
+    const PayloadMap pm = payload_map(*s, part_hi - part_lo);
+    if (phase != 2)
+      HIP_TRY(h, slode_launch_gemm_tail(w.g_pre, obs, w.gslabs, s->Hc, (int)CT, w.glat, w.hid, w.gslabs2, w.gslabs3, s->L, s->B, w.gsplit,
+                                        w.ode_slabs, w.ode_stride, n_slabs, (part_hi - part_lo) + 1, w.ode_part, &ode_part, &ode_pn, st,
+                                        zr_rows, zr_lo, zr_hi));
+    if (phase == 1) {   // split-K partials and partial slab rows, summed in fixed order, into the contiguous payload
+      HIP_TRY(h, slode_launch_pack_payload(w.gslabs, w.gslabs2, w.gslabs3, w.gsplit, s->Hc, (int)CT, s->L, ode_part, w.ode_stride, ode_pn,
+                                           (part_hi - part_lo) + 1, payload, pm.g_loc, pm.g_ls, pm.ode, pm.total, st));
+      return SLODE_OK;
+    }
     TailK tl{};
     tl.gslabs = w.gslabs; tl.gslabs_loc = w.gslabs2; tl.gslabs_ls = w.gslabs3; tl.conv_slabs = w.conv_slabs;
     tl.ode_part = ode_part; tl.ode_stride = w.ode_stride; tl.ode_n = ode_pn; tl.loss_out = loss_out;
+    int gsplit_eff = w.gsplit;
+    if (phase == 2) {   // the (reduced) payload stands for ONE split / ONE partial row
+      fl.gslabs = payload; fl.n_gslabs = 1; gsplit_eff = 1;
+      tl.gslabs = payload; tl.gslabs_loc = payload + pm.g_loc; tl.gslabs_ls = payload + pm.g_ls;
+      tl.ode_part = payload + pm.ode; tl.ode_stride = 0; tl.ode_n = 1;
+    }
     tl.part_lo = part_lo; tl.part_hi = part_hi;
-    tl.gsplit = w.gsplit; tl.Hc = s->Hc; tl.L = s->L; tl.CT = (int)CT; tl.n_cv = s->F * s->C * s->K + s->F;
+    tl.gsplit = gsplit_eff; tl.Hc = s->Hc; tl.L = s->L; tl.CT = (int)CT; tl.n_cv = s->F * s->C * s->K + s->F;
     tl.conv_w = lay->conv_w; tl.lin_w = lay->lin_w; tl.lin_b = lay->lin_b; tl.zloc_w = lay->zloc_w; tl.zloc_b = lay->zloc_b;
     tl.zls_w = lay->zls_w; tl.zls_b = lay->zls_b; tl.ode_begin = lay->ode_begin; tl.n_params = lay->n_params;
     tl.n_total = (adam && adam->n > lay->n_params) ? (int)adam->n : lay->n_params;
@@ -582,6 +692,96 @@ int slode_aux_step(slode_handle h, const slode_shape* s, const slode_layout* lay
   const AdamArgs ad{params, exp_avg, exp_avg_sq, lr, beta1, beta2, adam_eps, step, n_total};
   return elbo_step_impl(h, s, lay, params, nullptr, nullptr, obs, obs_strides, u, eps, loss_out, grads, nullptr, nullptr, workspace,
                         workspace_bytes, stream, with_adam ? &ad : nullptr, 1);
+}
+
+int slode_svi_step(slode_handle h, const slode_shape* s, const slode_layout* lay, int kind, float* params, const float* times,
+                   const float* stage_t, const slode_batch* batch, float* loss_out, float* grads, void* workspace, size_t workspace_bytes,
+                   const slode_adam* adam, void* stream) {
+  if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
+  if (!s || !batch) return fail(h, SLODE_EINVAL, "shape / batch is NULL");
+  if (kind != SLODE_SVI_MAIN && kind != SLODE_SVI_AUX) return fail(h, SLODE_EINVAL, "kind must be SLODE_SVI_MAIN or SLODE_SVI_AUX");
+  LabelSrc lab{};
+  const int rc_lab = batch_labels(h, s, batch, &lab);
+  if (rc_lab != SLODE_OK) return rc_lab;
+  AdamArgs ad{};
+  if (adam) {
+    if (!grads || !adam->exp_avg || !adam->exp_avg_sq || adam->step < 1 || !lay || adam->n_total < lay->n_params)
+      return fail(h, SLODE_EINVAL, "slode_svi_step with Adam needs grads, both moments, step >= 1 and n_total >= layout n_params");
+    ad = AdamArgs{params, adam->exp_avg, adam->exp_avg_sq, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->step, adam->n_total};
+  }
+  return elbo_step_impl(h, s, lay, params, kind == SLODE_SVI_AUX ? nullptr : times, kind == SLODE_SVI_AUX ? nullptr : stage_t, batch->obs,
+                        batch->obs_strides, nullptr, batch->eps, loss_out, grads, nullptr, nullptr, workspace, workspace_bytes, stream,
+                        adam ? &ad : nullptr, kind == SLODE_SVI_AUX ? 1 : 0, batch->n_labels > 0 ? &lab : nullptr);
+}
+
+size_t slode_grad_payload_floats(const slode_shape* s, const slode_layout* lay, int kind) {
+  if (check_shape(s) || !lay) return 0;
+  const int part = kind == SLODE_SVI_AUX ? lay->cstd - lay->aux_w1[0] : lay->n_params - lay->ode_begin;
+  return (size_t)payload_map(*s, part).total;
+}
+
+int slode_grad_partial(slode_handle h, const slode_shape* s, const slode_layout* lay, int kind, const float* params, const float* times,
+                       const float* stage_t, const slode_batch* batch, float* payload, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
+  if (!s || !batch) return fail(h, SLODE_EINVAL, "shape / batch is NULL");
+  if (kind != SLODE_SVI_MAIN && kind != SLODE_SVI_AUX) return fail(h, SLODE_EINVAL, "kind must be SLODE_SVI_MAIN or SLODE_SVI_AUX");
+  LabelSrc lab{};
+  const int rc = batch_labels(h, s, batch, &lab);
+  if (rc != SLODE_OK) return rc;
+  const bool aux = kind == SLODE_SVI_AUX;
+  return elbo_step_impl(h, s, lay, params, aux ? nullptr : times, aux ? nullptr : stage_t, batch->obs, batch->obs_strides, nullptr, batch->eps,
+                        nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream, nullptr, aux ? 1 : 0,
+                        batch->n_labels > 0 ? &lab : nullptr, 1, payload);
+}
+
+int slode_grad_apply(slode_handle h, const slode_shape* s, const slode_layout* lay, int kind, float* params, const int64_t obs_strides[3],
+                     const float* payload, float* loss_out, float* grads, void* workspace, size_t workspace_bytes, const slode_adam* adam,
+                     void* stream) {
+  if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
+  if (kind != SLODE_SVI_MAIN && kind != SLODE_SVI_AUX) return fail(h, SLODE_EINVAL, "kind must be SLODE_SVI_MAIN or SLODE_SVI_AUX");
+  AdamArgs ad{};
+  if (adam) {
+    if (!grads || !adam->exp_avg || !adam->exp_avg_sq || adam->step < 1 || !lay || adam->n_total < lay->n_params)
+      return fail(h, SLODE_EINVAL, "slode_grad_apply with Adam needs grads, both moments, step >= 1 and n_total >= layout n_params");
+    ad = AdamArgs{params, adam->exp_avg, adam->exp_avg_sq, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->step, adam->n_total};
+  }
+  return elbo_step_impl(h, s, lay, params, nullptr, nullptr, nullptr, obs_strides, nullptr, nullptr, loss_out, grads, nullptr, nullptr, workspace,
+                        workspace_bytes, stream, adam ? &ad : nullptr, kind == SLODE_SVI_AUX ? 1 : 0, nullptr, 2, const_cast<float*>(payload));
+}
+
+int slode_rng_seed(slode_handle h, uint64_t seed, int64_t first_trajectory) {
+  if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
+  if (first_trajectory < 0) return fail(h, SLODE_EINVAL, "first_trajectory < 0");
+  h->rng_seed = seed; h->rng_b0 = first_trajectory; h->rng_counter = 0;
+  return SLODE_OK;
+}
+
+int slode_rng_set_counter(slode_handle h, uint64_t n) {
+  if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
+  h->rng_counter = n;
+  return SLODE_OK;
+}
+
+int slode_rng_get(slode_handle h, uint64_t* seed, int64_t* first_trajectory, uint64_t* n) {
+  if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
+  if (seed) *seed = h->rng_seed;
+  if (first_trajectory) *first_trajectory = h->rng_b0;
+  if (n) *n = h->rng_counter;
+  return SLODE_OK;
+}
+
+int slode_rng_normal(slode_handle h, uint64_t n, int32_t B, int32_t L, float* eps_out, uint32_t* raw_out, void* stream) {
+  if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
+  if (B < 1 || L < 1 || L > SLODE_MAX_L || (!eps_out && !raw_out)) return fail(h, SLODE_EINVAL, "slode_rng_normal: B >= 1, 1 <= L <= 64 and an output required");
+  HIP_TRY(h, slode_launch_rng_fill(rng_of(h, n), B, L, eps_out, raw_out, (hipStream_t)stream));
+  return SLODE_OK;
+}
+
+int slode_sample_normal(slode_handle h, int32_t B, int32_t L, const float* loc, const float* scale, float* z_out, void* stream) {
+  if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
+  if (B < 1 || L < 1 || L > SLODE_MAX_L || !loc || !scale || !z_out) return fail(h, SLODE_EINVAL, "slode_sample_normal: B >= 1, 1 <= L <= 64, loc / scale / z_out required");
+  HIP_TRY(h, slode_launch_rng_fill(rng_of(h, h->rng_counter++), B, L, z_out, nullptr, (hipStream_t)stream, loc, scale));
+  return SLODE_OK;
 }
 
 int slode_dynamics_eval(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params, float t,

@@ -53,7 +53,57 @@ struct slode_ctx {
   int enc_fuse;           // SLODE_ENC_FUSE (default 1): encoder forward inside the ODE kernel where an instantiation exists
   int ode_pack;           // SLODE_ODE_PACK = 4: four trajectories per ODE workgroup (metric shape)
   int ode_grid_cap;       // SLODE_ODE_GRID = n: at most n workgroups in the persistent-loop grid (tests: several trajectories per workgroup at small B)
+  // slode_rng_seed: the Philox stream of the calls that draw their own noise (eps == NULL); rng_counter = drawing calls made so far
+  uint64_t rng_seed, rng_counter; int64_t rng_b0;
 };
+
+// ---- reparameterisation noise drawn in the kernels (slode_rng_seed; eps == NULL) and labels as the loader yields them -------------
+// Philox-4x32-10 (Salmon et al., SC'11), counter-based: the draw for (trajectory b, latent index l) of the handle's n-th drawing call is
+//   block = philox(counter = [b + b0 (low 32) | l >> 2 | n (low 32) | n (high 32)], key = seed),  eps = Box-Muller(block)[l & 3]
+// -- no state, no ordering between threads, and independent of how the batch is sharded over GPUs (b0 = the shard's first global
+// trajectory).  Latent indices run in the guide's site order (mechanistic_cvs.py:225-237: z_iext, z_rtpr, z_epsilon are consecutive
+// ranges of the concatenated latent), so l IS the site order.  tests/test_rng_cpu.py restates it in numpy.
+struct RngK { unsigned int k0, k1, c2, c3; long long b0; int on; };
+// label columns of u[B, n_u] as separate dense [B, width] tensors (n == 0: one dense matrix, the `u` pointer)
+struct LabelSrc { const float* p[SLODE_MAX_LABELS]; int off[SLODE_MAX_LABELS + 1]; int n; };
+
+__host__ __device__ inline void philox4x32_10(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3, unsigned int k0, unsigned int k1,
+                                              unsigned int (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned int)p1;
+    const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned int)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+#ifdef __HIPCC__
+// standard normal for (trajectory b of this launch, latent index l): words (0, 1) of the block give the pair of l & 2 == 0, words (2, 3)
+// the other; u = ((x >> 9) + 0.5) 2^-23 in (0, 1) (exact in fp32), r = sqrt(-2 ln u_a), angle 2 pi u_b, cos for even l, sin for odd l
+__device__ __forceinline__ float slode_rng_normal(const RngK& r, long long b, int l) {
+  unsigned int x[4];
+  philox4x32_10((unsigned int)(b + r.b0), (unsigned int)(l >> 2), r.c2, r.c3, r.k0, r.k1, x);
+  const unsigned int xa = (l & 2) ? x[2] : x[0], xb = (l & 2) ? x[3] : x[1];
+  const float ua = ((float)(xa >> 9) + 0.5f) * 1.1920928955078125e-7f, ub = ((float)(xb >> 9) + 0.5f) * 1.1920928955078125e-7f;   // exact in fp32
+  const float rad = sqrtf(-2.0f * logf(ua));
+  float sn, cs;
+  sincospif(2.0f * ub, &sn, &cs);
+  return rad * ((l & 1) ? sn : cs);
+}
+__device__ __forceinline__ float slode_eps_at(const RngK& r, const float* eps, long long b, int L, int l) {
+  return r.on ? slode_rng_normal(r, b, l) : eps[b * L + l];
+}
+__device__ __forceinline__ float slode_label_at(const LabelSrc& ls, const float* u, int nu, long long b, int col) {
+  if (ls.n == 0) return u[b * nu + col];
+  int i = 0;
+#pragma unroll
+  for (int q = 1; q < SLODE_MAX_LABELS; ++q) i = (q < ls.n && col >= ls.off[q]) ? q : i;
+  const int w = ls.off[i + 1] - ls.off[i];
+  return ls.p[i][b * w + (col - ls.off[i])];
+}
+#endif
 
 // ---- device helpers -------------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -318,6 +368,8 @@ struct OdeLaunch {
   const float *enc_weff = nullptr, *enc_beff = nullptr;   // the fold launch's W_eff [Hc][C*T] / b_eff [Hc]; obs must be dense rows (sb == C*T)
   float* enc_hid_out = nullptr;                          // saved tanh [B][Hc]
   int pack = 0;          // 4: four trajectories per workgroup where the shape has such an instantiation (ode_kernel.hip, PK)
+  RngK rng{};            // on: eps is drawn in the kernel (eps may be NULL)
+  LabelSrc lab{};        // n > 0: the label columns come from separate tensors (u may be NULL)
 };
 hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, size_t errlen);
 size_t slode_ode_lds_bytes(const slode_shape& s, int nthreads, bool one = false);
@@ -401,6 +453,8 @@ struct AuxLaunch {
   int compact = 0;                   // slab row = [loss | flat range [lay.aux_w1[0], lay.cstd)] instead of the whole ODE segment
   const float* enc_hid = nullptr;    // folded encoder path: the kernel also runs the encoder heads + tanh backward (g_pre, glat)
   float *g_pre = nullptr, *glat = nullptr;
+  RngK rng{};
+  LabelSrc lab{};
 };
 hipError_t slode_launch_aux(const AuxLaunch& a, hipStream_t stream);
 
@@ -437,7 +491,8 @@ hipError_t slode_launch_label_heads(const slode_shape& s, const slode_layout& la
 hipError_t slode_launch_dynamics_eval(const slode_shape& s, const slode_layout& lay, const float* params, float t,
                                       const float* state, const float* z, float* out, hipStream_t stream);
 // adaptive solve with step records (training): z = loc + scale * eps is formed in the kernel and written to z_out
-struct DopriRec { const float *loc, *scale, *eps; float* z_out; float* rec; int* nrec; int kmax; };
+// rng.on: eps is drawn by the forward kernel and written to eps_out, which the scorer and the reverse sweep then read as `eps`
+struct DopriRec { const float *loc, *scale, *eps; float* z_out; float* rec; int* nrec; int kmax; RngK rng{}; float* eps_out = nullptr; };
 int slode_dopri5_kmax(const slode_shape& s);
 int slode_dopri5_rows(const slode_shape& s);
 hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const float* z,
@@ -448,3 +503,11 @@ hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay
 hipError_t slode_launch_adam_k(int64_t n, const float* g, const AdamHost& a, hipStream_t stream);
 hipError_t slode_launch_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2,
                              float eps, int64_t step, hipStream_t stream);
+// data-parallel payload: out[0, total) = [sum of the gsplit split-K partials of G | of G_loc | of G_ls | sum of the ode_n partial rows],
+// every sum in fixed order (slode_api.hip: PayloadMap); the gaps between the pieces are written as zeros
+hipError_t slode_launch_pack_payload(const float* gslabs, const float* gslabs_loc, const float* gslabs_ls, int gsplit, int Hc, int CT, int L,
+                                     const float* ode_part, int ode_stride, int ode_n, int ode_count, float* out, int o_loc, int o_ls, int o_ode,
+                                     int total, hipStream_t stream);
+// eps_out[B][L] (may be NULL) and / or raw[B][ceil(L/4)][4] Philox words (may be NULL) of one drawing call: misc_kernels.hip
+hipError_t slode_launch_rng_fill(const RngK& r, int B, int L, float* eps_out, unsigned int* raw, hipStream_t stream,
+                                 const float* loc = nullptr, const float* scale = nullptr);   // loc given: eps_out = loc + scale * eps

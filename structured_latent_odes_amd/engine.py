@@ -331,16 +331,31 @@ class Engine:
             self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._f32(x, "x")), self._p(mu), self._p(std), self._stream()))
         return mu, std
 
-    def decode_heads_bwd(self, params, x, g_mu, g_std=None):
-        """Backward of decode_heads: g_mu [Q, B, C, T] (+ g_std [C, T]) -> (g_x [B, T, S], g_heads [Q, C, S], g_cstd [C, T])."""
+    def heads_snapshot(self, params):
+        """Copy of the flat range [first decoder head, n_params) -- the decoder heads and constant_std (with the label heads, if any,
+        between them) -- and its start: what decode_heads_bwd reads of the parameters, frozen at forward time."""
+        lo = int(self.layout.head_w[0])
+        return params[lo:self.n_params].clone(), lo
+
+    def decode_heads_bwd(self, params, x, g_mu, g_std=None, snapshot=None):
+        """Backward of decode_heads: g_mu [Q, B, C, T] (+ g_std [C, T]) -> (g_x [B, T, S], g_heads [Q, C, S], g_cstd [C, T]).
+        `snapshot` = heads_snapshot(...) of the forward: the kernel then reads the head weights / constant_std from it (it touches no
+        parameter below the first decoder head, so the base pointer is the snapshot's, moved back by its start)."""
         B = x.shape[0]
         sp = self.spec
         Q = 1 if sp.gauss else 3
         g_x = torch.empty(B, self.T, sp.ode_state_dim, dtype=torch.float32, device=self.device)
         g_heads = torch.empty(Q, sp.n_channels, sp.ode_state_dim, dtype=torch.float32, device=self.device)
         g_cstd = torch.empty(sp.n_channels, self.T, dtype=torch.float32, device=self.device)
+        if snapshot is not None:
+            snap, lo = snapshot
+            if snap.numel() != self.n_params - lo or lo != int(self.layout.head_w[0]):
+                raise ValueError("snapshot does not match this engine's layout")
+            p_ptr = C.c_void_p(self._f32(snap, "snapshot").data_ptr() - 4 * lo)
+        else:
+            p_ptr = self._p(params)
         _check(self.lib, self.handle, self.lib.slode_decode_heads_bwd(
-            self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._f32(x, "x")), self._p(self._f32(g_mu, "g_mu")),
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), p_ptr, self._p(self._f32(x, "x")), self._p(self._f32(g_mu, "g_mu")),
             self._p(self._f32(g_std, "g_std") if g_std is not None else None), self._p(g_x), self._p(g_heads), self._p(g_cstd), self._stream()))
         return g_x, g_heads, g_cstd
 
@@ -379,6 +394,106 @@ class Engine:
             self._p(eps), self._p(loss_out), self._p(grads), self._p(ws), ws.numel() * 4, params.numel(), self._p(m), self._p(v), float(lr),
             float(betas[0]), float(betas[1]), float(aeps), int(step), self._stream()))
         return loss_out
+
+    # ---- SVI.step(**batch) as one call: labels as the loader yields them, noise drawn in the kernels -----------------------------
+    def make_batch(self, obs, labels, eps=None) -> L.Batch:
+        """slode_batch for `obs` [B, C, T] (any strides) and the label tensors in the model's concatenation order (each [B, width] or [B],
+        float32, contiguous, on the device).  eps [B, L] or None (None: drawn in-kernel from the handle's Philox stream, rng_seed)."""
+        B = obs.shape[0]
+        self._f32(obs, "observations", contiguous=False)
+        bt = L.Batch()
+        bt.obs = obs.data_ptr()
+        st = self._obs_strides(obs)
+        for i in range(3):
+            bt.obs_strides[i] = st[i]
+        if len(labels) > L.MAX_LABELS:
+            raise ValueError("at most %d label tensors, got %d" % (L.MAX_LABELS, len(labels)))
+        cols = 0
+        for i, t in enumerate(labels):
+            self._f32(t, "label %d" % i)
+            if t.shape[0] != B:
+                raise ValueError("label %d has %d rows, the batch %d" % (i, t.shape[0], B))
+            w = t.numel() // B
+            bt.labels[i], bt.label_width[i] = t.data_ptr(), w
+            cols += w
+        if labels and cols != self.spec.n_u:
+            raise ValueError("the label tensors have %d columns in all, the model's u has %d" % (cols, self.spec.n_u))
+        bt.n_labels = len(labels)
+        if eps is not None:
+            self._f32(eps, "eps")
+            if tuple(eps.shape) != (B, self.spec.latent_dim):
+                raise ValueError("eps must be [%d, %d], got %s" % (B, self.spec.latent_dim, tuple(eps.shape)))
+            bt.eps = eps.data_ptr()
+        return bt
+
+    def svi_step(self, kind: int, params, batch: L.Batch, B: int, loss_out, grads=None, adam=None):
+        """slode_svi_step: kind L.SVI_MAIN | L.SVI_AUX; adam = (exp_avg, exp_avg_sq, lr, step, betas, eps) or None."""
+        ws = self.workspace(B)
+        ad = None
+        if adam is not None:
+            m, v, lr, step, betas, aeps = adam
+            ad = L.AdamArgs(params.numel(), m.data_ptr(), v.data_ptr(), float(lr), float(betas[0]), float(betas[1]), float(aeps), int(step))
+        _check(self.lib, self.handle, self.lib.slode_svi_step(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), int(kind), self._p(params), self._p(self._times), self._p(self._stage_t),
+            C.byref(batch), self._p(loss_out), self._p(grads), self._p(ws), ws.numel() * 4, C.byref(ad) if ad is not None else None, self._stream()))
+        return loss_out
+
+    # ---- data parallel with the small payload: grad_partial -> all-reduce(payload) -> grad_apply (include/slode.h) ------------------
+    def payload_floats(self, kind: int) -> int:
+        return int(self.lib.slode_grad_payload_floats(C.byref(self.shape(1)), C.byref(self.layout), int(kind)))
+
+    def grad_partial(self, kind: int, params, batch: L.Batch, B: int, payload):
+        ws = self.workspace(B)
+        _check(self.lib, self.handle, self.lib.slode_grad_partial(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), int(kind), self._p(params), self._p(self._times), self._p(self._stage_t),
+            C.byref(batch), self._p(self._f32(payload, "payload")), self._p(ws), ws.numel() * 4, self._stream()))
+
+    def grad_apply(self, kind: int, params, batch: L.Batch, B: int, payload, loss_out, grads, adam=None):
+        ws = self.workspace(B)
+        ad = None
+        if adam is not None:
+            m, v, lr, step, betas, aeps = adam
+            ad = L.AdamArgs(params.numel(), m.data_ptr(), v.data_ptr(), float(lr), float(betas[0]), float(betas[1]), float(aeps), int(step))
+        _check(self.lib, self.handle, self.lib.slode_grad_apply(
+            self.handle, C.byref(self.shape(B)), C.byref(self.layout), int(kind), self._p(params), batch.obs_strides, self._p(payload),
+            self._p(loss_out), self._p(grads), self._p(ws), ws.numel() * 4, C.byref(ad) if ad is not None else None, self._stream()))
+        return loss_out
+
+    def rng_seed(self, seed: int, first_trajectory: int = 0):
+        """Key of the in-kernel noise generator (Philox-4x32-10); resets its call counter.  Data parallel: every rank passes the global
+        index of its shard's first trajectory, so the draws do not depend on the sharding."""
+        _check(self.lib, self.handle, self.lib.slode_rng_seed(self.handle, int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_trajectory)))
+
+    def rng_state(self):
+        """(seed, first_trajectory, calls drawn so far)."""
+        a, b, c = C.c_uint64(), C.c_int64(), C.c_uint64()
+        _check(self.lib, self.handle, self.lib.slode_rng_get(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
+
+    def rng_set_counter(self, n: int):
+        _check(self.lib, self.handle, self.lib.slode_rng_set_counter(self.handle, int(n)))
+
+    def rng_normal(self, n: int, B: int, raw: bool = False):
+        """The noise drawing call `n` uses for B trajectories: eps [B, L] (and the raw Philox words [B, ceil(L/4), 4] as int64 if raw)."""
+        Ld = self.spec.latent_dim
+        eps = torch.empty(B, Ld, dtype=torch.float32, device=self.device)
+        words = torch.empty(B, (Ld + 3) // 4, 4, dtype=torch.int32, device=self.device) if raw else None
+        _check(self.lib, self.handle, self.lib.slode_rng_normal(self.handle, int(n), B, Ld, self._p(eps), self._p(words), self._stream()))
+        return (eps, words.to(torch.int64) & 0xFFFFFFFF) if raw else eps
+
+    def draw_normal(self, B: int):
+        """eps [B, L] of the next drawing call of the engine's generator (the call counter moves on)."""
+        _, _, n = self.rng_state()
+        eps = self.rng_normal(n, B)
+        self.rng_set_counter(n + 1)
+        return eps
+
+    def sample_normal(self, loc, scale):
+        """torch.normal(loc, scale) on the engine's generator: z = loc + scale * eps, one HIP kernel, one drawing call."""
+        z = torch.empty_like(self._f32(loc, "loc"))
+        _check(self.lib, self.handle, self.lib.slode_sample_normal(self.handle, loc.shape[0], loc.shape[1], self._p(loc),
+                                                                   self._p(self._f32(scale, "scale")), self._p(z), self._stream()))
+        return z
 
     def adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-8):
         _check(self.lib, self.handle, self.lib.slode_adam_step(

@@ -17,6 +17,9 @@ class Binding:
         self.engine = Engine(spec, int(times.numel()), device)
         self.engine.set_times(times)
         eng = self.engine
+        # the in-kernel noise generator takes its key from torch's global seed (utils.set_seed / torch.manual_seed: the reference seeds
+        # everything through set_seed(config.seed), training_cvs.py:203) -- runs with the same seed draw the same noise
+        eng.rng_seed(torch.initial_seed())
         extra = list(extra or [])
         n_extra = sum(p.numel() for p in extra)
         self.flat = torch.zeros(eng.n_params + n_extra, dtype=torch.float32, device=eng.device)

@@ -161,9 +161,9 @@ class MechanisticBase(nn.Module):
 
     def guide(self, observations, **labels):
         """q(z | x): encoder + one reparameterised Normal per latent group (mechanistic_cvs.py:213-238)."""
-        self._bind()
+        b = self._bind()
         loc, scale = self.encoder.forward(observations)
-        z = loc + scale * self.draw_eps(observations.shape[0], loc.device)
+        z = b.engine.sample_normal(loc.contiguous(), scale.contiguous())
         return tuple(self._z_group(z, g) for g in self.Z_GROUPS)
 
     def model_meta(self, observations, **labels):
@@ -182,8 +182,8 @@ class MechanisticBase(nn.Module):
         b = self._bind()
         with torch.no_grad():
             loc, scale = self.encoder.forward(observations)
-            z = torch.normal(loc, scale)
-            probs = b.engine.label_heads(b.flat, z.contiguous())
+            z = b.engine.sample_normal(loc.contiguous(), scale.contiguous())
+            probs = b.engine.label_heads(b.flat, z)
             res = {}
             heads = {h.prefix: h for h in b.engine.spec.aux_heads}
             for attr, group, label, kind in self.AUX:
@@ -199,14 +199,14 @@ class MechanisticBase(nn.Module):
 
     def recon(self, observations, is_post, **labels):
         """Posterior (is_post) or prior reconstruction (mechanistic_cvs.py:298-323): returns the reference's dict."""
-        self._bind()
+        b = self._bind()
         with torch.no_grad():
             if is_post:
                 loc, scale = self.encoder.forward(observations)
-                z = torch.normal(loc, scale)
+                z = b.engine.sample_normal(loc.contiguous(), scale.contiguous())
             else:
                 ploc, pscale = self._prior_loc_scale(labels)      # [B, L]: conditional groups, then (0, 1) for z_epsilon
-                z = torch.normal(ploc, pscale)
+                z = b.engine.sample_normal(ploc, pscale)
             if self.GAUSS:
                 solution_xt, mean, std = self.decoder.forward(z=z)
                 return {"l1": self.l1_func(mean, observations), "solution_xt": solution_xt, "mean": mean, "std": std, "z": z}
@@ -229,7 +229,7 @@ class MechanisticBase(nn.Module):
             else:
                 loc, scale = self._prior_loc_scale(labels)
             if eps is None:
-                eps = torch.randn(ns, B, loc.shape[1], device=loc.device)
+                eps = self._bind().engine.draw_normal(ns * B).view(ns, B, loc.shape[1])
             z = loc.unsqueeze(0) + scale.unsqueeze(0) * eps.to(loc.device)               # [ns, B, L]
             out = self.decoder.forward(z=z.reshape(ns * B, -1).contiguous())
             names = ("solution_xt", "mean", "std") if self.GAUSS else ("solution_xt", "mu_75", "mu_50", "mu_25", "std")

@@ -13,7 +13,9 @@ from .blackbox_ode import OdeModel
 
 class _HeadsFn(torch.autograd.Function):
     """Heads + softplus std.  Forward = ``slode_decode_heads``, backward = ``slode_decode_heads_bwd`` (the materialising API; the fused
-    training path never comes through here)."""
+    training path never comes through here).  The backward differentiates at the weights the FORWARD saw: the head weights and
+    ``constant_std`` are views of the flat parameter vector, which the fused Adam kernels update in place through raw pointers
+    (no autograd version bump), so the forward keeps its own copy of that small segment for the backward."""
 
     @staticmethod
     def forward(ctx, dec, x, cstd, *heads):
@@ -21,19 +23,21 @@ class _HeadsFn(torch.autograd.Function):
         x = x.contiguous()
         mu, std = b.engine.decode_heads(b.flat, x)
         ctx.binding = b
-        ctx.save_for_backward(x)
+        snap, ctx.snap_lo = b.engine.heads_snapshot(b.flat)
+        ctx.save_for_backward(x, snap)
         ctx.mu_shape = tuple(mu.shape)
         return (std, *[mu[i] for i in range(mu.shape[0])])
 
     @staticmethod
     def backward(ctx, g_std, *g_mu):
-        (x,) = ctx.saved_tensors
+        x, snap = ctx.saved_tensors
         b = ctx.binding
         stacked = torch.zeros(ctx.mu_shape, dtype=torch.float32, device=x.device)
         for i, g in enumerate(g_mu):
             if g is not None:
                 stacked[i].copy_(g)
-        g_x, g_heads, g_c = b.engine.decode_heads_bwd(b.flat, x, stacked, g_std.contiguous() if g_std is not None else None)
+        g_x, g_heads, g_c = b.engine.decode_heads_bwd(b.flat, x, stacked, g_std.contiguous() if g_std is not None else None,
+                                                      snapshot=(snap, ctx.snap_lo))
         return (None, g_x, g_c if g_std is not None else None, *[g_heads[i] for i in range(g_heads.shape[0])])
 
 

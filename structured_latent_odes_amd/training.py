@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import logging
 import os
+import time
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -104,7 +105,12 @@ def train(config, family: str, model_cls, model_cls_gauss, batches_per_epoch: in
     best_val_loss, best_epoch = np.inf, 0
     names = FAMILY_LABELS[family][:2]
     for epoch in range(config.num_epochs + 1):
-        epoch_loss = [run_batch(batch_to_device(b, device, family), losses) for b in train_b]
+        t_ep, n_traj, epoch_loss = time.perf_counter(), 0, []
+        for b in train_b:
+            d = batch_to_device(b, device, family)
+            epoch_loss.append(run_batch(d, losses))          # (every step ends in the .item() of its loss: the clock sees finished work)
+            n_traj += d["observations"].shape[0]
+        traj_per_s = n_traj / max(time.perf_counter() - t_ep, 1e-9)
         # the reference's four statistics passes per epoch (training_cvs.py:270-315): validation posterior / prior, training
         # posterior / prior -- every one a full pass over its loader: evaluate_loss of both SVI objects, recon, label prediction
         val = input_pred_stats(val_b, var_model, losses, True, device, family)
@@ -116,9 +122,11 @@ def train(config, family: str, model_cls, model_cls_gauss, batches_per_epoch: in
         if best_val_loss >= val_elbo:
             best_val_loss, best_epoch, improved = val_elbo, epoch, "*"
             best_model.load_state_dict(var_model.state_dict())
-        line = "[Epoch %d/%d] loss= %.4f  %s_acc=(%.4f,%.4f)  %s_acc=(%.4f,%.4f) l1=(%.6f,%.6f), %s" % (
+        # the reference's summary line (training_cvs.py:336-352) + the training throughput of the epoch: trajectories through
+        # run_batch (main + auxiliary SVI step, two Adam passes) per second of wall time, host-to-device copies included
+        line = "[Epoch %d/%d] loss= %.4f  %s_acc=(%.4f,%.4f)  %s_acc=(%.4f,%.4f) l1=(%.6f,%.6f), %s  trajectories/sec=%.0f" % (
             epoch, config.num_epochs, float(np.mean(epoch_loss)), names[0], trn[names[0]], val[names[0]], names[1], trn[names[1]],
-            val[names[1]], trn["l1"], val["l1"], improved)
+            val[names[1]], trn["l1"], val["l1"], improved, traj_per_s)
         print(line)
         logging.debug(line)
     # final test passes on the best model, posterior and prior (training_cvs.py:355-397); the losses stay bound to var_model, as there

@@ -46,6 +46,26 @@ class OracleEngine:
         grads[:self.n_params] = torch.cat([g[k].reshape(-1) for k, _, _ in self.keys])
         return loss_out
 
+    # the one-call step interface of the real engine (Engine.make_batch / svi_step / rng_state): explicit eps only -- the double has no
+    # in-kernel generator -- and the label tensors concatenated here, on the test side
+    def rng_state(self):
+        return 0, 0, 0
+
+    def make_batch(self, obs, labels, eps=None):
+        assert eps is not None, "the engine double needs explicit eps"
+        return (obs, torch.cat([t.reshape(t.shape[0], -1) for t in labels], dim=1) if labels else None, eps)
+
+    def svi_step(self, kind, params, batch, B, loss_out, grads=None, adam=None):
+        assert kind == 0
+        obs, u, eps = batch
+        self.elbo_step(params, obs, u, eps, loss_out, grads)
+        if adam is not None:
+            m, v, lr, step, betas, aeps = adam
+            full = torch.zeros_like(params)
+            full[:self.n_params] = grads[:self.n_params]
+            self.adam_step(params, full, m, v, lr, step, betas, aeps)
+        return loss_out
+
     def adam_step(self, params, grads, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8):
         b1, b2 = betas
         m.lerp_(grads, 1 - b1)

@@ -22,6 +22,9 @@ CASES = {
     "challenge_ald_midpoint": ("challenge", dict(solver="midpoint"), 9, 142),
     "proc_c2_rk4": ("proc", dict(z_g=10, z_eps=10, solver="rk4"), 16, 100),                 # BASELINE config[2] shapes (fixed grid)
     "proc_gauss_midpoint": ("proc", dict(z_g=3, z_eps=2, gauss=True, solver="midpoint"), 7, 86),
+    # a label head that reads 17 latent dims (a legal reference config, e.g. z_iext_dim = 17): every entry point takes it; the auxiliary
+    # kernel switches to its wide instantiation (round-3 advisor finding: check_shape used to reject z_dim > 16 everywhere)
+    "cvs_wide_head_z17": ("cvs", dict(z_iext=17, z_rtpr=3, z_eps=2, solver="midpoint"), 5, 64),
 }
 
 
@@ -652,6 +655,15 @@ def test_abi_error_paths():
     a = args(); a[1] = C.byref(bad2)
     assert lib.slode_elbo_step(*a) == -3 and b"workspace" in lib.slode_last_error(h)   # dopri5 training needs its record workspace
     assert lib.slode_adam_step(h, 10, p(flat), p(grads), p(flat), p(flat), 1e-3, 0.9, 0.999, 1e-8, 0, None) == -1   # step < 1
+    # label heads that read overlapping latent ranges: only the auxiliary step refuses them (its kernel gives every head the latent-gradient
+    # slots of its own dims); the main step, which does not score the heads of this family, still runs
+    bad3 = eng.shape(B).__class__.from_buffer_copy(eng.shape(B))
+    bad3.aux[1].z_off = bad3.aux[0].z_off
+    aux_args = [h, C.byref(bad3), C.byref(eng.layout), p(flat), p(obs), strides, p(u), p(eps), p(loss), p(grads), p(ws), ws.numel() * 4,
+                eng.n_params, None, None, C.c_float(0.0), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8), 1, None]
+    assert lib.slode_aux_step(*aux_args) == -1 and b"overlapping" in lib.slode_last_error(h)
+    a = args(); a[1] = C.byref(bad3)
+    assert lib.slode_elbo_step(*a) == 0
     assert lib.slode_elbo_step(*args()) == 0 and torch.isfinite(loss).all()      # the handle stays usable after errors
 
 
