@@ -50,9 +50,13 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-run-batch", action="store_true", help="skip the run_batch (main + auxiliary step) block: profiling runs of the metric step alone")
+    ap.add_argument("--ab", action="store_true", help="A/B runs (tools/ab_env.sh, ab_libs.sh): the metric step and its kernel clocks only")
     ap.add_argument("--grad-mode", choices=["exact", "reference_adjoint"], default="exact",
                     help="exact: gradient of the discrete scheme (adjoint_solver=False); reference_adjoint: torchdiffeq.odeint_adjoint's")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.ab:
+        a.no_cpu_baseline = a.no_other_configs = a.no_run_batch = True
+    return a
 
 
 def self_launch(args):
@@ -268,8 +272,15 @@ def main():
     # ---- per-kernel durations: every dispatch's own begin -> end timestamps, in an instrumented pass over the same steps ----
     if world == 1:
         calls = [step]
-    else:   # N > 1: the step is two entry points around the collective
-        calls = [lambda: eng.elbo_step(flat, obs_d, u_d, eps_d, svi.loss, svi.grads), lambda: opt.step(svi.gbuf[:flat.numel()])]
+    else:   # N > 1: the step is two entry points around the collective -- slode_grad_partial | all-reduce of the payload | slode_grad_apply
+        from structured_latent_odes_amd import _lib as SL
+        bt = eng.make_batch(obs_d, [u_d], eps_d)
+        if isinstance(svi._payload, torch.Tensor):
+            pay = svi._payload
+            calls = [lambda: eng.grad_partial(SL.SVI_MAIN, flat, bt, B_PER_GPU, pay),
+                     lambda: eng.grad_apply(SL.SVI_MAIN, flat, bt, B_PER_GPU, pay, svi.loss, svi.grads, adam=(opt.exp_avg, opt.exp_avg_sq, 0.0, 1, opt.betas, opt.eps))]
+        else:
+            calls = [lambda: eng.elbo_step(flat, obs_d, u_d, eps_d, svi.loss, svi.grads), lambda: opt.step(svi.gbuf[:flat.numel()])]
     kern_us = kernel_clocks(eng, calls, n=40)
     frac_variants = {}
     dom, flops_launch, achieved = roofline_of(kern_us, shape1, B_PER_GPU, frac_variants)
@@ -357,7 +368,7 @@ def main():
 
     # ---- one continuous leg of the metric step, >= 2 s of back-to-back enqueues with ONE synchronize at the end: long enough for an
     # outside sampler (the driver's gpu_busy) to see the steady state the K-step blocks above measure
-    if world == 1:
+    if world == 1 and not args.ab:
         n_sus = int(min(400000, max(1000, 2.6 / (ms_per_step * 1e-3))))
         sync()
         t0 = time.perf_counter()
@@ -368,7 +379,7 @@ def main():
         out["sustained"] = {"seconds": sus, "steps": n_sus, "traj_per_s": B_PER_GPU * n_sus / sus, "ms_per_step": 1e3 * sus / n_sus}
 
     # ---- the same step with the reference's DEFAULT gradients (adjoint_solver=True: torchdiffeq.odeint_adjoint's) ----------------------
-    if world == 1:
+    if world == 1 and not args.ab:
         other_mode = "exact" if args.grad_mode == "reference_adjoint" else "reference_adjoint"
         kw2 = dict(cvs_kw, adjoint_solver=(other_mode == "reference_adjoint"))
         cfg2, model2, _, obs2, u2, eps2, _, _ = build_case("cvs", False, B_PER_GPU, T, kw2, dev, seed=1234 + rank)
@@ -432,20 +443,27 @@ def main():
     # ---- N > 1: the collective alone, and strong scaling of the same global batch --------------------------------------------------------
     if world > 1:
         n_rep = 200
-        for _ in range(20):
-            torch.distributed.all_reduce(svi.gbuf, op=torch.distributed.ReduceOp.SUM)
-        sync()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n_rep):
-            torch.distributed.all_reduce(svi.gbuf, op=torch.distributed.ReduceOp.SUM)
-        e1.record()
-        e1.synchronize()
-        coll_us = 1e3 * e0.elapsed_time(e1) / n_rep
-        cmax = torch.tensor([coll_us], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(cmax, op=torch.distributed.ReduceOp.MAX)
-        out["collective_us"] = float(cmax.item())
-        out["collective"] = {"bytes": int(svi.gbuf.numel() * 4), "op": "SUM all-reduce of [flat gradient | loss]", "repeats": n_rep,
+        def coll_time(buf):
+            scratch = buf.clone()            # (the step's own buffer keeps its contents)
+            for _ in range(20):
+                torch.distributed.all_reduce(scratch, op=torch.distributed.ReduceOp.SUM)
+            sync()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n_rep):
+                torch.distributed.all_reduce(scratch, op=torch.distributed.ReduceOp.SUM)
+            e1.record()
+            e1.synchronize()
+            cmax = torch.tensor([1e3 * e0.elapsed_time(e1) / n_rep], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(cmax, op=torch.distributed.ReduceOp.MAX)
+            return float(cmax.item())
+        used = svi._payload if isinstance(svi._payload, torch.Tensor) else svi.gbuf
+        out["collective_us"] = coll_time(used)
+        out["collective"] = {"bytes": int(used.numel() * 4), "repeats": n_rep,
+                             "op": "SUM all-reduce of [G = g_pre^T [X|1] | head-layer products | loss | ODE-half gradient row] (slode_grad_partial -> "
+                                   "all-reduce -> slode_grad_apply: chain rule + Adam once, on the reduced payload)"
+                                   if used is not svi.gbuf else "SUM all-reduce of [flat gradient | loss]",
+                             "flat_gradient_bytes": int(svi.gbuf.numel() * 4), "flat_gradient_collective_us": coll_time(svi.gbuf),
                              "clock": "HIP events on the step's stream around %d back-to-back all-reduces, max over ranks" % n_rep}
         try:
             out["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if not rehearse else None

@@ -434,14 +434,40 @@ __device__ __forceinline__ void wave_affine_scan(const float* __restrict__ s_A, 
   }
 }
 
+// Barrier among the NW waves of ONE trajectory of a packed workgroup (PK > 1, SOFTB): gfx950's s_barrier always joins the whole workgroup,
+// which would lock the packed trajectories' phases together (the PK = 4 lockstep arm: +3.7 us).  One LDS word per trajectory counts
+// arrivals (ds_add_rtn by lane 0 behind the wave's own LDS / memory operations); the wave whose add completes the count wakes the others
+// with s_wakeup, which meanwhile sleep and poll (one broadcast ds_read per poll) until the count reaches their own arrival number --
+// `gen`, a per-wave register that every wave of the trajectory advances identically.  Workgroup-scope release / acquire fences give the compiler and the hardware the same
+// ordering a __syncthreads() would.
+#ifndef SLODE_SB_SLEEP
+#define SLODE_SB_SLEEP 8
+#endif
+__device__ __forceinline__ void soft_barrier(unsigned int* cnt, unsigned int& gen, int nwaves) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  gen += (unsigned int)nwaves;
+  unsigned int old = 0;
+  if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  old = (unsigned int)__builtin_amdgcn_readfirstlane((int)old);
+  if (old + 1u == gen) {
+    asm volatile("s_wakeup");   // the last arriver pings every sleeping wave of the workgroup: the waiters below leave their s_sleep at once
+  } else {
+    // a waiter parks in s_sleep (64 x SLODE_SB_SLEEP cycles at most: a ping that arrives between its poll and its sleep is lost) and looks
+    // at the counter again when woken -- by its own trajectory's last arriver or by another trajectory's (then it goes back to sleep)
+    while ((int)(__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - (int)gen) < 0)
+      __builtin_amdgcn_s_sleep(SLODE_SB_SLEEP);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // The same recurrence on ALL waves of the workgroup (forward scan: nothing else runs beside it).  NW * 8 chunks of <= 8 steps per
 // component (the block has at least roundup64(T) threads), lanes (s, chunk): compose the chunk's maps, Kogge-Stone over the wave's
 // chunks of the component (DPP, as above), the waves' total maps through LDS (s_xw[NW][2][S]) and one barrier, then every lane applies
 // the totals of the waves before its own and replays its chunk.  Contains a barrier: every thread of the workgroup calls it.  The
 // caller's next barrier publishes the results.
-template <int S, bool REV, int CLMAX = 8>
+template <int S, bool REV, int CLMAX = 8, class Bar>
 __device__ __forceinline__ void block_affine_scan(const float* __restrict__ s_A, float* __restrict__ s_v, int T, int tid, int NT,
-                                                  float* __restrict__ s_xw) {
+                                                  float* __restrict__ s_xw, Bar&& bar) {
   static_assert(S <= 8, "one half-row of eight chunks per state component");
   constexpr int NC = SCAN_NCH;   // (CLMAX: registers per lane; the shape-specialised kernels pass their exact chunk length)
   const int NW = NT >> 6, wave = tid >> 6, lane = tid & 63;
@@ -476,7 +502,7 @@ __device__ __forceinline__ void block_affine_scan(const float* __restrict__ s_A,
     s_xw[(wave * 2 + 1) * S + s] = Q;
   }
   const float Pe = scan_shr<1>(P), Qe = scan_shr<1>(Q);
-  __syncthreads();
+  bar();
   float y = y0;   // state at the start of this wave's stretch
   for (int w = 0; w < wave; ++w) y = fmaf(s_xw[(w * 2 + 0) * S + s], y, s_xw[(w * 2 + 1) * S + s]);
   y = (c == 0) ? y : fmaf(Pe, y, Qe);   // state at the start of this lane's chunk
@@ -537,9 +563,12 @@ __host__ __device__ constexpr int ode_block_bound(int S, int T_, int C_, int Q_,
 // trajectory in the set-up -- pre = b_eff + W_eff x (each wave 13 rows of W_eff, its lanes the columns: two batches of register-resident
 // rows, one wave_sum16), tanh, the two head layers -- while the set-up's LDS-DMA is in flight; loc / scale go straight to the LDS slots
 // P0a reads, the saved tanh to LDS (P7's head backward) and to global memory (the head-layer GEMMs).  The enc_fwd2 launch disappears.
+// SOFTB (PK > 1 with ENCF): the packed trajectories share ONE pass over W_eff in the set-up (wave w of the workgroup takes a few rows for
+// all PK trajectories: 120 KB per workgroup through the CU's L1 instead of 120 KB per trajectory) and then run on barriers of their own
+// (soft_barrier) -- not in lockstep.
 template <int S, int H, bool BWD, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1, bool RA = false, bool ONE = false, int ALG = 0, int PK = 1,
-          bool ENCF = false>
-__global__ void __launch_bounds__(ode_block_bound(S, T_, C_, Q_, ONE, BWD, PK))
+          bool ENCF = false, bool SOFTB = false>
+__global__ void __launch_bounds__(ode_block_bound(S, T_, C_, Q_, ONE, BWD, PK)) __attribute__((amdgpu_waves_per_eu(PK == 2 ? 4 : 1)))
 ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ pl_pseg, const float* __restrict__ pl_loc,
                 const float* __restrict__ pl_scale, const float* __restrict__ pl_eps, const float* __restrict__ pl_u,
                 const float* __restrict__ pl_sigtab, const OdeK k) {
@@ -548,7 +577,8 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   // set-up go out at once instead of behind an s_load of the kernel-argument segment -- one of the two serialised cold misses every
   // kernel of the step starts with.
   static_assert(PK == 1 || (ONE && T_ > 0), "packed trajectories: shape-specialised loop-free forms only");
-  static_assert(!ENCF || (ONE && T_ > 0 && PK == 1 && ALG == 0), "fused encoder forward: shape-specialised loop-free product form only");
+  static_assert(!ENCF || (ONE && T_ > 0 && ALG == 0 && (PK == 1 || SOFTB)), "fused encoder forward: shape-specialised loop-free product form only");
+  static_assert(!SOFTB || (PK > 1 && ENCF), "per-trajectory barriers: the packed form with the shared encoder pass");
   extern __shared__ __attribute__((aligned(16))) float smem_wg[];
   constexpr int NWT = PK > 1 ? ode_threads_for(T_ ? T_ : 1, Q_ ? Q_ : 1, C_ ? C_ : 1, S) / 64 : 1;   // waves per trajectory (PK > 1)
   const int wave_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -621,7 +651,14 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   int* s_meta = reinterpret_cast<int*>(smem + m.meta);
   float* s_pf = smem + m.pf;      // [3][pad4(L)]: loc | scale | eps of the trajectory about to start (or z_in | - | -)
   float* s_encw = s_st;   // P7: encoder head weights [2][L][Hc] staged over the (then idle) stage buffer
-  float* s_ehid = smem + m.total;   // ENCF: this trajectory's tanh(pre) [64] (the launch adds the 256 bytes)
+  float* s_ehid = PK > 1 ? smem_wg + PK * m.total + traj * 64 : smem + m.total;   // ENCF: this trajectory's tanh(pre) [64] (the launch adds 256 bytes per trajectory)
+  // SOFTB: this trajectory's arrival counter (behind the PK tanh rows) and the wave's own arrival number
+  unsigned int* const s_sbar = reinterpret_cast<unsigned int*>(smem_wg + PK * m.total + PK * 64) + traj;
+  unsigned int sb_gen = 0;
+  auto BAR = [&]() {
+    if constexpr (SOFTB) soft_barrier(s_sbar, sb_gen, NWT);
+    else __syncthreads();
+  };
 
   const cptr wg = (cptr)k.wg, bg = (cptr)k.bg, wd = (cptr)k.wd, bd = (cptr)k.bd;
   // wave 0 carries every serial stretch of a trajectory (latent sample, switching indices, table, both scans): it issues ahead of the
@@ -672,6 +709,22 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   };
   float sigr[SLODE_MAX_C] = {1.f, 1.f, 1.f, 1.f};   // ONE: softplus(constant_std[c, t = tid]) stays in registers until P3
   float e_hw[4] = {0.f, 0.f, 0.f, 0.f}, e_hb = 0.f;   // ENCF: this lane's head weights and bias, from the set-up's loads to the head layers
+  // packed form with the shared encoder pass: this wave's first batch of W_eff rows is the kernel's FIRST request (the longest wait of the
+  // set-up: everything else is issued behind it)
+  constexpr int ECT0 = (C_ ? C_ : 1) * (T_ ? T_ : 1), ENU0 = (ECT0 + 127) / 128, EBP0 = 4;
+  f32x2 w_first[(ENCF && PK > 1) ? EBP0 : 1][(ENCF && PK > 1) ? ENU0 : 1];
+  if (ENCF && PK > 1) {
+    constexpr int EWG0 = PK * 4, ERWP0 = (52 + EWG0 - 1) / EWG0, NRB0 = (52 + ERWP0 - 1) / ERWP0;
+    const int rblk = wave_wg < NRB0 ? (wave_wg + (int)blockIdx.x) % NRB0 : wave_wg, lane = (int)(threadIdx.x & 63);
+#pragma unroll
+    for (int r = 0; r < EBP0; ++r)
+#pragma unroll
+      for (int u = 0; u < ENU0; ++u) {
+        const int row = min(rblk * ERWP0 + r, k.Hc - 1);
+        w_first[r][u] = (r < ERWP0) ? *reinterpret_cast<const f32x2*>(k.enc_weff + (long long)row * ECT0 + min(2 * lane + 128 * u, ECT0 - 2)) : f32x2{0.f, 0.f};
+      }
+    asm volatile("" ::: "memory");
+  }
   {
     const int n_ts = n_stage_t, n_par = k.npar, n_sig = (!ONE && k.with_ll) ? C * T : 0;
     {
@@ -718,7 +771,66 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     constexpr int ERW = 13;                       // rows of W_eff per wave (4 waves: Hc <= 52, checked by the launcher)
     constexpr int ECT = (C_ ? C_ : 1) * (T_ ? T_ : 1), ENU = (ECT + 127) / 128;
     float e_acc[16], e_be = 0.f;
-    if (ENCF) {
+    constexpr int EWG = PK * 4, ERWP = (52 + EWG - 1) / EWG;   // packed form: waves of the workgroup, rows of W_eff per wave (all PK trajectories)
+    STAMP(23);   // (set-up: LDS-DMA and per-thread loads requested)
+    if (ENCF && PK > 1) {
+      static_assert(!(ENCF && PK > 1) || (ERWP * PK <= 16 && ode_threads_for(T_ ? T_ : 1, Q_ ? Q_ : 1, C_ ? C_ : 1, S) == 256), "one wave_sum16 per wave");
+      static_assert(!(ENCF && PK > 1) || ((ECT & 1) == 0 && 2 * (L_ ? L_ : 1) * 16 <= 256), "even C*T, 16 lanes per head output");
+      if (SOFTB && tid == 0) *s_sbar = 0u;
+      // (the row block a wave takes rotates with the workgroup index: at any instant the chip's workgroups ask for different lines)
+      constexpr int NRB = (52 + ERWP - 1) / ERWP;   // row blocks that hold rows (13 of 4 rows, 8 of 7)
+      const int rblk = wave_wg < NRB ? (wave_wg + (int)blockIdx.x) % NRB : wave_wg;
+      const int lane = (int)(threadIdx.x & 63), Hc = k.Hc, row0 = rblk * ERWP;
+      f32x2 xv[PK][ENU];
+#pragma unroll
+      for (int t = 0; t < PK; ++t) {
+        const float* xrow = k.obs + (long long)min((int)blockIdx.x * PK + t, k.B - 1) * ECT;
+#pragma unroll
+        for (int u = 0; u < ENU; ++u) xv[t][u] = *reinterpret_cast<const f32x2*>(xrow + min(2 * lane + 128 * u, ECT - 2));
+      }
+      {   // this trajectory's head weights and bias (as in the unpacked form); b_eff of the row whose sum this lane will finish
+        const int o = tid >> 4, l16 = tid & 15, which = o / L, l = o - which * L;
+        const float* W = (which ? k.enc_zls_w : k.enc_zloc_w) + l * Hc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e_hw[q] = W[min(l16 + 16 * q, Hc - 1)];
+        e_hb = which ? k.enc_zls_b[l] : k.enc_zloc_b[l];
+        e_be = k.enc_beff[min(row0 + ((lane >> 2) & 15) / PK, Hc - 1)];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) e_acc[r] = 0.f;
+      constexpr int EBP = 4;   // rows per batch: 4 x ENU float2 = 40 registers in flight beside the PK x ENU float2 of the observations
+#pragma unroll
+      for (int r0 = 0; r0 < ERWP; r0 += EBP) {
+        f32x2 w[EBP][ENU];
+#pragma unroll
+        for (int r = 0; r < EBP; ++r)
+#pragma unroll
+          for (int u = 0; u < ENU; ++u) {
+            const int row = min(row0 + r0 + r, Hc - 1);   // (rows past Hc: a valid address, never used)
+            if (r0 == 0) w[r][u] = w_first[r][u];   // (requested at the top of the kernel)
+            else w[r][u] = (r0 + r < ERWP) ? *reinterpret_cast<const f32x2*>(k.enc_weff + (long long)row * ECT + min(2 * lane + 128 * u, ECT - 2)) : f32x2{0.f, 0.f};
+          }
+#pragma unroll
+        for (int r = 0; r < EBP; ++r)
+#pragma unroll
+          for (int u = 0; u < ENU; ++u) {
+            if (r0 + r < ERWP) {
+              const bool in = 2 * lane + 128 * u < ECT;
+              const float wx = in ? w[r][u].x : 0.f, wy = in ? w[r][u].y : 0.f;
+#pragma unroll
+              for (int t = 0; t < PK; ++t) e_acc[(r0 + r) * PK + t] = fmaf(wy, xv[t][u].y, fmaf(wx, xv[t][u].x, e_acc[(r0 + r) * PK + t]));
+            }
+          }
+#pragma unroll
+        for (int r = 0; r < EBP; ++r)
+          if (r0 + r < ERWP) {
+#pragma unroll
+            for (int t = 0; t < PK; ++t) asm volatile("" : "+v"(e_acc[(r0 + r) * PK + t]) : : "memory");
+          }
+      }
+    }
+    STAMP(24);   // (packed form: this wave's W_eff x observation products done, i.e. its loads have returned)
+    if (ENCF && PK == 1) {
       static_assert(!ENCF || ode_threads_for(T_ ? T_ : 1, Q_ ? Q_ : 1, C_ ? C_ : 1, S) == 256, "fused encoder forward: four waves");
       static_assert(!ENCF || ((ECT & 1) == 0 && 2 * (L_ ? L_ : 1) * 16 <= 256), "fused encoder forward: even C*T, 16 lanes per head output");
       const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, Hc = k.Hc;
@@ -793,7 +905,18 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
       if (!ENCF) { s_pf[tid] = v_l0; s_pf[pad4(L) + tid] = v_l1; }
       s_pf[2 * pad4(L) + tid] = v_l2;
     }
-    if (ENCF) {   // rows of this wave: one halving butterfly leaves the sum of row (lane >> 2) & 15 in every lane; tanh; saved
+    if (ENCF && PK > 1) {   // sum (row r, trajectory t) = entry r * PK + t of the butterfly; tanh; into trajectory t's LDS row and to memory
+      constexpr int NRB = (52 + ERWP - 1) / ERWP;
+      const int rblk = wave_wg < NRB ? (wave_wg + (int)blockIdx.x) % NRB : wave_wg;
+      const int lane = (int)(threadIdx.x & 63), idx = (lane >> 2) & 15, r = idx / PK, t = idx - r * PK, mrow = rblk * ERWP + r;
+      const float v = wave_sum16(e_acc, lane);
+      const float hv = tanhf(v + e_be);
+      if ((lane & 3) == 0 && r < ERWP && mrow < k.Hc) {
+        smem_wg[PK * m.total + t * 64 + mrow] = hv;
+        k.enc_hid_out[(long long)((int)blockIdx.x * PK + t) * k.Hc + mrow] = hv;
+      }
+    }
+    if (ENCF && PK == 1) {   // rows of this wave: one halving butterfly leaves the sum of row (lane >> 2) & 15 in every lane; tanh; saved
       const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, idx = (lane >> 2) & 15, mrow = wv * ERW + idx;
       const float v = wave_sum16(e_acc, lane);
       const float hv = tanhf(v + e_be);
@@ -802,6 +925,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
         if (b_first < k.B) k.enc_hid_out[(long long)b_first * k.Hc + mrow] = hv;
       }
     }
+    STAMP(25);   // (encoder products reduced, tanh stored)
     if (tid < k.nu) s_uu[tid] = v_u;
     if (COLDG && tid < 32) s_wt[tid] = v_wt;
     if (ONE && k.with_ll) {
@@ -829,7 +953,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     acc = row16_sum(acc);   // (four DPP adds: the 16 lanes of an output are one DPP row)
     acc += e_hb;
     if (l16 == 0 && o < 2 * L) s_pf[which * pad4(L) + l] = which ? expf(acc) : acc;
-    __syncthreads();
+    BAR();
   }
 
   float loss_acc = 0.f;   // the only value a thread carries from one trajectory to the next
@@ -860,11 +984,11 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     const bool first_traj = ONE || b == vblk;
     auto accum = [&](int idx, float v) { float* d = sl1 + idx; *d = first_traj ? v : (*d + v); };
     if (COLDB && !ONE && b != vblk) {
-      __syncthreads();   // the previous trajectory's last readers of the work block (its encoder-head block) are done
+      BAR();   // the previous trajectory's last readers of the work block (its encoder-head block) are done
       stage_cold();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (!ONE && b != vblk) __syncthreads();   // s_pf / s_uu of this trajectory are in place (first one: the setup barrier)
+    if (!ONE && b != vblk) BAR();   // s_pf / s_uu of this trajectory are in place (first one: the setup barrier)
 
     // ---- P0a: latent sample, log q, log p (mechanistic_cvs.py:125-135, 225-237) -------------------------
     if (tid < L) {
@@ -924,7 +1048,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     STAMP(15);
     // (P0a, P0b and the table part of P0c run on wave 0 only unless label heads are scored here: a wave's LDS accesses execute in
     //  program order, so the workgroup barriers in between are only needed for the label-head threads of the proc family)
-    if (COLDG || k.n_aux > 0) __syncthreads();
+    if (COLDG || k.n_aux > 0) BAR();
     // ---- P0b: u = W_z z + b_h (time-invariant part of the hidden layer), init-net hidden; each unit's switching index ------
     float uj = 0.f;
     if (tid < 64) {
@@ -1166,7 +1290,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
         s_tab[kk * 4 * S + 2 * S + c] = Ar[kk];
       }
     }
-    __syncthreads();   // table complete (ALG 0); u, w_t in place for every wave
+    BAR();   // table complete (ALG 0); u, w_t in place for every wave
 
     STAMP(2);
     // ---- P1: stage evaluations + step coefficients (thread n <-> grid step n) ---------------------------
@@ -1235,7 +1359,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           }
         }
       }
-      __syncthreads();
+      BAR();
       STAMP(3);
       if (own_step) {
         const float h = s_ts[R * (n + 1)] - s_ts[R * n];   // == times[n+1] - times[n]: stage 0 of a step sits on its node
@@ -1255,7 +1379,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
         }
       }
       if (tid < S) s_x[tid] = s_x0[tid];
-      __syncthreads();
+      BAR();
     }
     STAMP(4);
     // this trajectory's observation column (thread t <-> time point t): in flight during the scan
@@ -1271,7 +1395,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     if (!ext) {
       constexpr int NTc = T_ ? ode_threads_for(T_ ? T_ : 1, Q_ ? Q_ : 1, C_ ? C_ : 1, S) : 64;
       constexpr int CLc = T_ ? ((T_ - 1) + (NTc / 64) * SCAN_NCH - 1) / ((NTc / 64) * SCAN_NCH) : 8;   // steps per lane of the forward scan
-      block_affine_scan<S, false, (CLc < 8 ? CLc : 8)>(s_A, s_x, T, tid, NT, s_ct);   // (the chunk-sum buffer of P6 carries the waves' total maps)
+      block_affine_scan<S, false, (CLc < 8 ? CLc : 8)>(s_A, s_x, T, tid, NT, s_ct, BAR);   // (the chunk-sum buffer of P6 carries the waves' total maps)
     } else {   // score the adaptive solver's trajectory instead
       const float* xe = k.x_ext + (long long)b * T * S;
       for (int i = tid; i < T * S; i += NT) s_x[i] = xe[i];
@@ -1288,7 +1412,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
         t_inv[c] = k.sigtab[CTn + i]; t_lg[c] = k.sigtab[2 * CTn + i]; t_ds[c] = k.sigtab[3 * CTn + i];
       }
     }
-    __syncthreads();
+    BAR();
     STAMP(5);
     if (k.x_out) {
       float* xo = k.x_out + (long long)b * T * S;
@@ -1364,12 +1488,12 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
       if (RA && !ext) {
         // reference_adjoint: the adjoint recurrence runs on the backward step maps M_n (see radj_M), exchanged / stored through s_A
         // (the forward A is dead; the stage buffer still holds P3's dLoss/dmu for the head-gradient role)
-        __syncthreads();
+        BAR();
         if (own_step || own_last) {
 #pragma unroll
           for (int s = 0; s < S; ++s) s_A[n * S + s] = dv[0][s];
         }
-        __syncthreads();
+        BAR();
         float Mn[S];
         if (own_step) {
           const float hb = -(s_ts[R * (n + 1)] - s_ts[R * n]);
@@ -1379,13 +1503,13 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
             Mn[s] = radj_M(method, hb, D);
           }
         }
-        __syncthreads();
+        BAR();
         if (own_step) {
 #pragma unroll
           for (int s = 0; s < S; ++s) s_A[n * S + s] = Mn[s];
         }
       }
-      __syncthreads();
+      BAR();
       STAMP(6);
       // ---- P4: adjoint scan (wave 0) || head-weight gradients (waves >= 1) ------------------------------
       if (!ext && tid < 64) wave_affine_scan<S, true, wave_scan_cl(T_)>(s_A, s_lam, T, tid);
@@ -1409,7 +1533,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           s_hp[e] = a0 + a1;
         }
       }
-      __syncthreads();
+      BAR();
       STAMP(7);
       if (!ext) {
       // ---- P5: reverse mode of the step coefficients (thread n <-> step n) ------------------------------
@@ -1421,7 +1545,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           s_st[n * SP + S + s] = dv[0][s];
         }
       }
-      __syncthreads();
+      BAR();
       float g3a[S], g3d[S];   // contribution to the NEXT step's first stage (shared evaluation a(t_{n+1}))
 #pragma unroll
       for (int s = 0; s < S; ++s) { g3a[s] = 0.f; g3d[s] = 0.f; }
@@ -1483,7 +1607,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           s_gp0[j] = gh0;
         }
       }
-      __syncthreads();   // every read of A | x | lam | st is done: the block becomes the sample rows G[nt][2S]
+      BAR();   // every read of A | x | lam | st is done: the block becomes the sample rows G[nt][2S]
       if (tid < ode_pad_rows(n_stage_t, NT, S) * 2 * S) s_G[n_stage_t * GP + tid] = 0.f;   // zero pad rows: every P6 chunk is full
       if (need_next && own_step) {
 #pragma unroll
@@ -1492,7 +1616,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           s_G[R * (n + 1) * GP + S + s] = g3d[s];
         }
       }
-      __syncthreads();
+      BAR();
       if (own_step || own_last) {
         if (need_next && n >= 1) {
 #pragma unroll
@@ -1515,7 +1639,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 2 * S; ++c) s_G[(n_stage_t - 1) * GP + c] = 0.f;
       }
-      __syncthreads();
+      BAR();
       STAMP(8);
       // ---- P6: contraction of the sample rows with the hidden layer -------------------------------------
       //   GM[r][j] = sum_{m: unit j on} g[m][r],  GT[r][j] = sum_{m: unit j on} g[m][r] t_m   (unit H = constant 1: the head biases)
@@ -1570,7 +1694,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           s_ct[q * 4 * S + r] = cg;
           s_ct[q * 4 * S + 2 * S + r] = cgt;
         }
-        __syncthreads();
+        BAR();
         // (A') shape-specialised kernels: one lane per column turns the chunk sums into exclusive prefix sums (in place; row NQ = the
         // total) and suffix sums (in the event arrays of P0c / P1, dead by now), each column held in registers meanwhile -- (B) then
         // reads ONE row instead of adding up to NQ.  Still only additions on a unit's "on" side.
@@ -1593,7 +1717,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
             for (int q = 31; q >= 0; --q)
               if (q < NQ) { rs += cq[q]; s_sx[q * 4 * S + tid] = rs; }
           }
-          __syncthreads();
+          BAR();
         }
         // (B) lane (unit j, channel r): whole chunks on the unit's "on" side + the samples of the chunk its switching index cuts.
         //     Only additions on the "on" side: no total-minus-prefix cancellation.  Fixed trip counts, masked adds.
@@ -1697,7 +1821,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           d10 = __builtin_amdgcn_mfma_f32_16x16x4f32(gt, b0, d10, 0, 0, 0);
           d11 = __builtin_amdgcn_mfma_f32_16x16x4f32(gt, b1, d11, 0, 0, 0);
         }
-        __syncthreads();   // all waves are past their last read of G: the tiles go over it, [wave][tile][reg][lane]
+        BAR();   // all waves are past their last read of G: the tiles go over it, [wave][tile][reg][lane]
         float* tl = s_G + wv * 1024;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1706,7 +1830,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           tl[(2 * 4 + i) * 64 + lane] = d10[i];
           tl[(3 * 4 + i) * 64 + lane] = d11[i];
         }
-        __syncthreads();
+        BAR();
         // D[row = 4 (lane >> 4) + i][col = lane & 15]: element (which, r, j) sits in tile 2 which + (j >> 4), reg r & 3, lane 16 (r >> 2) + (j & 15)
         for (int e = tid; e < 2 * 2 * S * 32; e += NT) {
           const int which = e / (2 * S * 32), rem = e - which * (2 * S * 32), r = rem >> 5, j = rem & 31;
@@ -1716,7 +1840,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           s_gm[(which * 2 * S + r) * 32 + j] = v;
         }
       }
-      __syncthreads();
+      BAR();
       STAMP(9);
       // (C) into the gradient segment: head weights / biases, dLoss/du (P7 reads it), time column of the hidden layer
       {
@@ -1756,7 +1880,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           if (tid >= 64 && tid < 64 + 2 * S) accum((tid - 64) < S ? k.o_bg + (tid - 64) : k.o_bd + (tid - 64 - S), 0.f);
         }
       }
-      __syncthreads();
+      BAR();
       STAMP(17);
       // ---- P7: small nets (init net, z-part of the hidden layer, priors) and the latent gradient ----------
       if (tid < 64) {
@@ -1894,7 +2018,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
       }
       STAMP(20);
     }
-    __syncthreads();
+    BAR();
     STAMP(21);
     if (BWD && k.g_pre != nullptr && tid >= 64 && tid < 64 + k.Hc) {
       // encoder heads + tanh, backward (models/encoder_conv.py:48-51): thread <-> hidden unit.  s_gzl / s_gpl[L..] are next
@@ -1938,7 +2062,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   if (ts_bad) loss_acc = __builtin_nanf("");
   const float lw = wave_sum(loss_acc);
   if ((tid & 63) == 0) s_red[tid >> 6] = lw;
-  __syncthreads();
+  BAR();
   STAMP(22);
   if (tid == 0) {
     float loss = 0.f;
@@ -1953,9 +2077,9 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   STAMP(11);
 }
 
-template <int S, int H, bool BWD, int T_, int C_, int L_, int Q_, int M_, bool RA, bool ONE, int ALG, int PK = 1, bool ENCF = false>
+template <int S, int H, bool BWD, int T_, int C_, int L_, int Q_, int M_, bool RA, bool ONE, int ALG, int PK = 1, bool ENCF = false, bool SOFTB = false>
 hipError_t launch_one(const OdeK& k, int grid, int nthreads, size_t lds, hipStream_t stream) {
-  auto fn = ode_elbo_kernel<S, H, BWD, T_, C_, L_, Q_, M_, RA, ONE, ALG, PK, ENCF>;
+  auto fn = ode_elbo_kernel<S, H, BWD, T_, C_, L_, Q_, M_, RA, ONE, ALG, PK, ENCF, SOFTB>;
   (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   SLODE_LAUNCH("ode_elbo", fn, dim3(grid), dim3(nthreads), lds, stream, k.stage_t, k.pseg, k.loc ? k.loc : k.z_in, k.loc ? k.scale : nullptr,
                k.eps, k.u, k.sigtab ? k.sigtab : k.cstd, k);
@@ -2146,9 +2270,20 @@ hipError_t slode_launch_ode(const OdeLaunch& a, hipStream_t stream, char* err, s
   }
   // fused encoder forward (metric shape, loop-free, folded encoder path): the caller skipped the enc_fwd2 launch
   if (a.enc_fuse) {
-    if (!slode_ode_can_fuse_encoder(s, bwd, a.grid) || a.alg != 0 || a.x_ext || a.force_generic || a.force_loop || a.pack) {
+    if (!slode_ode_can_fuse_encoder(s, bwd, a.grid) || a.alg != 0 || a.x_ext || a.force_generic || a.force_loop || (a.pack && a.pack < 10)) {
       snprintf(err, errlen, "ode kernel: the fused encoder forward has no instantiation for this launch");
       return hipErrorInvalidValue;
+    }
+    // packed forms with the shared encoder pass and per-trajectory barriers (SOFTB): pack = 12 / 14 -> 2 / 4 trajectories per workgroup
+    const int pk = a.pack == 14 ? 4 : (a.pack == 12 ? 2 : 1);
+    const size_t lds_pk = (size_t)pk * lds + (size_t)pk * 256 + 64;
+    if (pk > 1 && s.B % pk == 0 && lds_pk <= 160 * 1024) {
+      if (pk == 4) {
+        if (ra) return launch_one<5, 25, true, 200, 3, 8, 3, SLODE_RK4, true, true, 0, 4, true, true>(k, a.grid / 4, nthreads * 4, lds_pk, stream);
+        return launch_one<5, 25, true, 200, 3, 8, 3, SLODE_RK4, false, true, 0, 4, true, true>(k, a.grid / 4, nthreads * 4, lds_pk, stream);
+      }
+      if (ra) return launch_one<5, 25, true, 200, 3, 8, 3, SLODE_RK4, true, true, 0, 2, true, true>(k, a.grid / 2, nthreads * 2, lds_pk, stream);
+      return launch_one<5, 25, true, 200, 3, 8, 3, SLODE_RK4, false, true, 0, 2, true, true>(k, a.grid / 2, nthreads * 2, lds_pk, stream);
     }
     if (ra) return launch_one<5, 25, true, 200, 3, 8, 3, SLODE_RK4, true, true, 0, 1, true>(k, a.grid, nthreads, lds + 256, stream);
     return launch_one<5, 25, true, 200, 3, 8, 3, SLODE_RK4, false, true, 0, 1, true>(k, a.grid, nthreads, lds + 256, stream);

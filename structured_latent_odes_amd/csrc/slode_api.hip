@@ -508,7 +508,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     fl.counter = w.counter;
     fl.sigtab = aux_mode ? nullptr : w.sigtab;
     // the loop-free ODE kernel of the metric shape runs the encoder forward of its own trajectories (ode_kernel.hip, ENCF): fold only
-    enc_fused = !aux_mode && !dp5 && bwd && h->enc_fuse && !h->ode_loop && !h->ode_generic && h->ode_alg == 0 && !h->ode_pack && !x_out &&
+    enc_fused = !aux_mode && !dp5 && bwd && h->enc_fuse && !h->ode_loop && !h->ode_generic && h->ode_alg == 0 && (h->ode_pack == 0 || h->ode_pack >= 10) && !x_out &&
                 slode_ode_can_fuse_encoder(*s, bwd, w.ode_grid);
     fl.skip_enc = enc_fused ? 1 : 0;
     e = slode_launch_fold_fwd(fl, st);

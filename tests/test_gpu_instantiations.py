@@ -135,6 +135,20 @@ def test_packed_arm_of_the_metric_shape(mode, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", ["exact", "reference_adjoint"])
+@pytest.mark.parametrize("pack", ["12", "14"])
+def test_packed_arms_with_shared_encoder_pass_and_own_barriers(pack, mode, monkeypatch):
+    """Round 4: 2 (SLODE_ODE_PACK=12) or 4 (=14) trajectories per workgroup on disjoint waves, ONE pass over W_eff for
+    all of them in the set-up (the encoder forward), then independent progress -- every trajectory on barriers of its own (an LDS arrival
+    counter per trajectory, soft_barrier in ode_kernel.hip) instead of the workgroup's s_barrier.  Same step as the shipped form: against the
+    oracle, NaN-poisoned workspace, bitwise repeat (inside _run), and against the shipped kernel to summation order."""
+    c = _case("c1_cvs_T200_L8_rk4", mode)
+    a = _run(c, mode, {"SLODE_ODE_PACK": pack}, monkeypatch)
+    b = _run(c, mode, {}, monkeypatch)
+    assert abs(a[0].item() - b[0].item()) <= 2e-6 * abs(b[0].item())
+    assert _rel(a[1], b[1]) < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["exact", "reference_adjoint"])
 def test_metric_shape_with_the_separate_encoder_launch(mode, monkeypatch):
     """The metric shape's loop-free kernel runs the encoder forward of its own trajectory by default (ENCF, ode_kernel.hip);
     SLODE_ENC_FUSE=0 restores the separate enc_fwd2 launch.  Both score the same step: each against the oracle, and the two losses agree

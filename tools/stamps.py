@@ -42,7 +42,9 @@ if hasattr(lib, "slode_debug_stamps_ode_late") and B > 1000:
         late = list(buf2)
 print("== ode kernel, workgroup 0 (us)   [second column: workgroup 1000, last residency slot of its CU]")
 tot = 0.0
-for lab, i, j in (("setup: table loads -> LDS (+ encoder forward when fused)", 0, 13), ("setup: zero acc + barrier", 13, 14), ("setup: w_t, table check", 14, 1),
+for lab, i, j in (("  setup detail: start -> set-up loads requested", 0, 23), ("  setup detail: -> encoder products done (loads returned)", 23, 24),
+                  ("  setup detail: -> wave sums + tanh stored", 24, 25), ("  setup detail: -> LDS-DMA drained (vmcnt 0)", 25, 13),
+                  ("setup: table loads -> LDS (+ encoder forward when fused)", 0, 13), ("setup: zero acc + barrier", 13, 14), ("setup: w_t, table check", 14, 1),
                   ("P0a latent sample / log-probs", 1, 15), ("P0b u, init hidden, switching indices, rank", 15, 16),
                   ("P0c x0 || piecewise-linear table", 16, 2), ("P1 stage evaluations + exchange", 2, 3), ("P1 step coefficients", 3, 4),
                   ("P2 forward scan", 4, 5), ("P3 heads + likelihood", 5, 6), ("P4 adjoint scan | head grads", 6, 7),
@@ -52,7 +54,8 @@ for lab, i, j in (("setup: table loads -> LDS (+ encoder forward when fused)", 0
     if v[i] and v[j]:
         extra = "  %8.2f" % ((late[j] - late[i]) / 100.0) if late and late[i] and late[j] else ""
         print("  %-58s %8.2f%s" % (lab, (v[j] - v[i]) / 100.0, extra))
-        tot += (v[j] - v[i]) / 100.0
+        if not lab.startswith("  setup detail"):
+            tot += (v[j] - v[i]) / 100.0
 print("  %-58s %8.2f" % ("total", tot))
 import numpy as np
 n = 1024
