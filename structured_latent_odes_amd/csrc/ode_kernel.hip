@@ -832,12 +832,15 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     STAMP(24);   // (packed form: this wave's W_eff x observation products done, i.e. its loads have returned)
     if (ENCF && PK == 1) {
       static_assert(!ENCF || ode_threads_for(T_ ? T_ : 1, Q_ ? Q_ : 1, C_ ? C_ : 1, S) == 256, "fused encoder forward: four waves");
-      static_assert(!ENCF || ((ECT & 1) == 0 && 2 * (L_ ? L_ : 1) * 16 <= 256), "fused encoder forward: even C*T, 16 lanes per head output");
+      static_assert(!ENCF || ((ECT & 3) == 0 && 2 * (L_ ? L_ : 1) * 16 <= 256), "fused encoder forward: C*T a multiple of 4, 16 lanes per head output");
+      // 16 bytes per lane and request (global_load_dwordx4: 1 KiB per wave instruction, the width the memory pipeline is built for; the
+      // round-3 form asked for 8 bytes per lane, five requests per row instead of three)
+      constexpr int ENU4 = (ECT + 255) / 256;
       const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, Hc = k.Hc;
       const float* xrow = k.obs + (long long)min(b_first, k.B - 1) * ECT;   // dense row, memory order = the column order of W_eff
-      f32x2 xv[ENU];
+      f32x4 xv[ENU4];
 #pragma unroll
-      for (int u = 0; u < ENU; ++u) xv[u] = *reinterpret_cast<const f32x2*>(xrow + min(2 * lane + 128 * u, ECT - 2));
+      for (int u = 0; u < ENU4; ++u) xv[u] = *reinterpret_cast<const f32x4*>(xrow + min(4 * lane + 256 * u, ECT - 4));
       {   // head weights (16 lanes per output: lane l16 takes hidden units l16 + 16 q), b_eff of the row this lane will finish, head bias
         const int o = tid >> 4, l16 = tid & 15, which = o / L, l = o - which * L;
         const float* W = (which ? k.enc_zls_w : k.enc_zloc_w) + l * Hc;
@@ -849,25 +852,25 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) e_acc[r] = 0.f;
       const float* wbase = k.enc_weff + (long long)(wv * ERW) * ECT;
-      constexpr int EB0 = 5;   // rows per batch: 5 x ENU float2 = 50 registers in flight, one batch at a time (the kernel's budget is 128)
+      constexpr int EB0 = 5;   // rows per batch: 5 x ENU4 float4 = 60 registers in flight, one batch at a time (the kernel's budget is 128)
 #pragma unroll
       for (int r0 = 0; r0 < ERW; r0 += EB0) {
-        f32x2 w[EB0][ENU];
+        f32x4 w[EB0][ENU4];
 #pragma unroll
         for (int r = 0; r < EB0; ++r)
 #pragma unroll
-          for (int u = 0; u < ENU; ++u) {
+          for (int u = 0; u < ENU4; ++u) {
             const int row = min(wv * ERW + r0 + r, Hc - 1) - wv * ERW;   // (rows past Hc: a valid address, never used)
-            w[r][u] = (r0 + r < ERW) ? *reinterpret_cast<const f32x2*>(wbase + (long long)row * ECT + min(2 * lane + 128 * u, ECT - 2)) : f32x2{0.f, 0.f};
+            w[r][u] = (r0 + r < ERW) ? *reinterpret_cast<const f32x4*>(wbase + (long long)row * ECT + min(4 * lane + 256 * u, ECT - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
         for (int r = 0; r < EB0; ++r)
 #pragma unroll
-          for (int u = 0; u < ENU; ++u) {
+          for (int u = 0; u < ENU4; ++u) {
             if (r0 + r < ERW) {
-              const bool in = 2 * lane + 128 * u < ECT;
-              const float wx = in ? w[r][u].x : 0.f, wy = in ? w[r][u].y : 0.f;
-              e_acc[r0 + r] = fmaf(wy, xv[u].y, fmaf(wx, xv[u].x, e_acc[r0 + r]));
+              const bool in = 4 * lane + 256 * u < ECT;
+              const f32x4 wv4 = in ? w[r][u] : f32x4{0.f, 0.f, 0.f, 0.f};
+              e_acc[r0 + r] = fmaf(wv4.w, xv[u].w, fmaf(wv4.z, xv[u].z, fmaf(wv4.y, xv[u].y, fmaf(wv4.x, xv[u].x, e_acc[r0 + r]))));
             }
           }
         // the next batch's loads must not be issued over this batch's registers: its sums are finished ahead of a compiler barrier
