@@ -288,6 +288,15 @@ int slode_grad_apply(slode_handle h, const slode_shape* s, const slode_layout* l
                      const float* payload, float* loss_out, float* grads, void* workspace, size_t workspace_bytes, const slode_adam* adam,
                      void* stream);
 
+/* Measured arm, OFF by default (SLODE_FOLD_NEXT=1 in the environment of slode_create turns it on): the launch that applies a step's Adam
+ * update also folds the UPDATED encoder weights (W_eff & co.: csrc/encoder_fused.hip) and leaves them in the workspace, so consecutive
+ * training steps on one (workspace, params) pair -- slode_svi_step / slode_elbo_adam_step / slode_aux_step / slode_grad_apply with Adam --
+ * start without a fold launch.  Bitwise the same results; on MI355X the hand-offs inside the launch cost 6.0 us where the fold launch costs
+ * 5.5, hence off.  When it is on, the workspace carries state from step to step and the library notices every weight change IT
+ * makes; a caller that writes the parameter vector (or the workspace) itself between two steps -- checkpoint load, `load_state_dict`, its
+ * own optimizer -- calls slode_fold_invalidate first.  With the arm off the call is a no-op. */
+int slode_fold_invalidate(slode_handle h);
+
 /* The handle's noise generator (replaces torch's global generator behind `rsample`): Philox-4x32-10 keyed by `seed`; the draw of
  * (drawing call n, trajectory b, latent index l) is word l & 3 -> Box-Muller of block [b + first_trajectory | l >> 2 | n] -- stateless,
  * so results do not depend on the grid or on how a global batch is sharded (data parallel: every rank passes the global index of its

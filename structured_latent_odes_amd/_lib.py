@@ -60,7 +60,7 @@ EXPORTS = ["slode_version", "slode_create", "slode_destroy", "slode_last_error",
            "slode_elbo_step", "slode_adam_step", "slode_profile_enable", "slode_profile_read", "slode_dynamics_eval", "slode_elbo_adam_step", "slode_aux_step", "slode_adam_region",
            "slode_initialize_state", "slode_prior_nets", "slode_label_heads", "slode_dopri5_step_counts", "slode_decode_heads_bwd",
            "slode_svi_step", "slode_rng_seed", "slode_rng_set_counter", "slode_rng_get", "slode_rng_normal", "slode_sample_normal",
-           "slode_grad_payload_floats", "slode_grad_partial", "slode_grad_apply"]
+           "slode_grad_payload_floats", "slode_grad_partial", "slode_grad_apply", "slode_fold_invalidate"]
 
 _lib = None
 
@@ -119,6 +119,7 @@ def load():
     lib.slode_rng_get.argtypes = [VP, P(C.c_uint64), P(C.c_int64), P(C.c_uint64)]
     lib.slode_rng_normal.argtypes = [VP, C.c_uint64, C.c_int32, C.c_int32, VP, VP, VP]
     lib.slode_sample_normal.argtypes = [VP, C.c_int32, C.c_int32, VP, VP, VP, VP]
+    lib.slode_fold_invalidate.argtypes = [VP]
     lib.slode_grad_payload_floats.argtypes = [P(Shape), P(Layout), C.c_int]
     lib.slode_grad_payload_floats.restype = C.c_size_t
     lib.slode_grad_partial.argtypes = [VP, P(Shape), P(Layout), C.c_int, VP, VP, VP, P(Batch), VP, VP, C.c_size_t, VP]

@@ -57,6 +57,54 @@ __device__ __forceinline__ int kappa_of(const FoldK& k, int c, int t) { return k
 constexpr int WPB = 128;   // W_eff outputs per block of weff_kernel
 constexpr int WFG = 4;     // threads per output (filter groups): 8 waves per CU instead of 4 -- the output loop is latency-bound
 constexpr int WNT = WPB * WFG;
+// One output W_eff[m][kappa(c, t)] by the four lanes of a quad (fh = lane of the quad = group of filters; fixed order: the quad's partial
+// sums meet in two DPP adds).  wlm: row m of lin.weight [F][n_pool]; s_wp: w' [F][C][JM].  Shared by weff_kernel and by the in-launch fold
+// of enc_chain_kernel: the same operations in the same order, hence the same bits.
+template <int JM>
+__device__ __forceinline__ float weff_out(const FoldK& k, const float* __restrict__ wlm, const float* __restrict__ s_wp, int c, int t, int fh) {
+  const int C = k.C, fper = (k.F + WFG - 1) / WFG;
+  float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 2
+  for (int f = fh * fper; f < min(k.F, (fh + 1) * fper); ++f) {
+    const float* wl = wlm + f * k.n_pool;
+    const float* wp = s_wp + (f * C + c) * JM;
+    float v[JM];
+#pragma unroll
+    for (int j = 0; j < JM; ++j) v[j] = wl[min(max(t - j, 0), k.n_pool - 1)];   // unconditional, clamped
+#pragma unroll
+    for (int j = 0; j < JM; j += 2) {
+      acc0 = fmaf((t - j >= 0 && t - j < k.n_pool) ? v[j] : 0.f, wp[j], acc0);
+      if (j + 1 < JM) acc1 = fmaf((t - j - 1 >= 0 && t - j - 1 < k.n_pool) ? v[j + 1] : 0.f, wp[j + 1], acc1);
+    }
+  }
+  float r = acc0 + acc1;
+  r += dpp_f<0xB1>(r);   // quad_perm [1,0,3,2]
+  r += dpp_f<0x4E>(r);   // quad_perm [2,3,0,1]
+  return r;
+}
+// One wave: rowsum[m][f] for every f, then b_eff[m] (wlm: row m of lin.weight; conv_b / lin_b_m: the biases to fold in).  Shared likewise.
+__device__ __forceinline__ void rowsum_beff_wave(const FoldK& k, const float* __restrict__ wlm, int m, int lane, const float* __restrict__ conv_b,
+                                                 float lin_b_m) {
+  // all F partial sums advance together so F loads are in flight per pass (a serial f loop costs one HBM round trip per filter)
+  float sv[SLODE_MAX_F];
+#pragma unroll
+  for (int f = 0; f < SLODE_MAX_F; ++f) sv[f] = 0.f;
+  for (int q = lane; q < k.n_pool; q += 64) {
+#pragma unroll
+    for (int f = 0; f < SLODE_MAX_F; ++f) {
+      const float v = wlm[min(f, k.F - 1) * k.n_pool + q];
+      sv[f] += (f < k.F) ? v : 0.f;
+    }
+  }
+  static_assert(SLODE_MAX_F == 16, "wave_sum16 reduces the SLODE_MAX_F = 16 filter sums");
+  const float sf = wave_sum16(sv, lane);     // lane holds rowsum[m][(lane >> 2) & 15]
+  const int fl = (lane >> 2) & 15;
+  if ((lane & 3) == 0 && fl < k.F) k.rowsum[m * k.F + fl] = sf;
+  float be = ((lane & 3) == 0 && fl < k.F) ? conv_b[min(fl, k.F - 1)] * sf : 0.f;
+  be = wave_sum(be) + lin_b_m;
+  if (lane == 0) k.beff[m] = be;
+}
+
 template <int JM>  // compile-time bound on J = K + P - 1 (14 for every reference config)
 // (pl_*: the pointers of the kernel's first loads as leading arguments -- preloaded into SGPRs at wave launch, see ode_elbo_kernel)
 __global__ void __launch_bounds__(WNT) weff_kernel(const float* __restrict__ pl_conv_w, const float* __restrict__ pl_lin_w, const FoldK k,
@@ -65,7 +113,9 @@ __global__ void __launch_bounds__(WNT) weff_kernel(const float* __restrict__ pl_
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [stage_rows ? the block's lin.weight rows : 0]
   const int tid = threadIdx.x, J = k.J, C = k.C, K = k.K;
   const float fP = (float)k.P;
-  if (blockIdx.x == 0 && tid < 8 && k.counter) k.counter[32 * tid] = 0u;   // arrival counters of this step's chain blocks (one per filter pair, 128 B apart)
+  // arrival counters of the chain launch, 128 B apart: slots 0..7 one per filter pair; the in-launch fold's: 8 conv pairs done, 9 riders
+  // done, 16 + m the blocks of hidden unit m
+  if (blockIdx.x == 0 && tid < 16 + SLODE_MAX_HC && k.counter) k.counter[32 * tid] = 0u;
   STAMP(0);
   const int n_w = k.Hc * k.CT;
   const int nb_w = (n_w + WPB - 1) / WPB, nb_rs = (k.Hc + WNT / 64 - 1) / (WNT / 64);
@@ -128,29 +178,13 @@ __global__ void __launch_bounds__(WNT) weff_kernel(const float* __restrict__ pl_
     // WPB = 128 outputs per block, WFG = 4 threads per output (each a group of the filters): ~250 blocks fill the 256 CUs.  The four
     // threads of an output are one quad: their partial sums meet in two DPP adds (fixed order), no LDS, no barrier.
     static_assert(WFG == 4, "the filter groups of an output are the lanes of a quad");
-    const int el = tid >> 2, fh = tid & 3, fper = (k.F + WFG - 1) / WFG;
+    const int el = tid >> 2, fh = tid & 3;
     const int e = min((int)blockIdx.x * WPB + el, n_w - 1);
     const int m = e / k.CT, kap = e - m * k.CT;
     int c, t;
     if (k.t_major) { t = kap / C; c = kap - t * C; } else { c = kap / k.T; t = kap - c * k.T; }
-    float acc0 = 0.f, acc1 = 0.f;
     const float* wlm = stage_rows ? s_lw + (m - m0) * k.FQ : k.lin_w + (long long)m * k.FQ;
-#pragma unroll 2
-    for (int f = fh * fper; f < min(k.F, (fh + 1) * fper); ++f) {
-      const float* wl = wlm + f * k.n_pool;
-      const float* wp = s_wp + (f * C + c) * JM;
-      float v[JM];
-#pragma unroll
-      for (int j = 0; j < JM; ++j) v[j] = wl[min(max(t - j, 0), k.n_pool - 1)];   // unconditional, clamped
-#pragma unroll
-      for (int j = 0; j < JM; j += 2) {
-        acc0 = fmaf((t - j >= 0 && t - j < k.n_pool) ? v[j] : 0.f, wp[j], acc0);
-        if (j + 1 < JM) acc1 = fmaf((t - j - 1 >= 0 && t - j - 1 < k.n_pool) ? v[j + 1] : 0.f, wp[j + 1], acc1);
-      }
-    }
-    float r = acc0 + acc1;
-    r += dpp_f<0xB1>(r);   // quad_perm [1,0,3,2]
-    r += dpp_f<0x4E>(r);   // quad_perm [2,3,0,1]
+    const float r = weff_out<JM>(k, wlm, s_wp, c, t, fh);
     if (fh == 0 && (int)blockIdx.x * WPB + el < n_w) k.weff[e] = r;
     STAMP(2);
   } else if ((int)blockIdx.x >= nb_w + nb_rs) {
@@ -167,27 +201,7 @@ __global__ void __launch_bounds__(WNT) weff_kernel(const float* __restrict__ pl_
   } else {
     // one wave per hidden unit m: rowsum[m][f] for every f, then b_eff[m]
     const int m = ((int)blockIdx.x - nb_w) * (WNT / 64) + (tid >> 6), lane = tid & 63;
-    if (m < k.Hc) {
-      // all F partial sums advance together so F loads are in flight per pass (a serial f loop costs one HBM round trip per filter)
-      float sv[SLODE_MAX_F];
-#pragma unroll
-      for (int f = 0; f < SLODE_MAX_F; ++f) sv[f] = 0.f;
-      const float* wlm = k.lin_w + (long long)m * k.FQ;
-      for (int q = lane; q < k.n_pool; q += 64) {
-#pragma unroll
-        for (int f = 0; f < SLODE_MAX_F; ++f) {
-          const float v = wlm[min(f, k.F - 1) * k.n_pool + q];
-          sv[f] += (f < k.F) ? v : 0.f;
-        }
-      }
-      static_assert(SLODE_MAX_F == 16, "wave_sum16 reduces the SLODE_MAX_F = 16 filter sums");
-      const float sf = wave_sum16(sv, lane);     // lane holds rowsum[m][(lane >> 2) & 15]
-      const int fl = (lane >> 2) & 15;
-      if ((lane & 3) == 0 && fl < k.F) k.rowsum[m * k.F + fl] = sf;
-      float be = ((lane & 3) == 0 && fl < k.F) ? k.conv_b[min(fl, k.F - 1)] * sf : 0.f;
-      be = wave_sum(be) + k.lin_b[m];
-      if (lane == 0) k.beff[m] = be;
-    }
+    if (m < k.Hc) rowsum_beff_wave(k, k.lin_w + (long long)m * k.FQ, m, lane, k.conv_b, k.lin_b[m]);
   }
 }
 
@@ -459,11 +473,19 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
   const int tid = threadIdx.x;
   const int NFC = (k.F + FPC - 1) / FPC, n_chain = k.Hc * NFC;
   if ((int)blockIdx.x >= n_chain) {   // rider block
-    const int r = (int)blockIdx.x - n_chain, i = tl.lin_b + r * CNT + tid;
+    // (normally one element per rider thread; the in-launch fold form may run fewer, looping riders so that the whole grid is resident)
+    const int r = (int)blockIdx.x - n_chain, n_rid = (int)gridDim.x - n_chain;
     if (r == 0) STAMP_ANY(26);
-    if (i < tl.n_total) tail_element(tl, i);
-    else if (i == tl.n_total) tail_loss(tl);
+    for (int i = tl.lin_b + r * CNT + tid; i <= tl.n_total; i += n_rid * CNT) {
+      if (i < tl.n_total) tail_element(tl, i);
+      else tail_loss(tl);
+    }
     if (r == 0) STAMP_ANY(27);
+    if (tl.fold_next) {   // this block's new parameter values (lin.bias: stored agent-scope) have reached L2; count it in
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(tl.done + 32 * 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return;
   }
   const int m = (int)blockIdx.x % k.Hc, fci = (int)blockIdx.x / k.Hc, f0 = fci * FPC, nf = min(FPC, k.F - f0);
@@ -591,6 +613,9 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
   __syncthreads();
   const bool last = s_last != 0;
   if (last) STAMP_ANY(24);
+  // the pair's counter goes back to zero for the next launch on this workspace (the last block is the last to touch it: a step that finds
+  // the fold of the current weights already in the workspace has no fold launch to zero it)
+  if (last && tid == 0) tl.counter[32 * fci] = 0u;
   // the last block to arrive is the one every other block's work waits behind: its loads of the Hc conv rows (4 lanes per element, each
   // summing every 4th row in fixed order; 16 sc1 loads in flight per lane) go out now and fly during its own piece's Adam pass
   constexpr int NRV = 16;
@@ -610,7 +635,9 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
         const float g = s_glw[e];
         const float mi = am[u] + tl.ad.one_minus_b1 * (g - am[u]);
         const float vi = av[u] * tl.ad.b2 + tl.ad.one_minus_b2 * g * g;
-        tl.ad.p[lw0 + e] = ap[u] - tl.ad.step_size * (mi / (sqrtf(vi) / tl.ad.sqrt_bc2 + tl.ad.eps));
+        const float pn = ap[u] - tl.ad.step_size * (mi / (sqrtf(vi) / tl.ad.sqrt_bc2 + tl.ad.eps));
+        if (tl.fold_next) __hip_atomic_store(tl.ad.p + lw0 + e, pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by the row's other blocks)
+        else tl.ad.p[lw0 + e] = pn;
         tl.ad.m[lw0 + e] = mi;
         tl.ad.v[lw0 + e] = vi;
       }
@@ -621,12 +648,19 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
       float mi = tl.ad.m[i], vi = tl.ad.v[i];
       mi = mi + tl.ad.one_minus_b1 * (g - mi);
       vi = vi * tl.ad.b2 + tl.ad.one_minus_b2 * g * g;
-      tl.ad.p[i] = tl.ad.p[i] - tl.ad.step_size * (mi / (sqrtf(vi) / tl.ad.sqrt_bc2 + tl.ad.eps));
+      const float pn = tl.ad.p[i] - tl.ad.step_size * (mi / (sqrtf(vi) / tl.ad.sqrt_bc2 + tl.ad.eps));
+      if (tl.fold_next) __hip_atomic_store(tl.ad.p + i, pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else tl.ad.p[i] = pn;
       tl.ad.m[i] = mi;
       tl.ad.v[i] = vi;
     }
   }
   STAMP(22);
+  if (tl.fold_next) {   // this block's piece of the new lin.weight row (stored agent-scope above) has reached L2: count it in for row m
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(tl.done + 32 * (16 + m), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (last) {   // conv.weight, conv.bias of this filter pair
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (el_on) {
@@ -646,13 +680,125 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
       if (tl.ad.p) {   // adam_apply with the prefetched state
         const float mi = cm + tl.ad.one_minus_b1 * (g - cm);
         const float vi = cv * tl.ad.b2 + tl.ad.one_minus_b2 * g * g;
-        tl.ad.p[ci] = cp - tl.ad.step_size * (mi / (sqrtf(vi) / tl.ad.sqrt_bc2 + tl.ad.eps));
+        const float pn = cp - tl.ad.step_size * (mi / (sqrtf(vi) / tl.ad.sqrt_bc2 + tl.ad.eps));
+        if (tl.fold_next) __hip_atomic_store(tl.ad.p + ci, pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by every block's fold)
+        else tl.ad.p[ci] = pn;
         tl.ad.m[ci] = mi;
         tl.ad.v[ci] = vi;
       }
     }
     STAMP_ANY(25);
   }
+  if (!tl.fold_next) return;
+  // ---- FOLD-NEXT: W_eff, rowsum, b_eff, w' of the UPDATED weights, for the next step (which then has no fold launch) ---------------------
+  // Every parameter the fold reads was stored agent-scope (sc1) by its owner in this launch: this block's lin.weight piece above, the conv
+  // taps / biases by the pairs' last blocks, lin.bias by the rider blocks.  Hand-off as for the conv rows: every storing wave drains
+  // (s_waitcnt vmcnt(0)), barrier, ONE lane adds to the launch's arrival counter; ONE wave polls it with sc1 loads until every block of
+  // the launch has arrived (all of them are resident: the launcher enables this form only then), barrier, sc1 loads of the data.
+  // Arrivals (all generation-based, never reset: gen = the handle's count of such launches on this workspace): row m's NFC blocks on
+  // slot 16 + m (above), the NFC last blocks of the filter pairs on slot 8 (here, behind their conv Adam), the rider blocks on slot 9.
+  // No counter sees more than a handful of adds: a single launch-wide counter put 255 read-modify-writes behind 250 pollers of the same
+  // line (chain launch 8.5 -> 17.4 us, profiles/r04_c_ab7_fold_next_single_counter.log).
+  if (last) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // (the pair whose add completes the count raises a FLAG on a line of its own, slot 10: the 250 waiting blocks poll that line, which is
+    //  written once -- polling the counter itself puts the five adds behind the pollers' reads of the same line)
+    if (tid == 0 && __hip_atomic_fetch_add(tl.done + 32 * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == tl.done_target * (unsigned int)NFC)
+      __hip_atomic_store(tl.done + 32 * 10, tl.done_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __shared__ int s_fold_ok;
+  float* s_row = s_glw + ((FPC * n_pool + 3) & ~3);   // [F][n_pool] row m of the new lin.weight
+  float* s_wpf = s_row + ((FQ + 3) & ~3);              // [F][C][JM]  new w'
+  const unsigned int gen = tl.done_target, t_row = gen * (unsigned int)NFC, t_rid = gen * (unsigned int)tl.n_riders;
+  // bounded waits: the launcher only enables this form when the occupancy query says every block of the launch is resident at once; should
+  // that ever not hold, a wait ends after ~0.3 s and the row is written as NaN (a loud NaN loss in the next step, not a hung GPU)
+  if (tid == 0) {   // (1) the row's other blocks: their pieces of the new lin.weight row
+    int ok = 0;
+    for (int it = 0; it < (1 << 18); ++it) {
+      if ((int)(__hip_atomic_load(tl.done + 32 * (16 + m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - t_row) >= 0) { ok = 1; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    s_fold_ok = ok;
+  }
+  __syncthreads();
+  // the row is requested now (sc1) and flies while the block waits for the conv taps of the slowest filter pair
+  const float* src = tl.ad.p + tl.lin_w + (long long)m * FQ;
+  constexpr int NRQ = 4;
+  float rv4[NRQ];
+#pragma unroll
+  for (int q = 0; q < NRQ; ++q) rv4[q] = __hip_atomic_load(src + min(tid + q * CNT, FQ - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0 && s_fold_ok) {   // (2) every pair's conv taps / biases, and -- the row's first block -- the riders' lin.bias
+    int ok = 0;
+    for (int it = 0; it < (1 << 18); ++it) {
+      const unsigned int b = __hip_atomic_load(tl.done + 32 * 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int c = fci == 0 ? __hip_atomic_load(tl.done + 32 * 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t_rid;
+      if ((int)(b - gen) >= 0 && (int)(c - t_rid) >= 0) { ok = 1; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    s_fold_ok = ok;
+  }
+  __syncthreads();
+  if (!s_fold_ok) {
+    const int per = (CT + NFC - 1) / NFC, k0 = fci * per, k1 = min(CT, k0 + per);
+    for (int kap = k0 + tid; kap < k1; kap += CNT) k.weff[(long long)m * CT + kap] = __builtin_nanf("");
+    return;
+  }
+  STAMP(28);
+  {
+    // the conv taps under this thread's w' entry (sc1), then the stores of both
+    const int n_wp = F * C * JM;
+    const int e = min(tid, n_wp - 1), j = e % JM, fc = e / JM;
+    float tp[SLODE_MAX_P];
+#pragma unroll
+    for (int p = 0; p < SLODE_MAX_P; ++p) {
+      const int kk = j - p;
+      const bool on = p < k.P && j < J && kk >= 0 && kk < K;
+      tp[p] = on ? __hip_atomic_load(tl.ad.p + tl.conv_w + fc * K + min(max(kk, 0), K - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NRQ; ++q)
+      if (tid + q * CNT < FQ) s_row[tid + q * CNT] = rv4[q];
+    for (int i = tid + NRQ * CNT; i < FQ; i += CNT) s_row[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < n_wp) {
+      float sw = 0.f;
+#pragma unroll
+      for (int p = 0; p < SLODE_MAX_P; ++p) sw += tp[p];
+      sw = sw / fP;
+      s_wpf[tid] = sw;
+      if (blockIdx.x == 0 && j < J) k.wprime[fc * J + j] = sw;
+    }
+    for (int e2 = tid + CNT; e2 < n_wp; e2 += CNT) {   // (more entries than threads: long-tap shapes)
+      const int j2 = e2 % JM, fc2 = e2 / JM;
+      float sw = 0.f;
+      for (int p = 0; p < k.P; ++p) {
+        const int kk = j2 - p;
+        if (j2 < J && kk >= 0 && kk < K) sw += __hip_atomic_load(tl.ad.p + tl.conv_w + fc2 * K + kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      sw = sw / fP;
+      s_wpf[e2] = sw;
+      if (blockIdx.x == 0 && j2 < J) k.wprime[fc2 * J + j2] = sw;
+    }
+  }
+  __syncthreads();
+  STAMP(29);
+  {   // this block's share of row m: kappas [fci * per, (fci + 1) * per), four lanes per output exactly as weff_kernel
+    const int per = (CT + NFC - 1) / NFC, k0 = fci * per, k1 = min(CT, k0 + per);
+    for (int el = tid >> 2; k0 + el < k1; el += CNT / 4) {
+      const int kap = k0 + el, fh = tid & 3;
+      int c, t;
+      if (k.t_major) { t = kap / C; c = kap - t * C; } else { c = kap / T; t = kap - c * T; }
+      const float r = weff_out<JM>(k, s_row, s_wpf, c, t, fh);
+      if (fh == 0) k.weff[(long long)m * CT + kap] = r;
+    }
+  }
+  if (fci == 0 && tid < 64) {   // the row's first block: rowsum[m][:] and b_eff[m] with the new conv.bias / lin.bias (sc1: other blocks' stores)
+    float* s_cb = s_wpf + F * C * JM;   // [F] new conv.bias
+    if (tid < F) s_cb[tid] = __hip_atomic_load(tl.ad.p + tl.conv_w + F * C * K + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float lb = __hip_atomic_load(tl.ad.p + tl.lin_b + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rowsum_beff_wave(k, s_row, m, tid, s_cb, lb);   // (same wave: its LDS stores above are read in program order)
+  }
+  STAMP(30);
 }
 
 FoldK make_foldk(const FoldLaunch& a) {
@@ -677,6 +823,29 @@ FoldK make_foldk(const FoldLaunch& a) {
 }  // namespace
 
 int slode_fold_small_count(const slode_shape& s) { return s.Hc + 2 * (s.L * s.Hc + s.L); }
+int slode_chain_blocks(const slode_shape& s, int n_total, int lin_b, int* n_chain) {
+  *n_chain = s.Hc * ((s.F + FPC - 1) / FPC);
+  return *n_chain + (n_total + 1 - lin_b + CNT - 1) / CNT;
+}
+static size_t chain_lds(const slode_shape& s, bool fold_next) {
+  const int n_pool = s.T - s.K + 1 - s.P + 1, J = s.K + s.P - 1, JM = J <= 14 ? 14 : SLODE_MAX_K + SLODE_MAX_P;
+  return sizeof(float) * ((size_t)s.C * s.T + 8 + 2 * ((size_t)FPC * n_pool + 4) + 2 * (size_t)FPC * s.C * JM +
+                          (fold_next ? (size_t)s.F * n_pool + 4 + (size_t)s.F * s.C * JM + SLODE_MAX_F : 0));
+}
+// how many blocks of the chain launch (in-launch fold form) the device holds AT ONCE: the blocks of that form wait for each other, so the
+// form is only used when this covers the whole grid.  The runtime's occupancy query for the instantiation the launch would take.
+int slode_chain_resident_blocks(const slode_shape& s, int num_cu) {
+  const int J = s.K + s.P - 1, JM = J <= 14 ? 14 : SLODE_MAX_K + SLODE_MAX_P;
+  const size_t lds = chain_lds(s, true);
+  int per_cu = 0;
+  hipError_t e = hipErrorInvalidValue;
+  if (s.C == 3 && JM == 14) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, enc_chain_kernel<3, 14>, CNT, lds);
+  else if (s.C == 4 && JM == 14) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, enc_chain_kernel<4, 14>, CNT, lds);
+  else if (s.C == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (enc_chain_kernel<3, SLODE_MAX_K + SLODE_MAX_P>), CNT, lds);
+  else if (s.C == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (enc_chain_kernel<4, SLODE_MAX_K + SLODE_MAX_P>), CNT, lds);
+  if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); return 0; }
+  return per_cu * num_cu;
+}
 
 hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream) {
   FoldK k = make_foldk(a);
@@ -685,7 +854,9 @@ hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream) {
   const size_t max_rows = (size_t)(WPB - 1) / k.CT + 2;   // WPB outputs starting anywhere inside a row of CT
   const int stage_rows = (max_rows * (size_t)k.FQ) * sizeof(float) <= 96 * 1024 ? 1 : 0;
   const size_t wlds = sizeof(float) * (stage_rows ? max_rows * (size_t)k.FQ : 4);
-  if (k.J <= 14) {
+  if (a.fold_skip) {
+    // (the previous step's chain launch folded the current weights: encoder forward only)
+  } else if (k.J <= 14) {
     if (wlds > 48 * 1024) (void)hipFuncSetAttribute((const void*)weff_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds);
     SLODE_LAUNCH("weff", (weff_kernel<14>), dim3(nb_w + nb_r), dim3(WNT), wlds, stream, k.conv_w, k.lin_w, k, stage_rows);
   } else {
@@ -713,9 +884,9 @@ hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream) {
   if (!a.tail) return hipErrorInvalidValue;   // the chain launch always finishes the flat gradient (its only caller is the fused tail)
   FoldK k = make_foldk(a);
   const int JM = k.J <= 14 ? 14 : SLODE_MAX_K + SLODE_MAX_P;
-  const size_t lds = sizeof(float) * ((size_t)k.CT + 8 + 2 * ((size_t)FPC * k.n_pool + 4) + 2 * (size_t)FPC * k.C * JM);
   const TailK tl = *a.tail;
-  const int riders = (tl.n_total + 1 - tl.lin_b + CNT - 1) / CNT;
+  const size_t lds = chain_lds(a.s, tl.fold_next != 0);
+  const int riders = tl.n_riders > 0 ? tl.n_riders : (tl.n_total + 1 - tl.lin_b + CNT - 1) / CNT;
   const dim3 grid(k.Hc * ((k.F + FPC - 1) / FPC) + riders);
 #define SLODE_CHAIN(CC, JJ)                                                                                          \
   do {                                                                                                               \

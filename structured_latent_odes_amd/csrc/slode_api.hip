@@ -99,6 +99,11 @@ int slode_create(slode_handle* out, int device_id) {
   c->profile = 0; c->ev_ready = 0; c->clk.n = 0;
   c->adam_lo2 = c->adam_hi2 = 0; c->adam_delta2 = 0;
   c->rng_seed = 0; c->rng_counter = 0; c->rng_b0 = 0;
+  // the in-launch fold is a measured arm, off by default: it removes the 5.5 us fold launch and adds 6.0 us to the chain launch
+  // (profiles/r04_c_ab*_fold_next_*.log)
+  c->fold_on = getenv("SLODE_FOLD_NEXT") ? atoi(getenv("SLODE_FOLD_NEXT")) : 0;
+  c->fold_valid = 0; c->fold_tmajor = 0; c->fold_ws = nullptr; c->fold_params = nullptr; c->fold_gen = 0;
+  c->chain_resident = 0; memset(c->chain_resident_sig, 0, sizeof(c->chain_resident_sig));
   // diagnostics and test hooks: the environment is read here, once per handle, never at launch time
   c->no_fold = getenv("SLODE_NO_FOLD") != nullptr;   // force the layer-by-layer encoder kernels
   c->ode_loop = getenv("SLODE_ODE_LOOP") != nullptr;
@@ -270,7 +275,7 @@ static Workspace carve(slode_handle h, const slode_shape& s_in, const slode_layo
   w.glat = take((size_t)s.B * 128);
   w.gslabs2 = take((size_t)w.gsplit * s.L * (s.Hc + 1));
   w.gslabs3 = take((size_t)w.gsplit * s.L * (s.Hc + 1));
-  w.counter = reinterpret_cast<unsigned int*>(take(32 * ((SLODE_MAX_F + 1) / 2)));   // one arrival counter per conv-filter pair, 128 B apart
+  w.counter = reinterpret_cast<unsigned int*>(take(32 * (16 + SLODE_MAX_HC)));   // arrival counters 128 B apart: one per conv-filter pair (0..7), the in-launch fold's (8, 9, 16 + m)
   w.sigtab = take(4 * (size_t)s.C * s.T);
   if (dp5) {
     w.dp_kmax = slode_dopri5_kmax(s);
@@ -506,13 +511,28 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     fl.g_loc = w.g_loc; fl.g_scale = w.g_scale; fl.g_pre = w.g_pre; fl.small_slabs = w.small_slabs; fl.small_stride = w.small_stride;
     fl.gslabs = w.gslabs; fl.n_gslabs = w.gsplit; fl.g_lin_w = grads ? grads + lay->lin_w : nullptr; fl.conv_slabs = w.conv_slabs;
     fl.counter = w.counter;
-    fl.sigtab = aux_mode ? nullptr : w.sigtab;
+    fl.sigtab = w.sigtab;   // (the auxiliary step does not read it, but the fold it leaves in the workspace serves the next main step too)
     // the loop-free ODE kernel of the metric shape runs the encoder forward of its own trajectories (ode_kernel.hip, ENCF): fold only
     enc_fused = !aux_mode && !dp5 && bwd && h->enc_fuse && !h->ode_loop && !h->ode_generic && h->ode_alg == 0 && (h->ode_pack == 0 || h->ode_pack >= 10) && !x_out &&
                 slode_ode_can_fuse_encoder(*s, bwd, w.ode_grid);
     fl.skip_enc = enc_fused ? 1 : 0;
-    e = slode_launch_fold_fwd(fl, st);
-    HIP_TRY(h, e);
+    // The previous weight-updating step on this (workspace, params) left W_eff / b_eff / rowsum / w' / the likelihood-scale table of the
+    // CURRENT weights behind (enc_chain_kernel, FOLD-NEXT): no fold launch then.  Anything else -- first step, another workspace, weights
+    // changed outside this handle (slode_fold_invalidate) -- folds here, which also zeroes the arrival counters.
+    const bool have_fold = h->fold_on && h->fold_valid && h->fold_ws == workspace && h->fold_params == (const void*)params &&
+                           h->fold_tmajor == (t_major ? 1 : 0);
+    if (have_fold && enc_fused) {
+      // (nothing to launch)
+    } else if (have_fold) {
+      fl.fold_skip = 1;                  // the encoder forward launch alone
+      e = slode_launch_fold_fwd(fl, st);
+      HIP_TRY(h, e);
+    } else {
+      e = slode_launch_fold_fwd(fl, st);
+      HIP_TRY(h, e);
+      h->fold_gen = 0;                   // (the fold launch zeroed the in-launch fold's arrival counter)
+      h->fold_valid = 1; h->fold_ws = workspace; h->fold_params = params; h->fold_tmajor = t_major ? 1 : 0;
+    }
   } else {
     EncLaunch ef{*s, *lay, params, obs, obs_strides[0], obs_strides[1], obs_strides[2], w.loc, w.scale, w.pooled, w.hid};
     e = slode_launch_enc_fwd(ef, st);
@@ -644,9 +664,40 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     tl.zls_w = lay->zls_w; tl.zls_b = lay->zls_b; tl.ode_begin = lay->ode_begin; tl.n_params = lay->n_params;
     tl.n_total = (adam && adam->n > lay->n_params) ? (int)adam->n : lay->n_params;
     tl.grads = grads; tl.ad = make_adamk(adam ? &ah : nullptr); tl.counter = w.counter;
+    // FOLD-NEXT: this launch updates the weights (Adam inside) => it also folds them for the next step, provided every block of the launch
+    // is resident at once (the blocks wait for each other) and the handle's W_eff bookkeeping covers this workspace
+    int n_chain = 0;
+    int nblk = slode_chain_blocks(*s, tl.n_total, lay->lin_b, &n_chain);
+    int resident = 0;
+    if (h->fold_on && adam) {   // (the occupancy query is asked once per shape and handle)
+      const int sig[8] = {s->T, s->C, s->F, s->K, s->P, s->Hc, s->L, lay->n_params};
+      if (memcmp(sig, h->chain_resident_sig, sizeof(sig)) != 0) {
+        h->chain_resident = slode_chain_resident_blocks(*s, h->num_cu);
+        memcpy(h->chain_resident_sig, sig, sizeof(sig));
+      }
+      resident = h->chain_resident;
+    }
+    tl.n_riders = 0;
+    if (nblk > resident && resident > n_chain && nblk - n_chain <= 4 * (resident - n_chain)) {   // fewer, looping riders: the grid fits
+      tl.n_riders = resident - n_chain;
+      nblk = resident;
+    }
+    const bool fold_next = h->fold_on && adam && adam->p == params && nblk <= resident && h->fold_valid && h->fold_ws == workspace &&
+                           h->fold_params == (const void*)params;
+    tl.fold_next = fold_next ? 1 : 0;
+    if (!fold_next) tl.n_riders = 0;
+    tl.done = w.counter; tl.done_target = 0; tl.cstd_off = lay->cstd; tl.gauss = s->likelihood == SLODE_GAUSS ? 1 : 0;
+    tl.sigtab = w.sigtab;
+    if (fold_next) {
+      ++h->fold_gen;
+      tl.done_target = h->fold_gen;   // (the generation: every counter's target is gen x its number of arrivals per launch)
+      if (tl.n_riders == 0) tl.n_riders = nblk - n_chain;
+    }
     fl.tail = &tl;
+    if (adam) h->fold_valid = fold_next ? 1 : 0;   // the weights change now: what the workspace holds is current only if this launch re-folds
     HIP_TRY(h, slode_launch_fold_chain(fl, st));   // + rider blocks and the last-block conv reduction: the flat gradient is complete
   } else if (bwd) {
+    if (adam) h->fold_valid = 0;
     EncBwdLaunch eb{*s, *lay, params, obs, obs_strides[0], obs_strides[1], obs_strides[2], w.scale, w.pooled, w.hid,
                     w.g_loc, w.g_scale, w.g_pre, w.small_slabs, w.small_stride, w.small_grid, w.lin_slabs, w.lin_splitk};
     HIP_TRY(h, slode_launch_enc_bwd(eb, st));
@@ -747,6 +798,12 @@ int slode_grad_apply(slode_handle h, const slode_shape* s, const slode_layout* l
   }
   return elbo_step_impl(h, s, lay, params, nullptr, nullptr, nullptr, obs_strides, nullptr, nullptr, loss_out, grads, nullptr, nullptr, workspace,
                         workspace_bytes, stream, adam ? &ad : nullptr, kind == SLODE_SVI_AUX ? 1 : 0, nullptr, 2, const_cast<float*>(payload));
+}
+
+int slode_fold_invalidate(slode_handle h) {
+  if (!h) return fail(nullptr, SLODE_EINVAL, "handle is NULL");
+  h->fold_valid = 0;
+  return SLODE_OK;
 }
 
 int slode_rng_seed(slode_handle h, uint64_t seed, int64_t first_trajectory) {
@@ -875,6 +932,7 @@ int slode_adam_step(slode_handle h, int64_t n, float* params, const float* grads
   if (n == 0) return SLODE_OK;
   AdamHost a{params, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, n};
   a.lo2 = h->adam_lo2; a.hi2 = h->adam_hi2; a.delta2 = h->adam_delta2;
+  h->fold_valid = 0;   // the weights change outside a step's chain launch: the next step folds again
   ClockScope clock_scope(h, true);
   HIP_TRY(h, slode_launch_adam_k(n, grads, a, (hipStream_t)stream));
   return SLODE_OK;

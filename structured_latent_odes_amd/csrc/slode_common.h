@@ -55,6 +55,12 @@ struct slode_ctx {
   int ode_grid_cap;       // SLODE_ODE_GRID = n: at most n workgroups in the persistent-loop grid (tests: several trajectories per workgroup at small B)
   // slode_rng_seed: the Philox stream of the calls that draw their own noise (eps == NULL); rng_counter = drawing calls made so far
   uint64_t rng_seed, rng_counter; int64_t rng_b0;
+  // in-launch fold (SLODE_FOLD_NEXT, default on): the chain launch of a step that updates the weights leaves W_eff & co. of the NEW weights
+  // in the workspace; the next step on the same (workspace, params) skips its fold launch.  fold_gen: launches that counted on `done`.
+  int fold_on, fold_valid, fold_tmajor;
+  const void* fold_ws; const void* fold_params;
+  unsigned int fold_gen;
+  int chain_resident; int chain_resident_sig[8];   // cached occupancy answer for the shape (T, C, F, K, P, Hc, L, n_params)
 };
 
 // ---- reparameterisation noise drawn in the kernels (slode_rng_seed; eps == NULL) and labels as the loader yields them -------------
@@ -206,16 +212,21 @@ __device__ __forceinline__ float strided_sum(const float* p, int stride, int n) 
 // step_size2 / sqrt_bc2_2 are their bias corrections, skip2 != 0 leaves them untouched (their step count is still 0).
 struct AdamK { float *p, *m, *v; float step_size, one_minus_b1, b2, one_minus_b2, sqrt_bc2, eps; int lo2, hi2, skip2; float step_size2, sqrt_bc2_2; };
 // torch.optim.Adam single-tensor formulas (see adam_kernel, misc_kernels.hip)
-__device__ __forceinline__ void adam_apply(const AdamK& a, int i, float g) {
+// Returns the parameter's value after the step.  through != 0: the new value is stored agent-scope (sc1, write-through) -- it is handed to
+// other workgroups of the same launch (the in-launch fold of enc_chain_kernel reads lin.bias that way).
+__device__ __forceinline__ float adam_apply(const AdamK& a, int i, float g, int through = 0) {
   const bool r2 = i >= a.lo2 && i < a.hi2;
-  if (r2 && a.skip2) return;
+  if (r2 && a.skip2) return a.p[i];
   float mi = a.m[i], vi = a.v[i];
   mi = mi + a.one_minus_b1 * (g - mi);
   vi = vi * a.b2 + a.one_minus_b2 * g * g;
   const float denom = sqrtf(vi) / (r2 ? a.sqrt_bc2_2 : a.sqrt_bc2) + a.eps;
-  a.p[i] = a.p[i] - (r2 ? a.step_size2 : a.step_size) * (mi / denom);
+  const float pn = a.p[i] - (r2 ? a.step_size2 : a.step_size) * (mi / denom);
+  if (through) __hip_atomic_store(a.p + i, pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else a.p[i] = pn;
   a.m[i] = mi;
   a.v[i] = vi;
+  return pn;
 }
 struct AdamHost { float *p, *m, *v; float lr, b1, b2, eps; int64_t step, n; int lo2 = 0, hi2 = 0; int64_t delta2 = 0; };
 inline AdamK make_adamk(const AdamHost* a) {
@@ -251,6 +262,15 @@ struct TailK {
   float* grads;
   AdamK ad;
   unsigned int* counter;   // arrivals of the chain blocks (zeroed by the fold kernel at the start of the step)
+  // FOLD-NEXT (enc_chain_kernel): the launch also folds W_eff / b_eff / rowsum / w' / the likelihood-scale table of the UPDATED weights
+  // for the next step, so that step needs no fold launch.  done: arrival counter of all blocks of the launch (never reset: the launch's
+  // target is done_target); cstd_off: flat offset of constant_std (its rider threads write the table), sigtab [4][CT], gauss
+  int fold_next;
+  int n_riders;            // > 0: rider blocks of the launch (fewer than one thread per element: they loop)
+  unsigned int* done;
+  unsigned int done_target;
+  int cstd_off, gauss;
+  float* sigtab;
 };
 __device__ __forceinline__ void tail_loss(const TailK& k) {
   if (!k.loss_out) return;
@@ -280,7 +300,18 @@ __device__ __forceinline__ void tail_element(const TailK& k, int i) {
     }
   }
   if (i < k.n_params) k.grads[i] = g;
-  if (k.ad.p) adam_apply(k.ad, i, g);
+  if (k.ad.p) {
+    const float pn = adam_apply(k.ad, i, g, k.fold_next);
+    if (k.fold_next && k.sigtab && i >= k.cstd_off && i < k.cstd_off + k.CT) {
+      // likelihood scales of the NEXT step (what weff_kernel's extra blocks compute at the start of a step: same functions, same bits)
+      const int e = i - k.cstd_off;
+      const float sig = softplusf(pn);
+      k.sigtab[e] = sig;
+      k.sigtab[k.CT + e] = 1.0f / sig;
+      k.sigtab[2 * k.CT + e] = k.gauss ? logf(sig) : logf(2.f * sig);
+      k.sigtab[3 * k.CT + e] = 1.f - expf(-sig);
+    }
+  }
 }
 
 // Stage 1 of the slab reduction: [n][stride] -> [G][stride] partial sums.  One 256-thread block = 64 elements x 4 sub-groups; every
@@ -429,7 +460,11 @@ struct FoldLaunch {
   float* sigtab = nullptr;           // [4][C*T] likelihood-scale table of this step (see OdeLaunch::sigtab), written by extra fold blocks
   const TailK* tail = nullptr;       // chain launch also finishes the whole flat gradient (+ loss, + optional Adam)
   int skip_enc = 0;                  // 1: fold only (the ODE kernel runs the encoder forward itself)
+  int fold_skip = 0;                 // 1: encoder forward only (the workspace already holds the fold of the current weights)
 };
+// blocks of the chain launch (chain blocks + riders): what the in-launch fold's arrival target counts, and whether they are all resident
+int slode_chain_blocks(const slode_shape& s, int n_total, int lin_b, int* n_chain);
+int slode_chain_resident_blocks(const slode_shape& s, int num_cu);
 hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream);
 hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream);
 // The three split-K MFMA products of the fused tail in one launch, each with a ones-column appended to its right-hand matrix:

@@ -364,6 +364,7 @@ class Engine:
         B = obs.shape[0]
         self._check_batch(obs, u, eps)
         ws = self.workspace(B)
+        self._guard(params, ws)
         _check(self.lib, self.handle, self.lib.slode_elbo_step(
             self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._times), self._p(self._stage_t),
             self._p(obs), self._obs_strides(obs), self._p(u), self._p(eps), self._p(loss_out), self._p(grads), self._p(x_out), self._p(z_out),
@@ -375,6 +376,7 @@ class Engine:
         B = obs.shape[0]
         self._check_batch(obs, u, eps)
         ws = self.workspace(B)
+        self._guard(params, ws)
         _check(self.lib, self.handle, self.lib.slode_elbo_adam_step(
             self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(self._times), self._p(self._stage_t),
             self._p(obs), self._obs_strides(obs), self._p(u), self._p(eps), self._p(loss_out), self._p(grads), self._p(ws), ws.numel() * 4,
@@ -388,6 +390,7 @@ class Engine:
         B = obs.shape[0]
         self._check_batch(obs, u, eps)
         ws = self.workspace(B)
+        self._guard(params, ws)
         m, v, lr, step, betas, aeps = adam if adam is not None else (None, None, 0.0, 1, (0.9, 0.999), 1e-8)
         _check(self.lib, self.handle, self.lib.slode_aux_step(
             self.handle, C.byref(self.shape(B)), C.byref(self.layout), self._p(params), self._p(obs), self._obs_strides(obs), self._p(u),
@@ -429,6 +432,7 @@ class Engine:
     def svi_step(self, kind: int, params, batch: L.Batch, B: int, loss_out, grads=None, adam=None):
         """slode_svi_step: kind L.SVI_MAIN | L.SVI_AUX; adam = (exp_avg, exp_avg_sq, lr, step, betas, eps) or None."""
         ws = self.workspace(B)
+        self._guard(params, ws)
         ad = None
         if adam is not None:
             m, v, lr, step, betas, aeps = adam
@@ -444,6 +448,7 @@ class Engine:
 
     def grad_partial(self, kind: int, params, batch: L.Batch, B: int, payload):
         ws = self.workspace(B)
+        self._guard(params, ws)
         _check(self.lib, self.handle, self.lib.slode_grad_partial(
             self.handle, C.byref(self.shape(B)), C.byref(self.layout), int(kind), self._p(params), self._p(self._times), self._p(self._stage_t),
             C.byref(batch), self._p(self._f32(payload, "payload")), self._p(ws), ws.numel() * 4, self._stream()))
@@ -458,6 +463,24 @@ class Engine:
             self.handle, C.byref(self.shape(B)), C.byref(self.layout), int(kind), self._p(params), batch.obs_strides, self._p(payload),
             self._p(loss_out), self._p(grads), self._p(ws), ws.numel() * 4, C.byref(ad) if ad is not None else None, self._stream()))
         return loss_out
+
+    def fold_invalidate(self):
+        """Tell the engine that the parameter vector was written outside its own steps (checkpoint load, another optimizer): the next step
+        folds the encoder weights again instead of trusting the fold the previous step left in the workspace (slode_fold_invalidate)."""
+        _check(self.lib, self.handle, self.lib.slode_fold_invalidate(self.handle))
+
+    def _guard(self, params, ws):
+        """torch-side writes to the flat vector itself, or to the workspace of this call (it carries the kept fold), bump the tensor's
+        version counter: such a write between two steps invalidates the kept fold.  (Writes through re-pointed nn.Parameters do not show
+        here: models call fold_invalidate from load_state_dict.)"""
+        pk = (params.data_ptr(), params._version)
+        wk = ws.data_ptr()
+        if (getattr(self, "_pk", None) not in (None, pk)) or getattr(self, "_wv", {}).get(wk, ws._version) != ws._version:
+            self.fold_invalidate()
+        self._pk = pk
+        if not hasattr(self, "_wv"):
+            self._wv = {}
+        self._wv[wk] = ws._version
 
     def rng_seed(self, seed: int, first_trajectory: int = 0):
         """Key of the in-kernel noise generator (Philox-4x32-10); resets its call counter.  Data parallel: every rank passes the global

@@ -129,6 +129,19 @@ class MechanisticBase(nn.Module):
             self.decoder.ode_model._binding = self._binding
         return self._binding
 
+    def load_state_dict(self, *args, **kwargs):
+        """nn.Module.load_state_dict + a note to the engine: the weights were written behind its back, so the next step must fold the
+        encoder again (the kept fold belongs to the old weights; include/slode.h, slode_fold_invalidate)."""
+        res = super().load_state_dict(*args, **kwargs)
+        if self._binding is not None:
+            self._binding.engine.fold_invalidate()
+        return res
+
+    def parameters_changed(self):
+        """Call after writing parameters by any other route (own optimizer, manual edits) between two SVI steps."""
+        if self._binding is not None:
+            self._binding.engine.fold_invalidate()
+
     # ---- helpers ------------------------------------------------------------------------------------------
     def labels_to_u(self, **labels) -> torch.Tensor:
         return torch.cat([labels[l].reshape(labels[l].shape[0], -1).to(torch.float32) for l in self.LABELS], dim=1).contiguous()

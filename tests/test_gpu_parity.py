@@ -178,7 +178,9 @@ def test_elbo_gradients(ctx):
     # forward-only evaluation gives the same loss value (SVI.evaluate_loss vs SVI.step, training_cvs.py:81,152)
     loss2 = torch.zeros(1, device=dev)
     eng.elbo_step(ctx["flat"], ctx["obs_d"], ctx["u_d"], ctx["eps_d"], loss2, grads=None)
-    assert loss2.item() == loss.item()
+    # (to fp32 summation order: the forward-only step runs the encoder in its own launch, enc_fwd2, the training step of the metric
+    #  shape inside the ODE kernel with 16-byte loads -- the same products, summed in a different order)
+    assert abs(loss2.item() - loss.item()) <= 2e-6 * abs(loss.item())
 
 
 def test_bitwise_reproducible(ctx):
@@ -436,7 +438,9 @@ def test_dopri5_elbo_step_solution_level(fam, mode):
     # loss-only evaluation (SVI.evaluate_loss) scores the same solution
     loss2 = torch.zeros(1, device=dev)
     eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss2, grads=None)
-    assert loss2.item() == loss.item()
+    # (to fp32 summation order: the forward-only step runs the encoder in its own launch, enc_fwd2, the training step of the metric
+    #  shape inside the ODE kernel with 16-byte loads -- the same products, summed in a different order)
+    assert abs(loss2.item() - loss.item()) <= 2e-6 * abs(loss.item())
     # bitwise reproducible
     grads2 = torch.zeros_like(grads)
     eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss2, grads=grads2)
@@ -623,7 +627,9 @@ def test_aux_step_matches_oracle(ctx):
             assert _rel(v, w) < 5e-4, (k, _rel(v, w))
     loss2 = torch.zeros(1, device=dev)
     eng.aux_step(ctx["flat"], ctx["obs_d"], ctx["u_d"], ctx["eps_d"], loss2, None)      # evaluate_loss
-    assert loss2.item() == loss.item()
+    # (to fp32 summation order: the forward-only step runs the encoder in its own launch, enc_fwd2, the training step of the metric
+    #  shape inside the ODE kernel with 16-byte loads -- the same products, summed in a different order)
+    assert abs(loss2.item() - loss.item()) <= 2e-6 * abs(loss.item())
 
 
 def test_abi_error_paths():
