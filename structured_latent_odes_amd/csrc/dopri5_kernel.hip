@@ -323,8 +323,15 @@ __device__ __forceinline__ unsigned load_units(const float* wh, const float* bh,
 template <int S>
 __device__ __forceinline__ float group_rms(float v, bool own) { return sqrtf(group_add(own ? v * v : 0.f) * (1.0f / S)); }
 // the controller's copy: v_sqrt_f32 (1 ulp) -- the ratio only steers the step size
+#ifdef SLODE_DP5_PRECISE   // diagnostic build (make dp5precise; tools/dp5_accuracy.py): IEEE division / sqrt / pow in the controller, fp64 dense output
+#define DP5_RCP(x) (1.0f / (x))
+template <int S>
+__device__ __forceinline__ float group_rms_fast(float v, bool own) { return sqrtf(group_add(own ? v * v : 0.f) * (1.0f / S)); }
+#else
+#define DP5_RCP(x) __builtin_amdgcn_rcpf(x)
 template <int S>
 __device__ __forceinline__ float group_rms_fast(float v, bool own) { return __builtin_amdgcn_sqrtf(group_add(own ? v * v : 0.f) * (1.0f / S)); }
+#endif
 
 template <int S, int H>
 __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
@@ -410,7 +417,7 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
     const float k7 = a6 - d6 * y1;
     const float e = dt * ((35.f / 384 - 1951.f / 21600) * fcur + (500.f / 1113 - 22642.f / 50085) * k3 + (125.f / 192 - 451.f / 720) * k4 +
                           (-2187.f / 6784 + 12231.f / 42400) * k5 + (11.f / 84 - 649.f / 6300) * k6 + (-1.f / 60) * k7);
-    const float ratio = group_rms_fast<S>(e * __builtin_amdgcn_rcpf(atol + rtol * fmaxf(fabsf(y), fabsf(y1))), own);
+    const float ratio = group_rms_fast<S>(e * DP5_RCP(atol + rtol * fmaxf(fabsf(y), fabsf(y1))), own);
     // a step at the resolution floor of fp32 time is accepted regardless (torchdiffeq would raise 'underflow in dt')
     const bool accept = act && (ratio <= 1.f || dt <= 16.f * 1.1920929e-7f * fmaxf(fabsf(t), 1.f));
     if (accept) {
@@ -429,10 +436,15 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
         const float cb = dt * (5.f * fcur - 3.f * k7) + 18.f * y + 14.f * y1 - 32.f * ymid;
         const float cc = dt * (k7 - 4.f * fcur) - 11.f * y - 5.f * y1 + 16.f * ymid;
         const float cd = dt * fcur;
-        const float rdt = __builtin_amdgcn_rcpf(dt);
+        const float rdt = DP5_RCP(dt);
         while (j < T && tj <= t1) {
+#ifdef SLODE_DP5_PRECISE
+          const double xq = ((double)tj - (double)t) / (double)dt;
+          if (own) xo[j * S + gs] = (float)((double)y + xq * ((double)cd + xq * ((double)cc + xq * ((double)cb + xq * (double)ca))));
+#else
           const float xq = (tj - t) * rdt;
           if (own) xo[j * S + gs] = y + xq * (cd + xq * (cc + xq * (cb + xq * ca)));
+#endif
           ++j;
           tj = s_times[j < T ? j : T - 1];
         }
@@ -445,7 +457,11 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
       float factor;
       if (ratio == 0.f) factor = 10.f;
       else {
+#ifdef SLODE_DP5_PRECISE
+        const float safe = 0.9f * powf(ratio, -0.2f);
+#else
         const float safe = 0.9f * __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf(ratio));   // 0.9 ratio^(-1/5) (v_log_f32 is log2)
+#endif
         factor = fminf(10.f, fmaxf(safe, ratio < 1.f ? 1.f : 0.2f));
       }
       dt *= factor;

@@ -427,6 +427,13 @@ def test_dopri5_elbo_step_solution_level(fam, mode):
     loose_loss, loose = O.loss_and_grads(p64, ospec, obs.double(), u.double(), eps.double(), times.double())
     # -ELBO: the likelihood scale is 0.01, so the solver's own tolerance shows in the loss amplified a hundredfold -- the oracle at the
     # engine's tolerances sits 1.6e-5 (relative) from the oracle at tight ones in the cvs case.  Bar: 2e-5 + 3x that sensitivity.
+    # Round 4 measured where the engine sits inside that band and why (tools/dp5_accuracy.py, profiles/r04_d_dp5_accuracy_*.txt): at
+    # rtol 1e-6 the shipped kernel lands 1.6e-5 from the tight loss -- exactly where the fp64 oracle at the same tolerances lands -- and a
+    # diagnostic build with IEEE division / sqrt / pow in the step-size controller and the dense output evaluated in fp64 lands at 2.9e-5:
+    # MORE precise arithmetic moves the loss FURTHER away.  What moves it is the accepted-step sequence (an accept / reject decision that
+    # flips at the tolerance boundary), not the rounding of v_rcp / v_sqrt / v_exp or of the fp32 Horner form; both solutions are 3e-4
+    # from the tight trajectories, as the oracle's is (3.6e-4).  At torchdiffeq's DEFAULT tolerances the question does not arise:
+    # test_dopri5_elbo_step_at_default_tolerances holds a plain 2e-5 bar (observed 2e-7).
     loss_sens = abs(loose_loss.item() - want_loss.item()) / abs(want_loss.item())
     assert abs(loss.item() - want_loss.item()) / abs(want_loss.item()) < 2e-5 + 3.0 * loss_sens, (loss.item(), want_loss.item(), loose_loss.item())
     bad = {k: (_rel(v, want[k]), _rel(loose[k], want[k])) for k, v in got.items() if _rel(v, want[k]) > 5e-4 + 3.0 * _rel(loose[k], want[k])}
@@ -445,6 +452,35 @@ def test_dopri5_elbo_step_solution_level(fam, mode):
     grads2 = torch.zeros_like(grads)
     eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss2, grads=grads2)
     assert torch.equal(grads, grads2)
+
+
+def test_dopri5_elbo_step_at_default_tolerances():
+    """The cvs family at torchdiffeq's default tolerances (rtol 1e-7, atol 1e-9: what `solver="dopri5"` means in the reference,
+    models/blackbox_ode.py:41-45): -ELBO against the fp64 oracle at tight tolerances within a PLAIN 2e-5 -- no sensitivity term -- and the
+    trajectories within 1e-4 (observed: 2e-7 and 7e-5; tools/dp5_accuracy.py)."""
+    from structured_latent_odes_amd import engine as E
+    dev = torch.device("cuda:0")
+    S, T, B = 5, 60, 38
+    kw = dict(z_iext=3, z_rtpr=3, z_eps=2)
+    ospec, espec = O.cvs_spec(solver="dopri5", **kw), E.cvs_spec(solver="dopri5", **kw)      # espec.rtol / atol: the defaults 1e-7 / 1e-9
+    ospec.solver_kw = dict(rtol=1e-10, atol=1e-12, per_trajectory=True)
+    p = O.init_params(ospec, T=T, S=S)
+    g = torch.Generator().manual_seed(31)
+    p = {k: v + 0.05 * torch.randn(v.shape, generator=g) for k, v in p.items()}
+    obs, u, eps, times = O.synthetic_batch(ospec, B, T)
+    times = times * 0.25
+    eng = E.Engine(espec, T, dev)
+    eng.set_times(times)
+    flat = eng.pack(p)
+    obs_d = obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)
+    loss, grads, x = torch.zeros(1, device=dev), torch.zeros(eng.n_params, device=dev), torch.empty(B, T, S, device=dev)
+    eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss, grads=grads, x_out=x)
+    p64 = {k: v.double() for k, v in p.items()}
+    with torch.no_grad():
+        want_loss, parts = O.main_loss(p64, ospec, obs.double(), u.double(), eps.double(), times.double(), return_parts=True)
+    assert abs(loss.item() - want_loss.item()) / abs(want_loss.item()) < 2e-5, (loss.item(), want_loss.item())
+    assert ((x.cpu().double() - parts["dec"][0]).abs() / parts["dec"][0].abs().clamp_min(1.0)).max().item() < 1e-4
+    assert torch.isfinite(grads).all()
 
 
 def test_dopri5_config2_full_size_properties():
