@@ -152,16 +152,19 @@ def kernel_clocks(eng, calls, n=40):
     """Average own duration (us) of every kernel of one step: `calls` is a list of callables, each ONE profiled entry point."""
     eng.profile_enable(True)
     acc, order = {}, []
-    for _ in range(n):
+    for it in range(n + 5):
         for call in calls:
             call()
             for name, us in eng.profile_read():
+                if it < 5:
+                    continue                      # (the first launches through the event-carrying launch path are not steady state)
                 if name not in acc:
-                    acc[name] = 0.0
+                    acc[name] = []
                     order.append(name)
-                acc[name] += us
+                acc[name].append(us)
     eng.profile_enable(False)
-    return {k: acc[k] / n for k in order}
+    # median: a launch that shares the chip with the host's own traffic (the read-back of the previous launch's events) is an outlier
+    return {k: statistics.median(acc[k]) for k in order}
 
 
 def roofline_of(kern_us, shape, B, variants=None):
@@ -354,7 +357,7 @@ def main():
                                   "encoder forward, credited at the reference's operation count); frac_by_flop_count gives the same clock under "
                                   "the narrower counts; step_frac_fp32 (whole step, fixed count) is the figure to compare across rounds",
                      "pipe": "fp32 VALU (the dominant kernel issues no MFMA; on gfx950 the f32 MFMA peak equals the f32 vector peak, 157.3 TF)",
-                     "clock": "the dispatch's own begin->end device timestamps (hipExtLaunchKernelGGL start/stop events), average of 40 "
+                     "clock": "the dispatch's own begin->end device timestamps (hipExtLaunchKernelGGL start/stop events), median of 40 "
                               "launches in this run: the quantity rocprofv3 --kernel-trace reports",
                      "kernel_avg_us": kern_us[dom], "rocprof_kernel_avg_us": rocprof_us,
                      "frac_on_rocprof_clock": (flops_launch / (rocprof_us * 1e-6) / 1e12 / PEAK_FP32) if rocprof_us else None,

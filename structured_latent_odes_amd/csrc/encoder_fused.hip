@@ -208,21 +208,28 @@ __global__ void __launch_bounds__(WNT) weff_kernel(const float* __restrict__ pl_
 // ---- forward: hid = tanh(W_eff x + b_eff), heads --------------------------------------------------------------------
 // TB trajectories per 1024-thread block (4, or 8 for large batches: every block streams the whole W_eff -- 120 KB at the metric shape --
 // so at B = 4096 the 1024 blocks of the 4-trajectory form pull 160 MB through the L2s: 30 us; twice the trajectories per block halve it)
-template <int NSET>
-__device__ __forceinline__ void enc_tile_fma(const float2 (&w)[RB][IU], const float* s_x, int CT, int i0, float (&acc)[NSET][RB * TBE]) {
+// VW floats per lane and request: 2 (8-byte requests, any even C*T) or 4 (16-byte requests -- global_load_dwordx4 / ds_read_b128, the width the
+// memory pipeline is built for: C*T a multiple of 4, rows 16-byte aligned); a tile of a row is 64 * VW * IUV columns
+template <int VW> struct EncVec { typedef __attribute__((ext_vector_type(VW))) float T; static constexpr int IUV = VW == 4 ? 3 : IU; };
+template <int NSET, int VW>
+__device__ __forceinline__ void enc_tile_fma(const typename EncVec<VW>::T (&w)[RB][EncVec<VW>::IUV], const float* s_x, int CT, int i0,
+                                             float (&acc)[NSET][RB * TBE]) {
+  typedef typename EncVec<VW>::T V;
 #pragma unroll
-  for (int u = 0; u < IU; ++u) {
-    const bool in = i0 + 128 * u < CT;
-    const int i = min(i0 + 128 * u, CT - 2);
+  for (int u = 0; u < EncVec<VW>::IUV; ++u) {
+    const bool in = i0 + 64 * VW * u < CT;
+    const int i = min(i0 + 64 * VW * u, CT - VW);
 #pragma unroll
     for (int st = 0; st < NSET; ++st)
 #pragma unroll
       for (int tb = 0; tb < TBE; ++tb) {
-        const float2 pv = *reinterpret_cast<const float2*>(s_x + (st * TBE + tb) * CT + i);
+        const V pv = *reinterpret_cast<const V*>(s_x + (st * TBE + tb) * CT + i);
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-          const float wx = in ? w[r][u].x : 0.f, wy = in ? w[r][u].y : 0.f;
-          acc[st][r * TBE + tb] = fmaf(wy, pv.y, fmaf(wx, pv.x, acc[st][r * TBE + tb]));
+          float a = acc[st][r * TBE + tb];
+#pragma unroll
+          for (int e = 0; e < VW; ++e) a = fmaf(in ? w[r][u][e] : 0.f, pv[e], a);
+          acc[st][r * TBE + tb] = a;
         }
       }
   }
@@ -247,7 +254,7 @@ __device__ __forceinline__ void enc_group_finish(float (&acc)[NSET][RB * TBE], i
 // on them and both are cold misses (W_eff was written by the fold launch a moment ago, from other CUs): one round trip instead of two.
 // BIGL (latent dim >= 32: the proc family's 50): the 2 * L * Hc head weights are staged in one batch of eight loads per thread and TRANSPOSED
 // ([which][mm][l]: the head threads of consecutive latent dims read consecutive words), one lane per head output.
-template <int TB, bool ONE, bool BIGL>
+template <int TB, bool ONE, bool BIGL, int VW = 2>
 __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__ pl_x, const float* __restrict__ pl_zloc_w, const float* __restrict__ pl_zls_w,
                                                        const float* __restrict__ pl_beff, const float* __restrict__ pl_weff, const FoldK k) {
   static_assert(TB % TBE == 0, "sets of four trajectories (wave_sum16 reduces RB x 4 partial sums)");
@@ -263,13 +270,16 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
   STAMP(8);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = NT >> 6;   // wave-uniform => row pointers in SGPRs
   const int ngroups = (Hc + RB - 1) / RB;
-  float2 w1[RB][IU];
+  typedef typename EncVec<VW>::T WV;
+  constexpr int IUV = EncVec<VW>::IUV;
+  static_assert(VW == 2 || ONE, "16-byte requests: the one-tile form only");
+  WV w1[RB][IUV];
   if (ONE && wave < ngroups) {
 #pragma unroll
-    for (int u = 0; u < IU; ++u) {
-      const int ic = min(2 * lane + 128 * u, CT - 2);
+    for (int u = 0; u < IUV; ++u) {
+      const int ic = min(VW * lane + 64 * VW * u, CT - VW);
 #pragma unroll
-      for (int r = 0; r < RB; ++r) w1[r][u] = *reinterpret_cast<const float2*>(pl_weff + (long long)min(wave * RB + r, Hc - 1) * CT + ic);
+      for (int r = 0; r < RB; ++r) w1[r][u] = *reinterpret_cast<const WV*>(pl_weff + (long long)min(wave * RB + r, Hc - 1) * CT + ic);
     }
   }
   {
@@ -328,7 +338,7 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
         float acc[1][RB * TBE];   // [r][tb] flattened: wave_sum16 reduces it in place
 #pragma unroll
         for (int i = 0; i < RB * TBE; ++i) acc[0][i] = 0.f;
-        enc_tile_fma<1>(w1, s_x + st * TBE * CT, CT, 2 * lane, acc);
+        enc_tile_fma<1, VW>(w1, s_x + st * TBE * CT, CT, VW * lane, acc);
         __builtin_amdgcn_sched_barrier(0);   // keep the reduction's temporaries out of the load/FMA phase (spills otherwise)
         if (st == 0) STAMP(12);
         enc_group_finish<1>(acc, lane, wave * RB, b0 + st * TBE, k, s_be, s_hid + st * TBE * 64);
@@ -349,14 +359,14 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
       // CT is even for C*T of every supported config; odd CT falls back to scalar columns
       if ((CT & 1) == 0) {
         for (int i0 = 2 * lane; i0 < CT; i0 += 128 * IU) {
-          float2 w[RB][IU];
+          EncVec<2>::T w[RB][IU];
 #pragma unroll
           for (int u = 0; u < IU; ++u) {
             const int ic = min(i0 + 128 * u, CT - 2);
 #pragma unroll
-            for (int r = 0; r < RB; ++r) w[r][u] = *reinterpret_cast<const float2*>(wrow[r] + ic);
+            for (int r = 0; r < RB; ++r) w[r][u] = *reinterpret_cast<const EncVec<2>::T*>(wrow[r] + ic);
           }
-          enc_tile_fma<NSET>(w, s_x, CT, i0, acc);
+          enc_tile_fma<NSET, 2>(w, s_x, CT, i0, acc);
         }
       } else {
         for (int i = lane; i < CT; i += 64) {
@@ -466,7 +476,9 @@ static_assert(SLODE_MAX_HC <= 64, "the last block holds ceil(Hc / 4) <= 16 row v
 // kernel (ODE half, lin.bias, head layers, loss), the chain blocks apply Adam to their own piece of the lin.weight row, and -- per filter
 // pair -- the LAST chain block to arrive (agent-scope counter, one per pair, 128 B apart) sums the Hc conv rows of the pair's taps.
 // Fixed order => reproducible.
-template <int C, int JM>
+// FN: the in-launch fold form (FOLD-NEXT, a measured arm: SLODE_FOLD_NEXT=1) -- a separate instantiation, so that the shipped form carries
+// none of its registers (with the fold section compiled into the one kernel: 87 -> 104 VGPRs, 87 -> 122 SGPR spills, +2 us at T = 300)
+template <int C, int JM, bool FN = false>
 __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict__ pl_gslabs, const float* __restrict__ pl_lin_w, const float* __restrict__ pl_wprime,
                                                         const FoldK k, const TailK tl) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -477,11 +489,11 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
     const int r = (int)blockIdx.x - n_chain, n_rid = (int)gridDim.x - n_chain;
     if (r == 0) STAMP_ANY(26);
     for (int i = tl.lin_b + r * CNT + tid; i <= tl.n_total; i += n_rid * CNT) {
-      if (i < tl.n_total) tail_element(tl, i);
+      if (i < tl.n_total) tail_element<FN>(tl, i);
       else tail_loss(tl);
     }
     if (r == 0) STAMP_ANY(27);
-    if (tl.fold_next) {   // this block's new parameter values (lin.bias: stored agent-scope) have reached L2; count it in
+    if (FN) {   // this block's new parameter values (lin.bias: stored agent-scope) have reached L2; count it in
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(tl.done + 32 * 9, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -636,7 +648,7 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
         const float mi = am[u] + tl.ad.one_minus_b1 * (g - am[u]);
         const float vi = av[u] * tl.ad.b2 + tl.ad.one_minus_b2 * g * g;
         const float pn = ap[u] - tl.ad.step_size * (mi / (sqrtf(vi) / tl.ad.sqrt_bc2 + tl.ad.eps));
-        if (tl.fold_next) __hip_atomic_store(tl.ad.p + lw0 + e, pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by the row's other blocks)
+        if (FN) __hip_atomic_store(tl.ad.p + lw0 + e, pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by the row's other blocks)
         else tl.ad.p[lw0 + e] = pn;
         tl.ad.m[lw0 + e] = mi;
         tl.ad.v[lw0 + e] = vi;
@@ -649,14 +661,14 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
       mi = mi + tl.ad.one_minus_b1 * (g - mi);
       vi = vi * tl.ad.b2 + tl.ad.one_minus_b2 * g * g;
       const float pn = tl.ad.p[i] - tl.ad.step_size * (mi / (sqrtf(vi) / tl.ad.sqrt_bc2 + tl.ad.eps));
-      if (tl.fold_next) __hip_atomic_store(tl.ad.p + i, pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (FN) __hip_atomic_store(tl.ad.p + i, pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else tl.ad.p[i] = pn;
       tl.ad.m[i] = mi;
       tl.ad.v[i] = vi;
     }
   }
   STAMP(22);
-  if (tl.fold_next) {   // this block's piece of the new lin.weight row (stored agent-scope above) has reached L2: count it in for row m
+  if (FN) {   // this block's piece of the new lin.weight row (stored agent-scope above) has reached L2: count it in for row m
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(tl.done + 32 * (16 + m), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -681,7 +693,7 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
         const float mi = cm + tl.ad.one_minus_b1 * (g - cm);
         const float vi = cv * tl.ad.b2 + tl.ad.one_minus_b2 * g * g;
         const float pn = cp - tl.ad.step_size * (mi / (sqrtf(vi) / tl.ad.sqrt_bc2 + tl.ad.eps));
-        if (tl.fold_next) __hip_atomic_store(tl.ad.p + ci, pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by every block's fold)
+        if (FN) __hip_atomic_store(tl.ad.p + ci, pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by every block's fold)
         else tl.ad.p[ci] = pn;
         tl.ad.m[ci] = mi;
         tl.ad.v[ci] = vi;
@@ -689,7 +701,7 @@ __global__ void __launch_bounds__(CNT) enc_chain_kernel(const float* __restrict_
     }
     STAMP_ANY(25);
   }
-  if (!tl.fold_next) return;
+  if (!FN) return;
   // ---- FOLD-NEXT: W_eff, rowsum, b_eff, w' of the UPDATED weights, for the next step (which then has no fold launch) ---------------------
   // Every parameter the fold reads was stored agent-scope (sc1) by its owner in this launch: this block's lin.weight piece above, the conv
   // taps / biases by the pairs' last blocks, lin.bias by the rider blocks.  Hand-off as for the conv rows: every storing wave drains
@@ -839,10 +851,10 @@ int slode_chain_resident_blocks(const slode_shape& s, int num_cu) {
   const size_t lds = chain_lds(s, true);
   int per_cu = 0;
   hipError_t e = hipErrorInvalidValue;
-  if (s.C == 3 && JM == 14) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, enc_chain_kernel<3, 14>, CNT, lds);
-  else if (s.C == 4 && JM == 14) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, enc_chain_kernel<4, 14>, CNT, lds);
-  else if (s.C == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (enc_chain_kernel<3, SLODE_MAX_K + SLODE_MAX_P>), CNT, lds);
-  else if (s.C == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (enc_chain_kernel<4, SLODE_MAX_K + SLODE_MAX_P>), CNT, lds);
+  if (s.C == 3 && JM == 14) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (enc_chain_kernel<3, 14, true>), CNT, lds);
+  else if (s.C == 4 && JM == 14) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (enc_chain_kernel<4, 14, true>), CNT, lds);
+  else if (s.C == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (enc_chain_kernel<3, SLODE_MAX_K + SLODE_MAX_P, true>), CNT, lds);
+  else if (s.C == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (enc_chain_kernel<4, SLODE_MAX_K + SLODE_MAX_P, true>), CNT, lds);
   if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); return 0; }
   return per_cu * num_cu;
 }
@@ -865,6 +877,8 @@ hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream) {
   }
   if (a.skip_enc) return hipGetLastError();
   const bool one = (k.CT & 1) == 0 && k.CT <= 128 * IU && (k.Hc + RB - 1) / RB <= FNT / 64;
+  // 16-byte requests where the rows allow them (C*T a multiple of 4, at most 3 x 256 columns; W_eff and the dense observation rows are 16-byte aligned then)
+  const bool wide = one && (k.CT & 3) == 0 && k.CT <= 256 * EncVec<4>::IUV && (reinterpret_cast<uintptr_t>(k.weff) & 15) == 0;
   // (a batch that fills the chip several times over: fewer, fatter blocks -- one block per CU at B = 4096)
   const int TB = (one && k.B >= 4096) ? 4 * TBE : (k.B >= 2048 ? 2 * TBE : TBE);
   const size_t lds = sizeof(float) * ((size_t)TB * k.CT + TB * 64 + 2 * (size_t)k.L * k.Hc + 64 + 2 * (size_t)k.L);
@@ -874,7 +888,16 @@ hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream) {
     SLODE_LAUNCH("enc_fwd2", (enc_fwd2_kernel<TT, OO, LL>), dim3((k.B + TB - 1) / TB), dim3(FNT), lds, stream, k.x, k.zloc_w, k.zls_w, k.beff, k.weff, k); \
   } while (0)
 #define SLODE_ENC_FWD2_L(TT, OO) do { if (k.L >= 32) SLODE_ENC_FWD2(TT, OO, true); else SLODE_ENC_FWD2(TT, OO, false); } while (0)
-  if (TB == 4 * TBE) SLODE_ENC_FWD2_L(4 * TBE, true);
+#define SLODE_ENC_FWD2_W(TT, LL)                                                                                                        \
+  do {                                                                                                                                \
+    (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel<TT, true, LL, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+    SLODE_LAUNCH("enc_fwd2", (enc_fwd2_kernel<TT, true, LL, 4>), dim3((k.B + TB - 1) / TB), dim3(FNT), lds, stream, k.x, k.zloc_w, k.zls_w, k.beff, k.weff, k); \
+  } while (0)
+#define SLODE_ENC_FWD2_WL(TT) do { if (k.L >= 32) SLODE_ENC_FWD2_W(TT, true); else SLODE_ENC_FWD2_W(TT, false); } while (0)
+  if (wide && TB == 4 * TBE) SLODE_ENC_FWD2_WL(4 * TBE);
+  else if (wide && TB == TBE) SLODE_ENC_FWD2_WL(TBE);
+  else if (wide) SLODE_ENC_FWD2_WL(2 * TBE);
+  else if (TB == 4 * TBE) SLODE_ENC_FWD2_L(4 * TBE, true);
   else if (TB == TBE) { if (one) SLODE_ENC_FWD2_L(TBE, true); else SLODE_ENC_FWD2_L(TBE, false); }
   else { if (one) SLODE_ENC_FWD2_L(2 * TBE, true); else SLODE_ENC_FWD2_L(2 * TBE, false); }
   return hipGetLastError();
@@ -890,8 +913,13 @@ hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream) {
   const dim3 grid(k.Hc * ((k.F + FPC - 1) / FPC) + riders);
 #define SLODE_CHAIN(CC, JJ)                                                                                          \
   do {                                                                                                               \
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)enc_chain_kernel<CC, JJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    SLODE_LAUNCH("enc_chain", (enc_chain_kernel<CC, JJ>), grid, dim3(CNT), lds, stream, k.gslabs, k.lin_w, (const float*)k.wprime, k, tl);                              \
+    if (tl.fold_next) {                                                                                             \
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)enc_chain_kernel<CC, JJ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      SLODE_LAUNCH("enc_chain", (enc_chain_kernel<CC, JJ, true>), grid, dim3(CNT), lds, stream, k.gslabs, k.lin_w, (const float*)k.wprime, k, tl);          \
+    } else {                                                                                                         \
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)enc_chain_kernel<CC, JJ, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      SLODE_LAUNCH("enc_chain", (enc_chain_kernel<CC, JJ, false>), grid, dim3(CNT), lds, stream, k.gslabs, k.lin_w, (const float*)k.wprime, k, tl);         \
+    }                                                                                                                \
   } while (0)
   if (k.C == 3 && JM == 14) SLODE_CHAIN(3, 14);
   else if (k.C == 4 && JM == 14) SLODE_CHAIN(4, 14);

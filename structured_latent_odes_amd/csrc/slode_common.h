@@ -279,6 +279,7 @@ __device__ __forceinline__ void tail_loss(const TailK& k) {
   k.loss_out[0] = (float)acc;
 }
 // element i of [0, lin_w) (conv) or [lin_b, n_total): gradient, write, optional Adam
+template <bool FN = false>   // FN: the in-launch fold form of the chain launch (its riders publish what the fold reads, and write the scale table)
 __device__ __forceinline__ void tail_element(const TailK& k, int i) {
   float g = 0.f;
   if (i >= k.ode_begin && i < k.n_params) {
@@ -301,8 +302,8 @@ __device__ __forceinline__ void tail_element(const TailK& k, int i) {
   }
   if (i < k.n_params) k.grads[i] = g;
   if (k.ad.p) {
-    const float pn = adam_apply(k.ad, i, g, k.fold_next);
-    if (k.fold_next && k.sigtab && i >= k.cstd_off && i < k.cstd_off + k.CT) {
+    const float pn = adam_apply(k.ad, i, g, FN ? 1 : 0);
+    if (FN && k.sigtab && i >= k.cstd_off && i < k.cstd_off + k.CT) {
       // likelihood scales of the NEXT step (what weff_kernel's extra blocks compute at the start of a step: same functions, same bits)
       const int e = i - k.cstd_off;
       const float sig = softplusf(pn);
