@@ -14,7 +14,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r3", "prof")
 tag = sys.argv[2] if len(sys.argv) > 2 else "r03_a"
-dst = os.path.join(ROOT, "profiles")
+dst = os.environ.get("PROFILE_DST") or os.path.join(ROOT, "profiles")   # (on the GPU box: a directory under gpurun_out/, which is what travels back)
+os.makedirs(dst, exist_ok=True)
 sha = hashlib.sha1(open(os.path.join(ROOT, "structured_latent_odes_amd", "csrc", "ode_kernel.hip"), "rb").read()).hexdigest()
 KERNELS = {"weff_kernel": "fold", "enc_fwd2_kernel": "enc_fwd", "ode_elbo_kernel": "ode_elbo", "enc_bwd_lin_kernel": "gemm", "enc_chain_kernel": "chain"}
 ARMS = {0: "product: piecewise-linear heads + switching-sum contraction", 1: "direct head evaluation (v_fma, SGPR operands) + switching-sum contraction",
