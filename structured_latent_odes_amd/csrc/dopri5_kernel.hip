@@ -203,11 +203,13 @@ struct GroupLds {
 // Fills the shared tables, this lane's hidden units (offsets u = W_z z + b_h of the dynamics net -> registers + LDS, pre-activations of
 // the init net -> pre0) and the trajectory's segment table.  [tlo, thi]: the integration range (segment centres are clamped to it).
 // Returns the dir bits.  Contains barriers: every thread of the workgroup calls it.
-template <int S, int H>
+// LPT: lanes per trajectory -- G (eight trajectories per wave) or 64 (one trajectory per wave: its eight lane groups run the set-up side by
+// side and write the same values)
+template <int S, int H, int LPT = G>
 __device__ __forceinline__ unsigned load_units(const float* wh, const float* bh, const float* wg, const float* bg, const float* wd,
                                                const float* bd, const float* w1, const float* b1, const float* zrow, int L, int tid,
                                                int nthreads, float tlo, float thi, const GroupLds<H>& m, Units& w, float (&pre0)[JL]) {
-  const int g = tid & (G - 1), slot = tid >> 3;
+  const int g = tid & (G - 1), slot = tid / LPT;
   const bool own = g < S;
   if (tid < 32) m.wt[tid] = tid < H ? wh[tid * (1 + L)] : 0.f;
   for (int i = tid; i < H * 16; i += nthreads) {
@@ -474,6 +476,171 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
     // loudly instead of scoring a trajectory that was not integrated to the end
     for (; j < T; ++j)
       if (own) xo[j * S + gs] = __builtin_nanf("");
+  }
+}
+
+// ---- LPT = 16 / 32 / 64 lanes per trajectory (round 4) ---------------------------------------------------------------------------------
+// The eight-lanes-per-trajectory kernel above puts B = 4096 trajectories on 512 waves: half the SIMDs idle, every wave a lone dependent
+// chain of ~350 instructions per attempted step, its trip count the MAXIMUM over its eight trajectories.  Here a trajectory has NG = LPT / 8
+// lane groups, lane = 8 e + g: the step's five stage times are evaluated SIDE BY SIDE by the groups (ceil(5 / NG) table look-ups per lane
+// instead of five), gathered with ten ds_bpermute, and every group then runs the Runge-Kutta combination, the error norm and the controller
+// on the same values -- the same operations in the same order as above, so the accepted steps, the records and the outputs are bit for bit
+// those of the eight-lane kernel.  More waves (1024 / 2048 / 4096 at B = 4096) with fewer instructions each; what the measurement says
+// about the three widths is in DESIGN 3.3 (LPT = 64 turns the latency problem into an equally large throughput problem: every lane group
+// repeats the combination, and the scalar bookkeeping of 16 waves per CU saturates the issue slots).
+constexpr int WNTH = 256;         // threads per workgroup: WNTH / LPT trajectories
+template <int S, int H, int LPT>
+__global__ void __launch_bounds__(WNTH) dopri5_lpt_kernel(const DpK k) {
+  static_assert(S <= G && H <= G * JL && H <= 32, "one state component and JL hidden units per lane; unit bits in one word");
+  static_assert(LPT == 16 || LPT == 32 || LPT == 64, "lane groups of eight inside a wave");
+  constexpr int NG = LPT / G, NR = (5 + NG - 1) / NG, WTP = WNTH / LPT;   // lane groups, evaluation rounds, trajectories per workgroup
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane & (G - 1), e = (lane & (LPT - 1)) >> 3, slot = tid / LPT, b = blockIdx.x * WTP + slot;
+  const int L = k.L, T = k.T;
+  GroupLds<H> m;
+  float* s_z = m.carve(smem, WTP);      // [WTP][L]
+  float* s_times = s_z + WTP * L;       // [T]
+  const bool live = b < k.B, own = g < S;
+  const long long bb = live ? b : 0;
+  for (int l = lane & (LPT - 1); l < L; l += LPT) {
+    const long long i = bb * L + l;
+    float zl = 0.f;
+    if (live) {
+      if (k.z) zl = k.z[i];
+      else {
+        const float ev = slode_eps_at(k.rng, k.eps, bb, L, l);
+        if (k.rng.on && k.eps_out) k.eps_out[i] = ev;
+        zl = fmaf(k.scale[i], ev, k.loc[i]);
+      }
+      if (k.z_out) k.z_out[i] = zl;
+    }
+    s_z[slot * L + l] = zl;
+  }
+  stage_to_lds(s_times, k.times, T, tid, WNTH);
+  __syncthreads();
+  int bad_grid = 0;
+  for (int i = tid; i + 1 < T; i += WNTH) bad_grid |= !(s_times[i + 1] > s_times[i]);
+  bad_grid = __syncthreads_or(bad_grid);
+  Units w;
+  float pre0[JL];
+  const float t_first = s_times[0], t_last = s_times[T - 1];
+  load_units<S, H, LPT>(k.wh, k.bh, k.wg, k.bg, k.wd, k.bd, k.w1, k.b1, s_z + slot * L, L, tid, WNTH, fminf(t_first, t_last), fmaxf(t_first, t_last),
+                        m, w, pre0);
+  const float4* tab = m.tab + slot * (H + 1) * G;
+  const float* ctr = m.ctr + slot * 32;
+  float y = init_state<S, H>(k.w2, k.b2, pre0, g, own);
+  const int gs = own ? g : 0;
+  const bool wr = own && e == 0;          // the lane group that writes the trajectory's outputs and records
+  float* xo = k.x + bb * T * S;
+  if (live && wr) xo[gs] = y;
+  const float rtol = k.rtol, atol = k.atol;
+  float t = t_first;
+  float a, d;
+  eval_ad<H>(t, w, g, own, tab, ctr, a, d);
+  float fcur = a - d * y;
+  float dt;
+  {   // Hairer's initial step (torchdiffeq _select_initial_step, order 4)
+    const float sc = atol + fabsf(y) * rtol;
+    const float d0 = group_rms<S>(y / sc, own), d1 = group_rms<S>(fcur / sc, own);
+    const float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
+    const float y1 = fmaf(h0, fcur, y);
+    eval_ad<H>(t + h0, w, g, own, tab, ctr, a, d);
+    const float f1 = a - d * y1;
+    const float d2 = group_rms<S>((f1 - fcur) / sc, own) / h0;
+    const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
+    dt = fminf(100.f * h0, h1);
+  }
+  int j = 1;
+  int steps = bad_grid ? k.max_steps : 0, nacc = 0;
+  float tj = s_times[j < T ? j : T - 1];   // the next output time, read ahead of its use
+  // stage i (t + dt {1/5, 3/10, 4/5, 8/9, 1}; stages 6 and 7 share the last) is evaluated by lane group i % NG in round i / NG
+  const int base = ((lane & ~(LPT - 1)) + g) << 2;   // ds_bpermute byte index of lane (this trajectory, group 0, component g)
+  // every lane leaves the loop: either all outputs written or max_steps reached (the missing outputs are then NaN).  The butterflies inside
+  // eval_ad / group_rms and the gathers sit at the top level of the loop body: all 64 lanes execute them.
+  while (__any(live && j < T && steps < k.max_steps)) {
+    const bool act = live && j < T && steps < k.max_steps;
+    ++steps;
+    const float te5[5] = {t + dt * (1.f / 5), t + dt * (3.f / 10), t + dt * (4.f / 5), t + dt * (8.f / 9), t + dt};
+    float ar[NR], dr[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      float te = te5[4];
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        if (i / NG == r) te = (e == i % NG) ? te5[i] : te;   // (groups without a stage in this round repeat the last one)
+      eval_ad<H>(te, w, g, own, tab, ctr, ar[r], dr[r]);
+    }
+    float av[5], dv[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int srcl = base + ((i % NG) << 5);
+      av[i] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(srcl, (int)__float_as_uint(ar[i / NG])));
+      dv[i] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(srcl, (int)__float_as_uint(dr[i / NG])));
+    }
+    const float a2 = av[0], d2 = dv[0], a3 = av[1], d3 = dv[1], a4 = av[2], d4 = dv[2], a5 = av[3], d5 = dv[3], a6 = av[4], d6 = dv[4];
+    const float k2 = a2 - d2 * fmaf(dt, (1.f / 5) * fcur, y);
+    const float k3 = a3 - d3 * fmaf(dt, (3.f / 40) * fcur + (9.f / 40) * k2, y);
+    const float k4 = a4 - d4 * fmaf(dt, (44.f / 45) * fcur + (-56.f / 15) * k2 + (32.f / 9) * k3, y);
+    const float k5 = a5 - d5 * fmaf(dt, (19372.f / 6561) * fcur + (-25360.f / 2187) * k2 + (64448.f / 6561) * k3 + (-212.f / 729) * k4, y);
+    const float k6 = a6 - d6 * fmaf(dt, (9017.f / 3168) * fcur + (-355.f / 33) * k2 + (46732.f / 5247) * k3 + (49.f / 176) * k4 + (-5103.f / 18656) * k5, y);
+    const float y1 = fmaf(dt, (35.f / 384) * fcur + (500.f / 1113) * k3 + (125.f / 192) * k4 + (-2187.f / 6784) * k5 + (11.f / 84) * k6, y);
+    const float k7 = a6 - d6 * y1;
+    const float er = dt * ((35.f / 384 - 1951.f / 21600) * fcur + (500.f / 1113 - 22642.f / 50085) * k3 + (125.f / 192 - 451.f / 720) * k4 +
+                           (-2187.f / 6784 + 12231.f / 42400) * k5 + (11.f / 84 - 649.f / 6300) * k6 + (-1.f / 60) * k7);
+    const float ratio = group_rms_fast<S>(er * DP5_RCP(atol + rtol * fmaxf(fabsf(y), fabsf(y1))), own);
+    // a step at the resolution floor of fp32 time is accepted regardless (torchdiffeq would raise 'underflow in dt')
+    const bool accept = act && (ratio <= 1.f || dt <= 16.f * 1.1920929e-7f * fmaxf(fabsf(t), 1.f));
+    if (accept) {
+      const float t1 = t + dt;
+      if (k.rec && nacc < k.kmax && e == 0) {
+        float* r = k.rec + ((long long)nacc * k.B + b) * (S + 2);
+        if (g == 0) { r[0] = t; r[1] = dt; }
+        if (own) r[2 + gs] = y;
+      }
+      ++nacc;
+      if (j < T && tj <= t1) {
+        const float ymid = fmaf(dt, (6025192743.f / 30085553152.f / 2) * fcur + (51252292925.f / 65400821598.f / 2) * k3 +
+                                        (-2691868925.f / 45128329728.f / 2) * k4 + (187940372067.f / 1594534317056.f / 2) * k5 +
+                                        (-1776094331.f / 19743644256.f / 2) * k6 + (11237099.f / 235043384.f / 2) * k7, y);
+        const float ca = 2.f * dt * (k7 - fcur) - 8.f * (y1 + y) + 16.f * ymid;
+        const float cb = dt * (5.f * fcur - 3.f * k7) + 18.f * y + 14.f * y1 - 32.f * ymid;
+        const float cc = dt * (k7 - 4.f * fcur) - 11.f * y - 5.f * y1 + 16.f * ymid;
+        const float cd = dt * fcur;
+        const float rdt = DP5_RCP(dt);
+        while (j < T && tj <= t1) {
+#ifdef SLODE_DP5_PRECISE
+          const double xq = ((double)tj - (double)t) / (double)dt;
+          if (wr) xo[j * S + gs] = (float)((double)y + xq * ((double)cd + xq * ((double)cc + xq * ((double)cb + xq * (double)ca))));
+#else
+          const float xq = (tj - t) * rdt;
+          if (wr) xo[j * S + gs] = y + xq * (cd + xq * (cc + xq * (cb + xq * ca)));
+#endif
+          ++j;
+          tj = s_times[j < T ? j : T - 1];
+        }
+      }
+      t = t1;
+      y = y1;
+      fcur = k7;
+    }
+    if (act) {
+      float factor;
+      if (ratio == 0.f) factor = 10.f;
+      else {
+#ifdef SLODE_DP5_PRECISE
+        const float safe = 0.9f * powf(ratio, -0.2f);
+#else
+        const float safe = 0.9f * __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf(ratio));   // 0.9 ratio^(-1/5) (v_log_f32 is log2)
+#endif
+        factor = fminf(10.f, fmaxf(safe, ratio < 1.f ? 1.f : 0.2f));
+      }
+      dt *= factor;
+    }
+  }
+  if (live) {
+    if (k.nrec && (lane & (LPT - 1)) == 0) k.nrec[b] = (j < T) ? -1 : nacc;
+    for (; j < T; ++j)   // max_steps exhausted (or a grid the controller cannot walk): the outputs that were never reached are NaN
+      if (wr) xo[j * S + gs] = __builtin_nanf("");
   }
 }
 
@@ -1005,6 +1172,17 @@ hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, co
   k.rtol = s.rtol > 0.f ? s.rtol : 1e-7f;
   k.atol = s.atol > 0.f ? s.atol : 1e-9f;
   k.max_steps = 20000;
+  const int lpt = rec ? rec->w64 : 8;    // lanes per trajectory of the forward solve: 8 (the round-2 kernel), 16, 32 or 64 -- all the same bits
+  if (lpt == 16 || lpt == 32 || lpt == 64) {
+    const int wtp = WNTH / lpt, grid = (s.B + wtp - 1) / wtp;
+    const size_t lds = sizeof(float) * ((size_t)GroupLds<25>::floats(wtp) + (size_t)wtp * s.L + (size_t)s.T);
+#define SLODE_DP5_LPT(SS, LL) SLODE_LAUNCH("dopri5_fwd", (dopri5_lpt_kernel<SS, 25, LL>), dim3(grid), dim3(WNTH), lds, stream, k)
+    if (s.H != 25 || (s.S != 5 && s.S != 8)) return hipErrorInvalidValue;
+    if (s.S == 5) { if (lpt == 16) SLODE_DP5_LPT(5, 16); else if (lpt == 32) SLODE_DP5_LPT(5, 32); else SLODE_DP5_LPT(5, 64); }
+    else { if (lpt == 16) SLODE_DP5_LPT(8, 16); else if (lpt == 32) SLODE_DP5_LPT(8, 32); else SLODE_DP5_LPT(8, 64); }
+#undef SLODE_DP5_LPT
+    return hipGetLastError();
+  }
   const int grid = (s.B + TPB - 1) / TPB;
   const size_t lds = sizeof(float) * ((size_t)GroupLds<25>::floats(TPB) + (size_t)TPB * s.L + (size_t)s.T);
   if (s.H == 25 && s.S == 5) SLODE_LAUNCH("dopri5_fwd", (dopri5_kernel<5, 25>), dim3(grid), dim3(DNT), lds, stream, k);

@@ -60,6 +60,7 @@ struct slode_ctx {
   int fold_on, fold_valid, fold_tmajor;
   const void* fold_ws; const void* fold_params;
   unsigned int fold_gen;
+  int dp5_w64;            // SLODE_DP5_LPT: lanes per trajectory of the forward adaptive solve (8, 16, 32, 64)
   int chain_resident; int chain_resident_sig[8];   // cached occupancy answer for the shape (T, C, F, K, P, Hc, L, n_params)
 };
 
@@ -528,7 +529,9 @@ hipError_t slode_launch_dynamics_eval(const slode_shape& s, const slode_layout& 
                                       const float* state, const float* z, float* out, hipStream_t stream);
 // adaptive solve with step records (training): z = loc + scale * eps is formed in the kernel and written to z_out
 // rng.on: eps is drawn by the forward kernel and written to eps_out, which the scorer and the reverse sweep then read as `eps`
-struct DopriRec { const float *loc, *scale, *eps; float* z_out; float* rec; int* nrec; int kmax; RngK rng{}; float* eps_out = nullptr; };
+struct DopriRec { const float *loc, *scale, *eps; float* z_out; float* rec; int* nrec; int kmax; RngK rng{}; float* eps_out = nullptr;
+                  int w64 = 8;   // lanes per trajectory of the forward solve: 8 (dopri5_kernel), 16 / 32 / 64 (dopri5_lpt_kernel); SLODE_DP5_LPT
+};
 int slode_dopri5_kmax(const slode_shape& s);
 int slode_dopri5_rows(const slode_shape& s);
 hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const float* z,

@@ -483,6 +483,44 @@ def test_dopri5_elbo_step_at_default_tolerances():
     assert torch.isfinite(grads).all()
 
 
+@pytest.mark.parametrize("lpt", ["16", "32", "64"])
+@pytest.mark.parametrize("fam", ["cvs", "proc"])
+def test_dopri5_wider_lane_groups_equal_the_eight_lane_kernel_bitwise(fam, lpt, monkeypatch):
+    """Round 4: the forward adaptive solve with 16 / 32 / 64 lanes per trajectory (lane = stage evaluation x state component: the stage times
+    of a step side by side, dopri5_lpt_kernel) instead of eight.  Same operations in the same order: trajectories, step counts, -ELBO and
+    every gradient element are bit for bit those of the eight-lane kernel (SLODE_DP5_LPT=8), in the bare solve and in the training step;
+    ragged batch (B not a multiple of the trajectories per workgroup)."""
+    from structured_latent_odes_amd import engine as E
+    dev = torch.device("cuda:0")
+    S, T, B = (8, 100, 37) if fam == "proc" else (5, 60, 38)
+    kw = dict(z_g=10, z_eps=10) if fam == "proc" else dict(z_iext=3, z_rtpr=3, z_eps=2)
+    mk_o, mk_e = (O.proc_spec, E.proc_spec) if fam == "proc" else (O.cvs_spec, E.cvs_spec)
+    ospec = mk_o(solver="dopri5", **kw)
+    p = O.init_params(ospec, T=T, S=S)
+    g = torch.Generator().manual_seed(31)
+    p = {k: v + 0.05 * torch.randn(v.shape, generator=g) for k, v in p.items()}
+    obs, u, eps, times = O.synthetic_batch(ospec, B, T)
+    if fam == "cvs":
+        times = times * 0.25
+    outs = []
+    for w64 in ("8", lpt):
+        monkeypatch.setenv("SLODE_DP5_LPT", w64)
+        eng = E.Engine(mk_e(solver="dopri5", **kw), T, dev)          # the switch is read in slode_create
+        eng.set_times(times)
+        flat = eng.pack(p)
+        obs_d = obs.contiguous().to(dev) if fam == "proc" else obs.permute(0, 2, 1).contiguous().to(dev).permute(0, 2, 1)
+        loss, grads = torch.zeros(1, device=dev), torch.full((eng.n_params,), float("nan"), device=dev)
+        x = torch.empty(B, T, S, device=dev)
+        eng.workspace(B).fill_(float("nan"))
+        eng.elbo_step(flat, obs_d, u.to(dev), eps.to(dev), loss, grads=grads, x_out=x)
+        z = torch.randn(B, ospec.latent_dim, generator=torch.Generator().manual_seed(1)).to(dev)
+        outs.append((loss.clone(), grads.clone(), x.clone(), eng.dopri5_step_counts(B).clone(), eng.ode_solve(flat, z).clone()))
+    a, b = outs
+    assert torch.isfinite(a[0]).all() and torch.isfinite(b[1]).all()
+    assert torch.equal(a[3], b[3]) and torch.equal(a[2], b[2]) and torch.equal(a[4], b[4])
+    assert a[0].item() == b[0].item() and torch.equal(a[1], b[1])
+
+
 def test_dopri5_config2_full_size_properties():
     """BASELINE config[2] at full size (proc, B = 4096, T = 100, latent dim 50, dopri5 at torchdiffeq's default tolerances): the
     size-independent properties of the step -- finite, bitwise reproducible, and additive over trajectories (per-trajectory step-size
