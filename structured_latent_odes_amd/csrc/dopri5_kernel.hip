@@ -179,6 +179,34 @@ __device__ __forceinline__ float init_state(const float* w2, const float* b2, co
   return own ? sigmoidf_fast(v + b2[g]) : 0.f;
 }
 
+// the same with the output layer's weights requested at the top of the kernel (w2r[i][s] = w2[s][unit g + 8 i], b2r = b2[g])
+template <int S, int H>
+struct InitRegs { float w2[JL][8], b2; };
+template <int S, int H>
+__device__ __forceinline__ void init_request(const float* w2, const float* b2, int g, InitRegs<S, H>& r) {
+#pragma unroll
+  for (int i = 0; i < JL; ++i) {
+    const int jj = (g + G * i) < H ? g + G * i : 0;
+#pragma unroll
+    for (int q = 0; q < S; ++q) r.w2[i][q] = w2[q * H + jj];
+  }
+  r.b2 = b2[g < S ? g : 0];
+}
+template <int S, int H>
+__device__ __forceinline__ float init_state(const InitRegs<S, H>& r, const float (&pre0)[JL], int g, bool own) {
+  float o[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) o[q] = 0.f;
+#pragma unroll
+  for (int i = 0; i < JL; ++i) {
+    const float hp = (g + G * i) < H ? fmaxf(pre0[i], 0.f) : 0.f;
+#pragma unroll
+    for (int q = 0; q < S; ++q) o[q] = fmaf(r.w2[i][q], hp, o[q]);
+  }
+  const float v = group_scatter8(o, g);
+  return own ? sigmoidf_fast(v + r.b2) : 0.f;
+}
+
 // LDS of one trajectory group: the shared tables (time weights, head weights by unit) and per trajectory the hidden offsets, the
 // switching times, their order, the segment centres and the segment table
 template <int H>
@@ -200,71 +228,160 @@ struct GroupLds {
   }
 };
 
-// Fills the shared tables, this lane's hidden units (offsets u = W_z z + b_h of the dynamics net -> registers + LDS, pre-activations of
-// the init net -> pre0) and the trajectory's segment table.  [tlo, thi]: the integration range (segment centres are clamped to it).
-// Returns the dir bits.  Contains barriers: every thread of the workgroup calls it.
-// LPT: lanes per trajectory -- G (eight trajectories per wave) or 64 (one trajectory per wave: its eight lane groups run the set-up side by
+// LDS-DMA of `nrows` rows of a row-major matrix (row pitch `pitch` floats, `L` columns starting at src) into dst[nrows][LP] -- the pad
+// columns repeat the row's last element and are never used.  One 4-byte element per lane: the LDS destination of a wave instruction is
+// contiguous, the global source of each lane is free.  wave / nwaves: wave-uniform.
+__device__ __forceinline__ void dma_rows(float* dst, const float* src, int nrows, int L, int pitch, int LP, int wave, int nwaves, int lane) {
+  const int n = nrows * LP, step = nwaves * 64;
+  // (row, column) of this lane's element, advanced by `step` elements per instruction without dividing again (an integer division per
+  // DMA instruction was 7 k cycles of the set-up)
+  const int sq = step / LP, sr = step - sq * LP;   // (uniform)
+  int j = (wave * 64 + lane) / LP, l = (wave * 64 + lane) - j * LP;
+  for (int b0 = wave * 64; b0 < n; b0 += step) {
+    if (b0 + lane < n)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long long)j * pitch + min(l, L - 1)),
+                                       (__attribute__((address_space(3))) void*)(dst + b0), 4, 0, 0);
+    j += sq; l += sr;
+    if (l >= LP) { l -= LP; ++j; }
+  }
+}
+__device__ __forceinline__ void dma_flat(float* dst, const float* src, int n, int wave, int nwaves, int lane) {
+  for (int b0 = wave * 64; b0 < n; b0 += nwaves * 64)
+    if (b0 + lane < n)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + b0 + lane),
+                                       (__attribute__((address_space(3))) void*)(dst + b0), 4, 0, 0);
+}
+
+// Set-up of the adaptive kernels, part 1 (the kernel's FIRST instructions): every global operand of the set-up is requested at once -- the
+// z-columns of the dynamics net's hidden layer and the init net's first layer straight into LDS (LDS-DMA, rows padded to LP = 4 ceil(L / 4)
+// floats so that the unit sums read them 16 bytes at a time; they borrow the table region, which is written only after their last read),
+// the output times likewise, the small per-unit operands into registers.  One memory round trip instead of eight (cycle stamps in DESIGN
+// 3.3: 17 k of the set-up's 43 k cycles were spent waiting for one staged copy after the other).
+template <int H>
+struct UnitRegs {
+  float wt, wgd[4], bh[JL], b1[JL];   // w_t of unit tid (tid < 32); this thread's elements of the by-unit head table; biases of this lane's units
+};
+template <int S, int H>
+__device__ __forceinline__ void units_request(const float* wh, const float* bh, const float* wg, const float* wd, const float* w1, const float* b1,
+                                              const float* times, int T, float* s_times, int L, int tid, int nthreads, const GroupLds<H>& m,
+                                              UnitRegs<H>& ur) {
+  const int LP = (L + 3) & ~3, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthreads >> 6, lane = tid & 63, g = tid & (G - 1);
+  float* s_whz = reinterpret_cast<float*>(m.tab);   // [H][LP]  z-columns of the hidden layer
+  float* s_w1m = s_whz + H * LP;                    // [H][LP]
+  dma_rows(s_whz, wh + 1, H, L, 1 + L, LP, wave, nwaves, lane);
+  dma_rows(s_w1m, w1, H, L, L, LP, wave, nwaves, lane);
+  dma_flat(s_times, times, T, wave, nwaves, lane);
+  ur.wt = wh[(tid < H ? tid : 0) * (1 + L)];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {   // (H * 16 <= 4 x nthreads: 400 elements, 128 threads or more)
+    const int i = min(tid + q * nthreads, H * 16 - 1), j = i >> 4, c = i & 15, gg = min(c & 7, S - 1);
+    ur.wgd[q] = c < 8 ? wg[gg * H + j] : wd[gg * H + j];
+  }
+#pragma unroll
+  for (int i = 0; i < JL; ++i) {
+    const int jj = (g + G * i) < H ? g + G * i : 0;
+    ur.bh[i] = bh[jj]; ur.b1[i] = b1[jj];
+  }
+}
+
+// Part 2: fills the shared tables, this lane's hidden units (offsets u = W_z z + b_h of the dynamics net -> registers + LDS,
+// pre-activations of the init net -> pre0) and the trajectory's segment table.  The caller has written the latent rows s_z[slot][LP]
+// (pad = 0) and waits for nothing: the DMA of part 1 is drained here.  The integration range [tlo, thi] (segment centres are clamped to it) is read from the staged output times.  Returns the dir bits.  Contains barriers: every thread of the workgroup calls it.
+// LPT: lanes per trajectory -- G (eight trajectories per wave) or 16 / 32 / 64 (the lane groups of a trajectory run the set-up side by
 // side and write the same values)
 template <int S, int H, int LPT = G>
-__device__ __forceinline__ unsigned load_units(const float* wh, const float* bh, const float* wg, const float* bg, const float* wd,
-                                               const float* bd, const float* w1, const float* b1, const float* zrow, int L, int tid,
-                                               int nthreads, float tlo, float thi, const GroupLds<H>& m, Units& w, float (&pre0)[JL]) {
-  const int g = tid & (G - 1), slot = tid / LPT;
+__device__ __forceinline__ unsigned load_units(const UnitRegs<H>& ur, const float* bg, const float* bd, const float* zrow, int L, int tid,
+                                               int nthreads, const float* s_times, int T, const GroupLds<H>& m, Units& w, float (&pre0)[JL]) {
+  static_assert(H * 16 <= 4 * 128, "by-unit head table: four elements per thread");
+  const int g = tid & (G - 1), slot = tid / LPT, LP = (L + 3) & ~3;
   const bool own = g < S;
-  if (tid < 32) m.wt[tid] = tid < H ? wh[tid * (1 + L)] : 0.f;
-  for (int i = tid; i < H * 16; i += nthreads) {
-    const int j = i >> 4, c = i & 15, gg = c & 7;
-    m.wgd[i] = gg < S ? (c < 8 ? wg[gg * H + j] : wd[gg * H + j]) : 0.f;
+  if (tid < 32) m.wt[tid] = tid < H ? ur.wt : 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = tid + q * nthreads;
+    if (i < H * 16) m.wgd[i] = ((i & 7) < S) ? ur.wgd[q] : 0.f;
   }
-  // both hidden-layer matrices go through LDS (one coalesced pass; 2 x H x L strided global loads per lane otherwise): they borrow the
-  // table region, which is written only after the last read below
-  float* s_whz = reinterpret_cast<float*>(m.tab);   // [H][1 + L]
-  float* s_w1m = s_whz + H * (1 + L);               // [H][L]
-  stage_to_lds(s_whz, wh, H * (1 + L), tid, nthreads);
-  stage_to_lds(s_w1m, w1, H * L, tid, nthreads);
+  const float* s_whz = reinterpret_cast<const float*>(m.tab);   // [H][LP]
+  const float* s_w1m = s_whz + H * LP;                          // [H][LP]
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's LDS-DMA has landed; the barrier covers the others'
   __syncthreads();
+  const float tlo = fminf(s_times[0], s_times[T - 1]), thi = fmaxf(s_times[0], s_times[T - 1]);
   float* s_us = m.u + slot * 32;
   float* s_th = m.th + slot * 32;
   unsigned dm = 0u;
+  {
+    float uj[JL], pj[JL];
+    const float4 *whr[JL], *w1r[JL];
 #pragma unroll
-  for (int i = 0; i < JL; ++i) {
-    const int j = g + G * i;
-    const bool valid = j < H;
-    const int jj = valid ? j : 0;
-    float uj = bh[jj], pj = b1[jj];
-    const float* whr = s_whz + jj * (1 + L) + 1;
-    const float* w1r = s_w1m + jj * L;
-#pragma unroll 5
-    for (int l = 0; l < L; ++l) {
-      const float zl = zrow[l];
-      uj = fmaf(whr[l], zl, uj);
-      pj = fmaf(w1r[l], zl, pj);
+    for (int i = 0; i < JL; ++i) {
+      const int jj = (g + G * i) < H ? g + G * i : 0;
+      uj[i] = ur.bh[i]; pj[i] = ur.b1[i];
+      whr[i] = reinterpret_cast<const float4*>(s_whz + jj * LP);
+      w1r[i] = reinterpret_cast<const float4*>(s_w1m + jj * LP);
     }
-    const float wt = valid ? s_whz[jj * (1 + L)] : 0.f;
-    w.wt[i] = wt;
-    w.u[i] = valid ? uj : 0.f;
-    pre0[i] = valid ? pj : 0.f;
-    // switching time; w_t == 0: the predicate is the sign of u (always / never on)
-    float th = wt != 0.f ? -uj / wt : (uj > 0.f ? -BIGT : BIGT);
-    th = fminf(fmaxf(th, -BIGT), BIGT);
-    if (!valid) th = BIGT;
-    w.th[i] = th;
-    dm |= (wt >= 0.f || !valid) ? (1u << j) : 0u;
-    s_us[j] = w.u[i];
-    s_th[j] = th;
+    const float4* z4 = reinterpret_cast<const float4*>(zrow);
+    // sixteen bytes per read, the next quad's nine reads issued before this quad's 32 multiply-adds (two register sets in rotation); the
+    // sums run over l in order and the pad columns are not added at all
+    float4 zv[2], a[2][JL], b[2][JL];
+    const int nq = LP >> 2;
+    auto fetch = [&](int l4, int set) __attribute__((always_inline)) {
+      const int q = min(l4, nq - 1);
+      zv[set] = z4[q];
+#pragma unroll
+      for (int i = 0; i < JL; ++i) { a[set][i] = whr[i][q]; b[set][i] = w1r[i][q]; }
+    };
+    auto sums = [&](int l4, int set) __attribute__((always_inline)) {
+      const int nv = min(4, L - 4 * l4);   // (uniform) elements of this quad inside the row
+#pragma unroll
+      for (int i = 0; i < JL; ++i) {
+        uj[i] = fmaf(a[set][i].x, zv[set].x, uj[i]); pj[i] = fmaf(b[set][i].x, zv[set].x, pj[i]);
+        if (nv > 1) { uj[i] = fmaf(a[set][i].y, zv[set].y, uj[i]); pj[i] = fmaf(b[set][i].y, zv[set].y, pj[i]); }
+        if (nv > 2) { uj[i] = fmaf(a[set][i].z, zv[set].z, uj[i]); pj[i] = fmaf(b[set][i].z, zv[set].z, pj[i]); }
+        if (nv > 3) { uj[i] = fmaf(a[set][i].w, zv[set].w, uj[i]); pj[i] = fmaf(b[set][i].w, zv[set].w, pj[i]); }
+      }
+    };
+    fetch(0, 0);
+    for (int l4 = 0; l4 < nq; l4 += 2) {
+      fetch(l4 + 1, 1);
+      sums(l4, 0);
+      if (l4 + 1 < nq) {   // (uniform)
+        fetch(l4 + 2, 0);
+        sums(l4 + 1, 1);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < JL; ++i) {
+      const int j = g + G * i;
+      const bool valid = j < H;
+      const float wt = valid ? m.wt[j] : 0.f;
+      w.wt[i] = wt;
+      w.u[i] = valid ? uj[i] : 0.f;
+      pre0[i] = valid ? pj[i] : 0.f;
+      // switching time; w_t == 0: the predicate is the sign of u (always / never on)
+      float th = wt != 0.f ? -uj[i] / wt : (uj[i] > 0.f ? -BIGT : BIGT);
+      th = fminf(fmaxf(th, -BIGT), BIGT);
+      if (!valid) th = BIGT;
+      w.th[i] = th;
+      dm |= (wt >= 0.f || !valid) ? (1u << j) : 0u;
+      s_us[j] = w.u[i];
+      s_th[j] = th;
+    }
   }
   const unsigned dirmask = group_or(dm);
   __syncthreads();
-  // order of the switching times: rank by counting (ties by unit index)
+  // order of the switching times: rank by counting (ties by unit index); the 32 switching times come in as eight 16-byte reads
   {
+    float thk[32];
+    const float4* t4 = reinterpret_cast<const float4*>(s_th);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const float4 v = t4[q]; thk[4 * q] = v.x; thk[4 * q + 1] = v.y; thk[4 * q + 2] = v.z; thk[4 * q + 3] = v.w; }
     int rank[JL];
 #pragma unroll
     for (int i = 0; i < JL; ++i) rank[i] = 0;
-#pragma unroll 5
-    for (int kk = 0; kk < H; ++kk) {
-      const float thk = s_th[kk];
 #pragma unroll
-      for (int i = 0; i < JL; ++i) rank[i] += (int)((thk < w.th[i]) | ((thk == w.th[i]) & (kk < g + G * i)));   // (bitwise: no branches)
+    for (int kk = 0; kk < H; ++kk) {
+#pragma unroll
+      for (int i = 0; i < JL; ++i) rank[i] += (int)((thk[kk] < w.th[i]) | ((thk[kk] == w.th[i]) & (kk < g + G * i)));   // (bitwise: no branches)
     }
 #pragma unroll
     for (int i = 0; i < JL; ++i)
@@ -277,19 +394,31 @@ __device__ __forceinline__ unsigned load_units(const float* wh, const float* bh,
     float* ctr = m.ctr + slot * 32;
     float c = tlo;
     float va = own ? bg[g] : 0.f, vd = own ? bd[g] : 0.f, ala = 0.f, ald = 0.f;
-    for (int j = 0; j < H; ++j) {   // below every switching time the units with w_t < 0 are on
-      const bool on = !((dirmask >> j) & 1u);
-      const float wt = m.wt[j], pre = fmaf(wt, c, s_us[j]);
-      const float h = on ? pre : 0.f, hw = on ? wt : 0.f;
-      const float w1_ = m.wgd[j * 16 + g], w2_ = m.wgd[j * 16 + 8 + g];
-      va = fmaf(w1_, h, va); vd = fmaf(w2_, h, vd);
-      ala = fmaf(w1_, hw, ala); ald = fmaf(w2_, hw, ald);
+    constexpr int EB = 5;
+    for (int j0 = 0; j0 < H; j0 += EB) {   // below every switching time the units with w_t < 0 are on; operands five units at a time
+      float wtv[EB], usv[EB], w1v[EB], w2v[EB];
+#pragma unroll
+      for (int q = 0; q < EB; ++q) {
+        const int j = min(j0 + q, H - 1);
+        wtv[q] = m.wt[j]; usv[q] = s_us[j]; w1v[q] = m.wgd[j * 16 + g]; w2v[q] = m.wgd[j * 16 + 8 + g];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < EB; ++q) {
+        const int j = j0 + q;
+        if (j < H) {   // (uniform)
+          const bool on = !((dirmask >> j) & 1u);
+          const float pre = fmaf(wtv[q], c, usv[q]);
+          const float h = on ? pre : 0.f, hw = on ? wtv[q] : 0.f;
+          va = fmaf(w1v[q], h, va); vd = fmaf(w2v[q], h, vd);
+          ala = fmaf(w1v[q], hw, ala); ald = fmaf(w2v[q], hw, ald);
+        }
+      }
     }
     tab[g] = make_float4(va, vd, ala, ald);
     if (g == 0) ctr[0] = c;
     // five events at a time: their units, then the units' five operands, are read in two batches ahead of the chain (one event at a
     // time costs two dependent LDS round trips per event on the trajectory's critical path)
-    constexpr int EB = 5;
     for (int r0 = 0; r0 < H; r0 += EB) {
       int jv[EB];
       float thv[EB], wtv[EB], usv[EB], w1v[EB], w2v[EB];
@@ -335,46 +464,68 @@ template <int S>
 __device__ __forceinline__ float group_rms_fast(float v, bool own) { return __builtin_amdgcn_sqrtf(group_add(own ? v * v : 0.f) * (1.0f / S)); }
 #endif
 
+// z = loc + scale * eps (or the given z) of one trajectory -> LDS row [LP] (and z_out / eps_out), LPT lanes per trajectory: all the loads
+// first, then the stores (a load-use-store loop pays one memory round trip per latent dim and lane)
+template <int LPT>
+__device__ __forceinline__ void stage_latent(const DpK& k, long long bb, bool live, int lg, int L, int LP, float* s_zrow) {
+  constexpr int ZQ = (SLODE_MAX_L + LPT - 1) / LPT;
+  float lo[ZQ], sc[ZQ], ep[ZQ];
+#pragma unroll
+  for (int q = 0; q < ZQ; ++q) {
+    const int l = min(lg + LPT * q, L - 1);
+    const long long i = bb * L + l;
+    if (k.z) { lo[q] = k.z[i]; sc[q] = 0.f; ep[q] = 0.f; }
+    else { lo[q] = k.loc[i]; sc[q] = k.scale[i]; ep[q] = slode_eps_at(k.rng, k.eps, bb, L, l); }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < ZQ; ++q) {
+    const int l = lg + LPT * q;
+    if (l < LP) {
+      float zl = 0.f;
+      if (l < L && live) {
+        const long long i = bb * L + l;
+        if (k.z) zl = lo[q];
+        else {
+          if (k.rng.on && k.eps_out) k.eps_out[i] = ep[q];
+          zl = fmaf(sc[q], ep[q], lo[q]);
+        }
+        if (k.z_out) k.z_out[i] = zl;
+      }
+      s_zrow[l] = zl;
+    }
+  }
+}
+
 template <int S, int H>
 __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
   static_assert(S <= G && H <= G * JL && H <= 32, "one state component and JL hidden units per lane; unit bits in one word");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, g = tid & (G - 1), slot = tid >> 3, b = blockIdx.x * TPB + slot, L = k.L, T = k.T;
   GroupLds<H> m;
-  float* s_z = m.carve(smem, TPB);      // [TPB][L]
-  float* s_times = s_z + TPB * L;       // [T]
+  const int LP = (L + 3) & ~3;
+  float* s_z = m.carve(smem, TPB);      // [TPB][LP]
+  float* s_times = s_z + TPB * LP;      // [T]
   const bool live = b < k.B, own = g < S;
   const long long bb = live ? b : 0;
-  for (int l = g; l < L; l += G) {
-    const long long i = bb * L + l;
-    float zl = 0.f;
-    if (live) {
-      if (k.z) zl = k.z[i];
-      else {
-        const float e = slode_eps_at(k.rng, k.eps, bb, L, l);
-        if (k.rng.on && k.eps_out) k.eps_out[i] = e;
-        zl = fmaf(k.scale[i], e, k.loc[i]);
-      }
-      if (k.z_out) k.z_out[i] = zl;
-    }
-    s_z[slot * L + l] = zl;
-  }
-  stage_to_lds(s_times, k.times, T, tid, DNT);
-  __syncthreads();
+  UnitRegs<H> ur;
+  units_request<S, H>(k.wh, k.bh, k.wg, k.wd, k.w1, k.b1, k.times, T, s_times, L, tid, DNT, m, ur);   // every set-up operand: one round trip
+  InitRegs<S, H> ir;
+  init_request<S, H>(k.w2, k.b2, g, ir);
+  stage_latent<G>(k, bb, live, g, L, LP, s_z + slot * LP);
+  Units w;
+  float pre0[JL];
+  load_units<S, H>(ur, k.bg, k.bd, s_z + slot * LP, L, tid, DNT, s_times, T, m, w, pre0);
   // The controller only integrates forward in time: a grid that is not strictly increasing (torchdiffeq accepts a decreasing one by
   // integrating in -t; this engine rejects it -- Engine.set_times raises, and a caller that comes through the bare C ABI gets NaN
   // trajectories, hence a NaN loss, instead of a quietly extrapolated dense output) fails the solve for the whole workgroup.
   int bad_grid = 0;
   for (int i = tid; i + 1 < T; i += DNT) bad_grid |= !(s_times[i + 1] > s_times[i]);
   bad_grid = __syncthreads_or(bad_grid);
-  Units w;
-  float pre0[JL];
-  const float t_first = s_times[0], t_last = s_times[T - 1];
-  load_units<S, H>(k.wh, k.bh, k.wg, k.bg, k.wd, k.bd, k.w1, k.b1, s_z + slot * L, L, tid, DNT, fminf(t_first, t_last), fmaxf(t_first, t_last),
-                   m, w, pre0);
+  const float t_first = s_times[0];
   const float4* tab = m.tab + slot * (H + 1) * G;
   const float* ctr = m.ctr + slot * 32;
-  float y = init_state<S, H>(k.w2, k.b2, pre0, g, own);
+  float y = init_state<S, H>(ir, pre0, g, own);
   const int gs = own ? g : 0;
   float* xo = k.x + bb * T * S;
   if (live && own) xo[gs] = y;
@@ -498,37 +649,26 @@ __global__ void __launch_bounds__(WNTH) dopri5_lpt_kernel(const DpK k) {
   const int tid = threadIdx.x, lane = tid & 63, g = lane & (G - 1), e = (lane & (LPT - 1)) >> 3, slot = tid / LPT, b = blockIdx.x * WTP + slot;
   const int L = k.L, T = k.T;
   GroupLds<H> m;
-  float* s_z = m.carve(smem, WTP);      // [WTP][L]
-  float* s_times = s_z + WTP * L;       // [T]
+  const int LP = (L + 3) & ~3;
+  float* s_z = m.carve(smem, WTP);      // [WTP][LP]
+  float* s_times = s_z + WTP * LP;      // [T]
   const bool live = b < k.B, own = g < S;
   const long long bb = live ? b : 0;
-  for (int l = lane & (LPT - 1); l < L; l += LPT) {
-    const long long i = bb * L + l;
-    float zl = 0.f;
-    if (live) {
-      if (k.z) zl = k.z[i];
-      else {
-        const float ev = slode_eps_at(k.rng, k.eps, bb, L, l);
-        if (k.rng.on && k.eps_out) k.eps_out[i] = ev;
-        zl = fmaf(k.scale[i], ev, k.loc[i]);
-      }
-      if (k.z_out) k.z_out[i] = zl;
-    }
-    s_z[slot * L + l] = zl;
-  }
-  stage_to_lds(s_times, k.times, T, tid, WNTH);
-  __syncthreads();
+  UnitRegs<H> ur;
+  units_request<S, H>(k.wh, k.bh, k.wg, k.wd, k.w1, k.b1, k.times, T, s_times, L, tid, WNTH, m, ur);
+  InitRegs<S, H> ir;
+  init_request<S, H>(k.w2, k.b2, g, ir);
+  stage_latent<LPT>(k, bb, live, lane & (LPT - 1), L, LP, s_z + slot * LP);
+  Units w;
+  float pre0[JL];
+  load_units<S, H, LPT>(ur, k.bg, k.bd, s_z + slot * LP, L, tid, WNTH, s_times, T, m, w, pre0);
   int bad_grid = 0;
   for (int i = tid; i + 1 < T; i += WNTH) bad_grid |= !(s_times[i + 1] > s_times[i]);
   bad_grid = __syncthreads_or(bad_grid);
-  Units w;
-  float pre0[JL];
-  const float t_first = s_times[0], t_last = s_times[T - 1];
-  load_units<S, H, LPT>(k.wh, k.bh, k.wg, k.bg, k.wd, k.bd, k.w1, k.b1, s_z + slot * L, L, tid, WNTH, fminf(t_first, t_last), fmaxf(t_first, t_last),
-                        m, w, pre0);
+  const float t_first = s_times[0];
   const float4* tab = m.tab + slot * (H + 1) * G;
   const float* ctr = m.ctr + slot * 32;
-  float y = init_state<S, H>(k.w2, k.b2, pre0, g, own);
+  float y = init_state<S, H>(ir, pre0, g, own);
   const int gs = own ? g : 0;
   const bool wr = own && e == 0;          // the lane group that writes the trajectory's outputs and records
   float* xo = k.x + bb * T * S;
@@ -553,6 +693,7 @@ __global__ void __launch_bounds__(WNTH) dopri5_lpt_kernel(const DpK k) {
   int j = 1;
   int steps = bad_grid ? k.max_steps : 0, nacc = 0;
   float tj = s_times[j < T ? j : T - 1];   // the next output time, read ahead of its use
+  float tj1 = s_times[min(j + 1, T - 1)];  // (sixteen lanes per trajectory: and the one after)
   // stage i (t + dt {1/5, 3/10, 4/5, 8/9, 1}; stages 6 and 7 share the last) is evaluated by lane group i % NG in round i / NG
   const int base = ((lane & ~(LPT - 1)) + g) << 2;   // ds_bpermute byte index of lane (this trajectory, group 0, component g)
   // every lane leaves the loop: either all outputs written or max_steps reached (the missing outputs are then NaN).  The butterflies inside
@@ -561,21 +702,34 @@ __global__ void __launch_bounds__(WNTH) dopri5_lpt_kernel(const DpK k) {
     const bool act = live && j < T && steps < k.max_steps;
     ++steps;
     const float te5[5] = {t + dt * (1.f / 5), t + dt * (3.f / 10), t + dt * (4.f / 5), t + dt * (8.f / 9), t + dt};
-    float ar[NR], dr[NR];
+    float ar[NR], dr[NR], ter[NR];
+    int rr[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       float te = te5[4];
 #pragma unroll
       for (int i = 0; i < 5; ++i)
         if (i / NG == r) te = (e == i % NG) ? te5[i] : te;   // (groups without a stage in this round repeat the last one)
-      eval_ad<H>(te, w, g, own, tab, ctr, ar[r], dr[r]);
+      ter[r] = te;
     }
+    eval_ad_batch<H, NR>(ter, w, g, own, tab, ctr, ar, dr, rr);   // the rounds' table reads in one batch (one LDS round trip per attempt)
     float av[5], dv[5];
+    if (LPT == 16) {
+      // two lane groups = the two halves of a DPP row: the other group's value is one row rotation by eight lanes away (no LDS round trip)
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int srcl = base + ((i % NG) << 5);
-      av[i] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(srcl, (int)__float_as_uint(ar[i / NG])));
-      dv[i] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(srcl, (int)__float_as_uint(dr[i / NG])));
+      for (int r = 0; r < 2; ++r) {
+        const float oa = __uint_as_float(dpp_u<0x128>(__float_as_uint(ar[r]))), od = __uint_as_float(dpp_u<0x128>(__float_as_uint(dr[r])));   // row_ror:8
+        av[2 * r] = e == 0 ? ar[r] : oa; dv[2 * r] = e == 0 ? dr[r] : od;
+        av[2 * r + 1] = e == 0 ? oa : ar[r]; dv[2 * r + 1] = e == 0 ? od : dr[r];
+      }
+      av[4] = ar[2]; dv[4] = dr[2];   // (both groups evaluated t + dt in the last round)
+    } else {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int srcl = base + ((i % NG) << 5);
+        av[i] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(srcl, (int)__float_as_uint(ar[i / NG])));
+        dv[i] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute(srcl, (int)__float_as_uint(dr[i / NG])));
+      }
     }
     const float a2 = av[0], d2 = dv[0], a3 = av[1], d3 = dv[1], a4 = av[2], d4 = dv[2], a5 = av[3], d5 = dv[3], a6 = av[4], d6 = dv[4];
     const float k2 = a2 - d2 * fmaf(dt, (1.f / 5) * fcur, y);
@@ -607,6 +761,23 @@ __global__ void __launch_bounds__(WNTH) dopri5_lpt_kernel(const DpK k) {
         const float cc = dt * (k7 - 4.f * fcur) - 11.f * y - 5.f * y1 + 16.f * ymid;
         const float cd = dt * fcur;
         const float rdt = DP5_RCP(dt);
+        if (LPT == 16) {
+          // the step's outputs two at a time: lane group e evaluates and writes output j + e (half the trips of the one-at-a-time loop)
+          while (j < T && tj <= t1) {
+            const float tq = e ? tj1 : tj;
+            const bool in = j + e < T && tq <= t1;
+#ifdef SLODE_DP5_PRECISE
+            const double xq = ((double)tq - (double)t) / (double)dt;
+            if (own && in) xo[(j + e) * S + gs] = (float)((double)y + xq * ((double)cd + xq * ((double)cc + xq * ((double)cb + xq * (double)ca))));
+#else
+            const float xq = (tq - t) * rdt;
+            if (own && in) xo[(j + e) * S + gs] = y + xq * (cd + xq * (cc + xq * (cb + xq * ca)));
+#endif
+            j += (j + 1 < T && tj1 <= t1) ? 2 : 1;
+            tj = s_times[min(j, T - 1)];
+            tj1 = s_times[min(j + 1, T - 1)];
+          }
+        } else {
         while (j < T && tj <= t1) {
 #ifdef SLODE_DP5_PRECISE
           const double xq = ((double)tj - (double)t) / (double)dt;
@@ -617,6 +788,7 @@ __global__ void __launch_bounds__(WNTH) dopri5_lpt_kernel(const DpK k) {
 #endif
           ++j;
           tj = s_times[j < T ? j : T - 1];
+        }
         }
       }
       t = t1;
@@ -710,8 +882,9 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   float* s_gp = s_gu + BTP * 32;        // [BTP][32] dLoss/d(init-net pre-activation j)
   float* s_h0 = s_gp + BTP * 32;        // [BTP][32] init-net hidden values
   float* s_go = s_h0 + BTP * 32;        // [BTP][8]  dLoss/d(init-net output pre-activation)
-  float* s_z = s_go + BTP * 8;          // [BTP][L]
-  float* s_times = s_z + BTP * L;       // [T]
+  const int LP = (L + 3) & ~3;
+  float* s_z = s_go + BTP * 8;          // [BTP][LP]
+  float* s_times = s_z + BTP * LP;      // [T]
   float* s_big = s_times + ((T + 3) & ~3);   // dL/dx rows of the workgroup's trajectories | column-sum tile | W1, W_z for the latent gradient
   const float *s_wt = m.wt, *s_wgd = m.wgd;
   const bool live = b < k.B, own = g < S;
@@ -719,6 +892,8 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   const int gs = own ? g : 0;
   float* row = k.slabs + (long long)blockIdx.x * k.slab_stride;
   float* prm = row + 1;
+  UnitRegs<H> ur;   // the set-up's operands are requested first (its wait also covers the two larger DMA transfers below)
+  units_request<S, H>(k.wh, k.bh, k.wg, k.wd, k.w1, k.b1, k.times, T, s_times, L, tid, BNT, m, ur);
   {   // encoder head weights for the epilogue: LDS-DMA now, awaited with the dL/dx rows (the sweep hides both).  (These kernel arguments
       // are read through an opaque copy of the kernel-argument pointer, here and in the epilogue: see there.)
     typedef const __attribute__((address_space(4))) char* kaptr;
@@ -761,14 +936,19 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
     }
   }
   for (int i = 1 + tid; i <= k.nseg; i += BNT) row[i] = 0.f;   // (every element is written again below; completes long before)
-  for (int l = g; l < L; l += G) s_z[slot * L + l] = live ? k.z[bb * L + l] : 0.f;
-  stage_to_lds(s_times, k.times, T, tid, BNT);
-  __syncthreads();
+  {
+    constexpr int ZQ = SLODE_MAX_L / G;
+    float zv[ZQ];
+#pragma unroll
+    for (int q = 0; q < ZQ; ++q) zv[q] = k.z[bb * L + min(g + G * q, L - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < ZQ; ++q)
+      if (g + G * q < LP) s_z[slot * LP + g + G * q] = (live && g + G * q < L) ? zv[q] : 0.f;
+  }
   Units w;
   float pre0[JL];
-  const float t_first = s_times[0], t_last = s_times[T - 1];
-  const unsigned dirmask = load_units<S, H>(k.wh, k.bh, k.wg, k.bg, k.wd, k.bd, k.w1, k.b1, s_z + slot * L, L, tid, BNT, fminf(t_first, t_last),
-                                            fmaxf(t_first, t_last), m, w, pre0);
+  const unsigned dirmask = load_units<S, H>(ur, k.bg, k.bd, s_z + slot * LP, L, tid, BNT, s_times, T, m, w, pre0);
   const float* s_us = m.u + slot * 32;
   const int* s_rnk = m.rnk + slot * 32;
   const float4* tab = m.tab + slot * (H + 1) * G;
@@ -1056,7 +1236,7 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
       const int jj = o / L, l = o - jj * L;
       float a1 = 0.f, a2 = 0.f;
       for (int r = 0; r < BTP; ++r) {
-        const float zl = s_z[r * L + l];
+        const float zl = s_z[r * LP + l];
         a1 = fmaf(s_gp[r * 32 + jj], zl, a1);
         a2 = fmaf(s_gu[r * 32 + jj], zl, a2);
       }
@@ -1175,7 +1355,7 @@ hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, co
   const int lpt = rec ? rec->w64 : 8;    // lanes per trajectory of the forward solve: 8 (the round-2 kernel), 16, 32 or 64 -- all the same bits
   if (lpt == 16 || lpt == 32 || lpt == 64) {
     const int wtp = WNTH / lpt, grid = (s.B + wtp - 1) / wtp;
-    const size_t lds = sizeof(float) * ((size_t)GroupLds<25>::floats(wtp) + (size_t)wtp * s.L + (size_t)s.T);
+    const size_t lds = sizeof(float) * ((size_t)GroupLds<25>::floats(wtp) + (size_t)wtp * ((s.L + 3) & ~3) + (size_t)s.T);
 #define SLODE_DP5_LPT(SS, LL) SLODE_LAUNCH("dopri5_fwd", (dopri5_lpt_kernel<SS, 25, LL>), dim3(grid), dim3(WNTH), lds, stream, k)
     if (s.H != 25 || (s.S != 5 && s.S != 8)) return hipErrorInvalidValue;
     if (s.S == 5) { if (lpt == 16) SLODE_DP5_LPT(5, 16); else if (lpt == 32) SLODE_DP5_LPT(5, 32); else SLODE_DP5_LPT(5, 64); }
@@ -1184,7 +1364,7 @@ hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, co
     return hipGetLastError();
   }
   const int grid = (s.B + TPB - 1) / TPB;
-  const size_t lds = sizeof(float) * ((size_t)GroupLds<25>::floats(TPB) + (size_t)TPB * s.L + (size_t)s.T);
+  const size_t lds = sizeof(float) * ((size_t)GroupLds<25>::floats(TPB) + (size_t)TPB * ((s.L + 3) & ~3) + (size_t)s.T);
   if (s.H == 25 && s.S == 5) SLODE_LAUNCH("dopri5_fwd", (dopri5_kernel<5, 25>), dim3(grid), dim3(DNT), lds, stream, k);
   else if (s.H == 25 && s.S == 8) SLODE_LAUNCH("dopri5_fwd", (dopri5_kernel<8, 25>), dim3(grid), dim3(DNT), lds, stream, k);
   else return hipErrorInvalidValue;
@@ -1210,7 +1390,7 @@ hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay
   {
     using namespace grp;
     const int grid = slode_dopri5_rows(s);
-    const size_t fixed = (size_t)GroupLds<25>::floats(BTP) + (size_t)BTP * 32 * 3 + BTP * 8 + (size_t)BTP * s.L + (size_t)((s.T + 3) & ~3);
+    const size_t fixed = (size_t)GroupLds<25>::floats(BTP) + (size_t)BTP * 32 * 3 + BTP * 8 + (size_t)BTP * ((s.L + 3) & ~3) + (size_t)((s.T + 3) & ~3);
     const size_t tile = (size_t)(s.H + 1) * (2 * s.S + 2) * TS, wz = 2 * (size_t)s.H * s.L, gxrows = (size_t)BTP * s.T * s.S;
     size_t big = tile > wz ? tile : wz;
     const size_t encb = g_pre ? 2 * (size_t)BTP * s.L : 0;   // the rows' latent gradients (epilogue)

@@ -33,6 +33,14 @@ static int fail(slode_handle h, int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(h, SLODE_EHIP, "%s: %s", #expr, hipGetErrorString(e_));        \
   } while (0)
 
+// Lanes per trajectory of the forward adaptive solve: sixteen while that leaves every wave a SIMD of its own (B / 4 waves <= 4 SIMDs per CU;
+// the two lane groups of a trajectory share the stage evaluations: DESIGN 3.3, 94 against 101 us at B = 4096), eight beyond (the groups
+// repeat the Runge-Kutta combination: more instructions in total, which is what counts once the SIMDs hold several waves).
+static int dp5_lanes(const slode_ctx* h, int B) {
+  if (h->dp5_w64) return h->dp5_w64;
+  return (B + 3) / 4 <= 4 * h->num_cu ? 16 : 8;
+}
+
 static int stages_per_step(int method) { return method == SLODE_EULER ? 1 : (method == SLODE_MIDPOINT ? 2 : 3); }
 
 static const char* check_shape(const slode_shape* s) {
@@ -104,7 +112,7 @@ int slode_create(slode_handle* out, int device_id) {
   c->fold_on = getenv("SLODE_FOLD_NEXT") ? atoi(getenv("SLODE_FOLD_NEXT")) : 0;
   c->fold_valid = 0; c->fold_tmajor = 0; c->fold_ws = nullptr; c->fold_params = nullptr; c->fold_gen = 0;
   // (measured arms: 16 / 32 / 64 lanes per trajectory give the same bits and the same time, profiles/r04_f_ab11_*: the shipped form stays 8)
-  c->dp5_w64 = getenv("SLODE_DP5_LPT") ? atoi(getenv("SLODE_DP5_LPT")) : 8;
+  c->dp5_w64 = getenv("SLODE_DP5_LPT") ? atoi(getenv("SLODE_DP5_LPT")) : 0;   // 0: chosen per batch (dp5_lanes)
   c->chain_resident = 0; memset(c->chain_resident_sig, 0, sizeof(c->chain_resident_sig));
   // diagnostics and test hooks: the environment is read here, once per handle, never at launch time
   c->no_fold = getenv("SLODE_NO_FOLD") != nullptr;   // force the layer-by-layer encoder kernels
@@ -391,7 +399,7 @@ int slode_ode_solve_fwd(slode_handle h, const slode_shape* s, const slode_layout
   if (!times || !z || !x) return fail(h, SLODE_EINVAL, "times / z / x is NULL");
   if (s->method == SLODE_DOPRI5) {  // adaptive solve: per-trajectory controller, no stage-time table
     DopriRec plain{};   // (no guide sample, no records: a bare solve) -- carries the handle's choice of forward kernel
-    plain.w64 = h->dp5_w64;
+    plain.w64 = dp5_lanes(h, s->B);
     hipError_t e5 = slode_launch_dopri5(*s, *lay, params, times, z, x, (hipStream_t)stream, &plain);
     if (e5 == hipErrorInvalidValue) return fail(h, SLODE_EINVAL, "dopri5 kernel is instantiated for (S,H) in {(5,25),(8,25)}");
     HIP_TRY(h, e5);
@@ -608,7 +616,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
       // records: solver-side gradients as extra slab rows, the latent gradient through the solver added to g_loc / g_scale -> the
       // unfused encoder tail below
       DopriRec rc{w.loc, w.scale, eps, w.dp_z, bwd ? w.dp_rec : nullptr, w.dp_nrec, w.dp_kmax};
-      rc.w64 = h->dp5_w64;
+      rc.w64 = dp5_lanes(h, s->B);
       if (rng.on) {   // the forward kernel draws the noise once and materialises it: the scorer and the reverse sweep read the same values
         rc.rng = rng; rc.eps_out = w.dp_eps;
         a.rng = RngK{}; a.eps = w.dp_eps; eps = w.dp_eps;

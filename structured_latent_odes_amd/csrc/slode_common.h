@@ -60,7 +60,7 @@ struct slode_ctx {
   int fold_on, fold_valid, fold_tmajor;
   const void* fold_ws; const void* fold_params;
   unsigned int fold_gen;
-  int dp5_w64;            // SLODE_DP5_LPT: lanes per trajectory of the forward adaptive solve (8, 16, 32, 64)
+  int dp5_w64;            // SLODE_DP5_LPT: lanes per trajectory of the forward adaptive solve (8, 16, 32, 64; 0 = by batch size)
   int chain_resident; int chain_resident_sig[8];   // cached occupancy answer for the shape (T, C, F, K, P, Hc, L, n_params)
 };
 

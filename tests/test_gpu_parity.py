@@ -483,7 +483,7 @@ def test_dopri5_elbo_step_at_default_tolerances():
     assert torch.isfinite(grads).all()
 
 
-@pytest.mark.parametrize("lpt", ["16", "32", "64"])
+@pytest.mark.parametrize("lpt", ["16", "32", "64", "0"])   # "0": chosen by batch size (the default: sixteen up to 4 x SIMDs trajectories)
 @pytest.mark.parametrize("fam", ["cvs", "proc"])
 def test_dopri5_wider_lane_groups_equal_the_eight_lane_kernel_bitwise(fam, lpt, monkeypatch):
     """Round 4: the forward adaptive solve with 16 / 32 / 64 lanes per trajectory (lane = stage evaluation x state component: the stage times

@@ -10,9 +10,8 @@ def rep(old, new):
     assert old in s, old[:60]
     s = s.replace(old, new, 1)
 rep("  GroupLds<H> m;\n  float* s_gu = m.carve(smem, BTP);", "  unsigned long long clk[12]; int nclk = 0;\n#define CLK() clk[nclk++] = __builtin_readcyclecounter()\n  CLK();\n  GroupLds<H> m;\n  float* s_gu = m.carve(smem, BTP);")
-rep("  for (int l = g; l < L; l += G) s_z[slot * L + l] = live ? k.z[bb * L + l] : 0.f;", "  unsigned long long c_a = __builtin_readcyclecounter();\n  for (int l = g; l < L; l += G) s_z[slot * L + l] = live ? k.z[bb * L + l] : 0.f;\n  unsigned long long c_b = __builtin_readcyclecounter();")
-rep("  if (k.stage_gx) {   // the workgroup's BTP rows of dL/dx are one contiguous block", "  unsigned long long c_c = __builtin_readcyclecounter();\n  if (k.stage_gx) {   // the workgroup's BTP rows of dL/dx are one contiguous block")
-rep("  Units w;\n  float pre0[JL];\n  const float t_first = s_times[0], t_last = s_times[T - 1];\n  const unsigned dirmask = load_units", "  CLK();\n  Units w;\n  float pre0[JL];\n  const float t_first = s_times[0], t_last = s_times[T - 1];\n  const unsigned dirmask = load_units")
+rep("  {\n    constexpr int ZQ = SLODE_MAX_L / G;\n    float zv[ZQ];", "  unsigned long long c_a = __builtin_readcyclecounter();\n  {\n    constexpr int ZQ = SLODE_MAX_L / G;\n    float zv[ZQ];")
+rep("  Units w;\n  float pre0[JL];\n  const unsigned dirmask = load_units<S, H>(ur,", "  unsigned long long c_b = __builtin_readcyclecounter(), c_c = c_b;\n  CLK();\n  Units w;\n  float pre0[JL];\n  const unsigned dirmask = load_units<S, H>(ur,")
 rep("  const float* s_us = m.u + slot * 32;\n  const int* s_rnk", "  CLK();\n  const float* s_us = m.u + slot * 32;\n  const int* s_rnk")
 rep("  const bool any_bad = __syncthreads_or(live && bad) != 0;", "  CLK();\n  const bool any_bad = __syncthreads_or(live && bad) != 0;\n  CLK();")
 rep("    __syncthreads();\n    for (int col = tid; col < (H + 1) * NTMP; col += BNT) {", "    CLK();\n    __syncthreads();\n    for (int col = tid; col < (H + 1) * NTMP; col += BNT) {")
@@ -21,7 +20,7 @@ rep("    // latent gradient of this trajectory: through the init net and (exact 
 rep("    // sums over the workgroup's trajectories (fixed order): outer products with z", "    CLK();\n    // sums over the workgroup's trajectories (fixed order): outer products with z")
 i = s.index("}  // namespace grp")
 j = s.rfind("}\n", 0, i)
-s = s[:j] + "  CLK();\n  if ((blockIdx.x == 0 || blockIdx.x == 100) && tid == 0) printf(\"dp5bwd wg %d stage detail: zero-fill %llu z %llu times %llu gx+barrier %llu\\n\", (int)blockIdx.x, c_a-clk[0], c_b-c_a, c_c-c_b, clk[1]-c_c);\n  if ((blockIdx.x == 0 || blockIdx.x == 100) && tid == 0) printf(\"dp5bwd wg %d K %d cycles: stage %llu units+table %llu loop %llu wait %llu snapshots %llu colsums %llu initnet %llu latent %llu outer %llu\\n\", (int)blockIdx.x, K, clk[1]-clk[0], clk[2]-clk[1], clk[3]-clk[2], clk[4]-clk[3], clk[5]-clk[4], clk[6]-clk[5], clk[7]-clk[6], clk[8]-clk[7], clk[9]-clk[8]);\n" + s[j:]
+s = s[:j] + "  CLK();\n  if ((blockIdx.x == 0 || blockIdx.x == 100) && tid == 0) printf(\"dp5bwd wg %d stage detail: requests + zero-fill %llu, latent rows %llu (%llu %llu)\\n\", (int)blockIdx.x, c_a-clk[0], c_b-c_a, c_c-c_b, clk[1]-c_c);\n  if ((blockIdx.x == 0 || blockIdx.x == 100) && tid == 0) printf(\"dp5bwd wg %d K %d cycles: stage %llu units+table %llu loop %llu wait %llu snapshots %llu colsums %llu initnet %llu latent %llu outer %llu\\n\", (int)blockIdx.x, K, clk[1]-clk[0], clk[2]-clk[1], clk[3]-clk[2], clk[4]-clk[3], clk[5]-clk[4], clk[6]-clk[5], clk[7]-clk[6], clk[8]-clk[7], clk[9]-clk[8]);\n" + s[j:]
 tmp = os.path.join(src, "_dp5_clk.hip")
 open(tmp, "w").write(s)
 others = [f for f in ("slode_api.hip", "ode_kernel.hip", "encoder_kernels.hip", "misc_kernels.hip", "encoder_fused.hip", "aux_kernel.hip")]

@@ -22,7 +22,26 @@ rep("      dt *= factor;\n    }\n  }", "      dt *= factor;\n    }\n    asm vola
     "  if ((blockIdx.x == 0 || blockIdx.x == 100) && tid == 0) printf(\"dp5fwd wg %d attempts %d accepted %d: set-up %llu cycles; per attempt: evals %llu  stages+error %llu  norm %llu  accept block (records, outputs) %llu  factor %llu\\n\","
     " (int)blockIdx.x, steps, nacc, c_set - c_begin, acc[0] / steps, acc[1] / steps, acc[2] / steps, acc[3] / steps, acc[4] / steps);")
 rep("  extern __shared__ __attribute__((aligned(16))) float smem[];", "  extern __shared__ __attribute__((aligned(16))) float smem[];\n  const unsigned long long c_begin = __builtin_readcyclecounter();")
-s = s[:i0] + body + s[i1:]
+# set-up detail: stamps inside load_units (workgroup 0, thread 0) through a __device__ array
+pre = s[:i0]
+def rep_pre(old, new):
+    global pre
+    assert old in pre, old[:70]
+    pre = pre.replace(old, new, 1)
+rep_pre("template <int S, int H, int LPT = G>\n__device__ __forceinline__ unsigned load_units(",
+        "__device__ unsigned long long g_clk[8];\n#define CLK(i) if (blockIdx.x == 0 && threadIdx.x == 0) g_clk[i] = __builtin_readcyclecounter()\n"
+        "template <int S, int H, int LPT = G>\n__device__ __forceinline__ unsigned load_units(")
+rep_pre("  asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");              // this wave's LDS-DMA has landed; the barrier covers the others'\n  __syncthreads();",
+        "  CLK(0);\n  asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n  __syncthreads();\n  CLK(1);")
+rep_pre("  const unsigned dirmask = group_or(dm);\n  __syncthreads();", "  const unsigned dirmask = group_or(dm);\n  __syncthreads();\n  CLK(2);")
+rep_pre("  __syncthreads();\n  // segment table, event by event", "  __syncthreads();\n  CLK(3);\n  // segment table, event by event")
+rep_pre("  __syncthreads();\n  return dirmask;", "  __syncthreads();\n  CLK(4);\n  return dirmask;")
+rep("  float y = init_state<S, H>(ir, pre0, g, own);", "  float y = init_state<S, H>(ir, pre0, g, own);\n  asm volatile(\"\" :: \"v\"(y)); CLK(5);")
+rep("  unsigned long long c_set = __builtin_readcyclecounter()", "  asm volatile(\"\" :: \"v\"(dt)); CLK(6);\n  unsigned long long c_set = __builtin_readcyclecounter()")
+rep("  if ((blockIdx.x == 0 || blockIdx.x == 100) && tid == 0) printf(", "  if (blockIdx.x == 0 && tid == 0) printf(\"dp5fwd set-up (cycles from kernel start): requests issued, latent rows staged %llu, all set-up operands landed %llu, unit sums %llu, rank %llu, segment table %llu, init state %llu, initial step %llu\\n\","
+    " g_clk[0] - c_begin, g_clk[1] - c_begin, g_clk[2] - c_begin, g_clk[3] - c_begin, g_clk[4] - c_begin, g_clk[5] - c_begin, g_clk[6] - c_begin);\n"
+    "  if ((blockIdx.x == 0 || blockIdx.x == 100) && tid == 0) printf(")
+s = pre + body + s[i1:]
 tmp = os.path.join(src, "_dp5_clk.hip")
 open(tmp, "w").write(s)
 others = ["slode_api.hip", "ode_kernel.hip", "encoder_kernels.hip", "misc_kernels.hip", "encoder_fused.hip", "aux_kernel.hip"]
