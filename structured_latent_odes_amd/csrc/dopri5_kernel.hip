@@ -824,7 +824,7 @@ struct DpBK {
   const float *w1, *b1, *w2, *b2, *wh, *bh, *wg, *bg, *wd, *bd;
   float *g_loc, *g_scale, *slabs;   // the latent gradient through the solver is ADDED to the scorer's dLoss/dloc, dLoss/dscale [B][L]
   const float* eps;                 // (z = loc + scale eps);  slabs: one row per workgroup, slot 0 = loss (0 / NaN on a failed solve), then the ode segment
-  float* snap;                 // [B][H][4S] running sums parked when the sweep passes a switching time, by RANK (see grp::sweep_sample)
+  float* snap;                 // [B][2][H][4S] running sums parked when the sweep passes a switching time, by lane group and RANK (see grp::sweep_sample)
   int slab_stride, nseg, stage_gx;
   int o_w1, o_b1, o_w2, o_b2, o_wh, o_bh, o_wg, o_bg, o_wd, o_bd;
   // folded encoder path: once the latent gradient is complete the kernel also runs the encoder heads + tanh backward of its trajectories
@@ -835,12 +835,20 @@ struct DpBK {
 };
 
 namespace grp {
-// Reverse sweep in the forward kernel's mapping: EIGHT LANES PER TRAJECTORY, lane g = state component g.  The reverse mode of a
-// Dormand-Prince step is component-wise (the right-hand side a_g(t) - d_g(t) y_g couples components only through the time-dependent
-// coefficients), so every quantity of the step -- stage states, stage adjoints, dense-output sums, the running sums of the weight
-// gradients -- is ONE scalar per lane: nothing spilled (tools/check_spills.py), no per-stage staging through LDS.
-constexpr int BNT = 128;        // threads per workgroup
-constexpr int BTP = BNT / G;    // trajectories per workgroup (= per slab row)
+// Reverse sweep in the forward kernel's mapping: lane g = state component g.  The reverse mode of a Dormand-Prince step is component-wise
+// (the right-hand side a_g(t) - d_g(t) y_g couples components only through the time-dependent coefficients), so every quantity of the
+// step -- stage states, stage adjoints, dense-output sums, the running sums of the weight gradients -- is ONE scalar per lane: nothing
+// spilled (tools/check_spills.py), no per-stage staging through LDS.
+// SIXTEEN LANES PER TRAJECTORY (round 4; eight before): a lone wave issues one vector instruction per ~4.2 cycles whatever its
+// dependences (tools/ubench/lone_wave_issue.hip), so the sweep's time is its instruction count, and with eight lanes half the SIMDs
+// had no wave.  The two lane groups e = 0 / 1 of a trajectory (the halves of a DPP row) run the recomputation and the adjoint chain side
+// by side on the same values, and SHARE what is per stage: group e evaluates the coefficients of stages e, e + 2, e + 4 (three table
+// look-ups instead of six; the other three arrive by a row rotation) and owns those stages' samples of the weight-gradient sweep --
+// its own running sums, segment indices and parked snapshots, added to the other group's after the sweep.  Four waves per workgroup, one
+// per SIMD; the epilogues (column sums, outer products, encoder heads) have twice the threads.
+constexpr int BNT = 256;        // threads per workgroup
+constexpr int LB = 16;          // lanes per trajectory
+constexpr int BTP = BNT / LB;   // trajectories per workgroup (= per slab row)
 constexpr int TS = BTP + 1;     // padded trajectory stride of the column-sum tile
 
 // Weight gradients.  Along the time-ordered sequence of evaluation times (all stages of all accepted steps) unit j is switched on over
@@ -872,11 +880,11 @@ __device__ __forceinline__ void sweep_sample(float t, int now, float ga, float g
 }
 
 template <int S, int H>
-__global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
+__global__ void __launch_bounds__(BNT) __attribute__((amdgpu_waves_per_eu(2))) dopri5_bwd_kernel(const DpBK k) {   // (register budget of two waves per SIMD: left alone, the scheduler parks values in AGPRs)
   static_assert(S <= G && H <= G * JL && H <= 32, "one state component and JL hidden units per lane; unit bits in one word");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NTMP = 2 * S + 2;
-  const int tid = threadIdx.x, g = tid & (G - 1), slot = tid >> 3, b = blockIdx.x * BTP + slot, L = k.L, T = k.T;
+  const int tid = threadIdx.x, g = tid & (G - 1), e = (tid >> 3) & 1, slot = tid / LB, b = blockIdx.x * BTP + slot, L = k.L, T = k.T;
   GroupLds<H> m;
   float* s_gu = m.carve(smem, BTP);     // [BTP][32] dLoss/du_j
   float* s_gp = s_gu + BTP * 32;        // [BTP][32] dLoss/d(init-net pre-activation j)
@@ -948,7 +956,7 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   }
   Units w;
   float pre0[JL];
-  const unsigned dirmask = load_units<S, H>(ur, k.bg, k.bd, s_z + slot * LP, L, tid, BNT, s_times, T, m, w, pre0);
+  const unsigned dirmask = load_units<S, H, LB>(ur, k.bg, k.bd, s_z + slot * LP, L, tid, BNT, s_times, T, m, w, pre0);
   const float* s_us = m.u + slot * 32;
   const int* s_rnk = m.rnk + slot * 32;
   const float4* tab = m.tab + slot * (H + 1) * G;
@@ -958,7 +966,7 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   const int K = bad ? 0 : nr;
   const float* gxb = k.gx + bb * T * S + gs;
   const float* gxs = s_big + slot * T * S + gs;
-  float* snap = k.snap + bb * H * 4 * S;
+  float* snap = k.snap + (bb * 2 + e) * H * 4 * S;   // this lane group's snapshots
   float lam = 0.f, RSa = 0.f, RSd = 0.f, RTa = 0.f, RTd = 0.f;
   int cnt_prev = 0, cnt_first = 0;   // segment index of the previous sample of the sweep (falls along it) and of its first sample
   if (k.stage_gx) {   // the LDS-DMA of dL/dx issued at the top has landed (every wave drains its own, the barrier covers the others')
@@ -986,16 +994,23 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
   auto step = [&](const float t, const float dt, const float y, const bool act) __attribute__((always_inline)) {
     const float te0 = t, te1 = t + dt * (1.f / 5), te2 = t + dt * (3.f / 10), te3 = t + dt * (4.f / 5), te4 = t + dt * (8.f / 9), te5 = t + dt;
     // ---- forward recomputation of the stages from the recorded (t, dt, y) ------------------------------------------------------
-    const float tev[6] = {te0, te1, te2, te3, te4, te5};   // six independent table look-ups, their LDS reads in one batch
-    float av[6], dv[6];
-    int rv[6];
-    eval_ad_batch<H, 6>(tev, w, g, own, tab, ctr, av, dv, rv);
-    const float a0 = av[0], a1 = av[1], a2 = av[2], a3 = av[3], a4 = av[4], a5 = av[5];
-    const float d0 = dv[0], d1 = dv[1], d2 = dv[2], d3 = dv[3], d4 = dv[4], d5 = dv[5];
-    const int mk0 = rv[0], mk1 = rv[1], mk2 = rv[2], mk3 = rv[3], mk4 = rv[4], mk5 = rv[5];
-    const float ap0 = a0 * (1.f - a0), dp0 = d0 * (1.f - d0), ap1 = a1 * (1.f - a1), dp1 = d1 * (1.f - d1);
-    const float ap2 = a2 * (1.f - a2), dp2 = d2 * (1.f - d2), ap3 = a3 * (1.f - a3), dp3 = d3 * (1.f - d3);
-    const float ap4 = a4 * (1.f - a4), dp4 = d4 * (1.f - d4), ap5 = a5 * (1.f - a5), dp5 = d5 * (1.f - d5);
+    // this lane group's three stage times: three independent table look-ups, their LDS reads in one batch; the other group's
+    // coefficients by a rotation of the DPP row (sixteen lanes = one trajectory) by eight lanes
+    const float mt[3] = {e ? te1 : te0, e ? te3 : te2, e ? te5 : te4};
+    float ma[3], md[3];
+    int mr[3];
+    eval_ad_batch<H, 3>(mt, w, g, own, tab, ctr, ma, md, mr);
+    float oa[3], od[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      oa[r] = __uint_as_float(dpp_u<0x128>(__float_as_uint(ma[r])));   // row_ror:8
+      od[r] = __uint_as_float(dpp_u<0x128>(__float_as_uint(md[r])));
+    }
+    const float a0 = e ? oa[0] : ma[0], a1 = e ? ma[0] : oa[0], a2 = e ? oa[1] : ma[1], a3 = e ? ma[1] : oa[1], a4 = e ? oa[2] : ma[2], a5 = e ? ma[2] : oa[2];
+    const float d0 = e ? od[0] : md[0], d1 = e ? md[0] : od[0], d2 = e ? od[1] : md[1], d3 = e ? md[1] : od[1], d4 = e ? od[2] : md[2], d5 = e ? md[2] : od[2];
+    // sigmoid' of the stages whose samples this group owns
+    const float map0 = ma[0] * (1.f - ma[0]), mdp0 = md[0] * (1.f - md[0]), map1 = ma[1] * (1.f - ma[1]), mdp1 = md[1] * (1.f - md[1]);
+    const float map2 = ma[2] * (1.f - ma[2]), mdp2 = md[2] * (1.f - md[2]);
     const float k1 = a0 - d0 * y;
     const float ys2 = fmaf(dt, (1.f / 5) * k1, y);
     const float k2 = a1 - d1 * ys2;
@@ -1035,61 +1050,64 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
     float g5 = dgm * (187940372067.f / 1594534317056.f / 2);
     float g6 = dgm * (-1776094331.f / 19743644256.f / 2);
     const float g7 = fmaf(dgm, 11237099.f / 235043384.f / 2, gf1);
-    // stage 7: k7 = a5 - d5 * y1
-    float xa = g7 * ap5, xd = -g7 * y1 * dp5;
+    // stage 7: k7 = a5 - d5 * y1   (the samples -- head gradients at a stage time -- are formed below, by the group that owns the stage)
     gy1 = fmaf(-d5, g7, gy1);
     // y1 = y + dt * sum b_i k_i
     gy += gy1;
     const float dg = dt * gy1;
     g1 = fmaf(dg, 35.f / 384, g1); g3 = fmaf(dg, 500.f / 1113, g3); g4 = fmaf(dg, 125.f / 192, g4);
     g5 = fmaf(dg, -2187.f / 6784, g5); g6 = fmaf(dg, 11.f / 84, g6);
-    // stage 6 (same time as stage 7: one sample for both)
-    xa = fmaf(g6, ap5, xa);
-    xd = fmaf(-g6 * ys6, dp5, xd);
-    {
-      const float e = -d5 * g6;
-      gy += e;
-      const float de = dt * e;
+    {   // stage 6 (same time as stage 7: one sample for both)
+      const float ee = -d5 * g6;
+      gy += ee;
+      const float de = dt * ee;
       g1 = fmaf(de, 9017.f / 3168, g1); g2 = fmaf(de, -355.f / 33, g2); g3 = fmaf(de, 46732.f / 5247, g3);
       g4 = fmaf(de, 49.f / 176, g4); g5 = fmaf(de, -5103.f / 18656, g5);
     }
-    sweep_sample<S>(te5, mk5, xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
+    float xa, xd;
+    {   // samples at te5 (group 1: stages 7 + 6) | te4 (group 0: stage 5)
+      const float gs_ = e ? g7 : g5, ys_ = e ? y1 : ys5;
+      xa = gs_ * map2; xd = -gs_ * ys_ * mdp2;
+      xa = e ? fmaf(g6, map2, xa) : xa;
+      xd = e ? fmaf(-g6 * ys6, mdp2, xd) : xd;
+    }
+    sweep_sample<S>(mt[2], mr[2], xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
     {   // stage 5
-      xa = g5 * ap4; xd = -g5 * ys5 * dp4;
-      const float e = -d4 * g5;
-      gy += e;
-      const float de = dt * e;
+      const float ee = -d4 * g5;
+      gy += ee;
+      const float de = dt * ee;
       g1 = fmaf(de, 19372.f / 6561, g1); g2 = fmaf(de, -25360.f / 2187, g2); g3 = fmaf(de, 64448.f / 6561, g3);
       g4 = fmaf(de, -212.f / 729, g4);
     }
-    sweep_sample<S>(te4, mk4, xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
     {   // stage 4
-      xa = g4 * ap3; xd = -g4 * ys4 * dp3;
-      const float e = -d3 * g4;
-      gy += e;
-      const float de = dt * e;
+      const float ee = -d3 * g4;
+      gy += ee;
+      const float de = dt * ee;
       g1 = fmaf(de, 44.f / 45, g1); g2 = fmaf(de, -56.f / 15, g2); g3 = fmaf(de, 32.f / 9, g3);
     }
-    sweep_sample<S>(te3, mk3, xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
+    {   // samples at te3 (group 1: stage 4) | te2 (group 0: stage 3)
+      const float gs_ = e ? g4 : g3, ys_ = e ? ys4 : ys3;
+      xa = gs_ * map1; xd = -gs_ * ys_ * mdp1;
+    }
+    sweep_sample<S>(mt[1], mr[1], xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
     {   // stage 3
-      xa = g3 * ap2; xd = -g3 * ys3 * dp2;
-      const float e = -d2 * g3;
-      gy += e;
-      const float de = dt * e;
+      const float ee = -d2 * g3;
+      gy += ee;
+      const float de = dt * ee;
       g1 = fmaf(de, 3.f / 40, g1); g2 = fmaf(de, 9.f / 40, g2);
     }
-    sweep_sample<S>(te2, mk2, xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
     {   // stage 2
-      xa = g2 * ap1; xd = -g2 * ys2 * dp1;
-      const float e = -d1 * g2;
-      gy += e;
-      g1 = fmaf(dt * e, 1.f / 5, g1);
+      const float ee = -d1 * g2;
+      gy += ee;
+      g1 = fmaf(dt * ee, 1.f / 5, g1);
     }
-    sweep_sample<S>(te1, mk1, xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
+    {   // samples at te1 (group 1: stage 2) | te0 (group 0: stage 1)
+      const float gs_ = e ? g2 : g1, ys_ = e ? ys2 : y;
+      xa = gs_ * map0; xd = -gs_ * ys_ * mdp0;
+    }
+    sweep_sample<S>(mt[0], mr[0], xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
     // stage 1
-    xa = g1 * ap0; xd = -g1 * y * dp0;
     gy = fmaf(-d0, g1, gy);
-    sweep_sample<S>(te0, mk0, xa, xd, RSa, RSd, RTa, RTd, cnt_prev, cnt_first, act, own, gs, snap);
     lam = act ? gy : lam;
   };
   for (int it = 0; __any(it < K); it += 3) {
@@ -1111,9 +1129,10 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
     float* tile = s_big;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's own snapshot stores are back-readable
     // unit jj has rank rk among the switching times: passed during the sweep iff cnt_prev <= rk < cnt_first; at the earliest sample
-    // `t >= th` holds iff rk < cnt_prev, and the unit is on there iff that agrees with its direction.  Snapshots are read five units at
-    // a time, unconditionally (a select on a loaded value otherwise serialises one memory round trip per unit).
-    constexpr int UB = 5;
+    // `t >= th` holds iff rk < cnt_prev, and the unit is on there iff that agrees with its direction.  Snapshots are read thirteen units at
+    // a time (two memory round trips for the 25 units), unconditionally (a select on a loaded value otherwise serialises one round trip
+    // per unit).
+    constexpr int UB = 13;
     for (int j0 = 0; j0 < H; j0 += UB) {
       int rk[UB];
       float sv[UB][4];
@@ -1132,16 +1151,19 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
           const bool flipped = rk[q] >= cnt_prev && rk[q] < cnt_first, on_early = (rk[q] < cnt_prev) == (((dirmask >> jj) & 1u) != 0u);
           const float sma = flipped ? sv[q][0] : 0.f, smd = flipped ? sv[q][1] : 0.f, sta = flipped ? sv[q][2] : 0.f, std_ = flipped ? sv[q][3] : 0.f;
           // on at early times: flipped ? total - snapshot : total;   off at early times: flipped ? snapshot : 0
-          const float gma = on_early ? RSa - sma : sma, gmd = on_early ? RSd - smd : smd;
-          const float gta = on_early ? RTa - sta : sta, gtd = on_early ? RTd - std_ : std_;
+          // (this lane group's samples; the other group's share is one row rotation away -- both groups end with the same sums)
+          const float gma_e = on_early ? RSa - sma : sma, gmd_e = on_early ? RSd - smd : smd;
+          const float gta_e = on_early ? RTa - sta : sta, gtd_e = on_early ? RTd - std_ : std_;
+          const float gma = gma_e + __uint_as_float(dpp_u<0x128>(__float_as_uint(gma_e))), gmd = gmd_e + __uint_as_float(dpp_u<0x128>(__float_as_uint(gmd_e)));
+          const float gta = gta_e + __uint_as_float(dpp_u<0x128>(__float_as_uint(gta_e))), gtd = gtd_e + __uint_as_float(dpp_u<0x128>(__float_as_uint(gtd_e)));
           const float wt = s_wt[jj], uj = s_us[jj];
           const float w1 = s_wgd[jj * 16 + g], w2 = s_wgd[jj * 16 + 8 + g];   // 0 for lanes without a component
           const float gu = group_add(fmaf(w1, gma, w2 * gmd)), gwt = group_add(fmaf(w1, gta, w2 * gtd));
-          if (own) {
+          if (own && e == 0) {
             tile[(jj * NTMP + g) * TS + slot] = fmaf(wt, gta, uj * gma);
             tile[(jj * NTMP + S + g) * TS + slot] = fmaf(wt, gtd, uj * gmd);
           }
-          if (g == 0) {
+          if (g == 0 && e == 0) {
             tile[(jj * NTMP + 2 * S) * TS + slot] = gu;
             tile[(jj * NTMP + 2 * S + 1) * TS + slot] = gwt;
             s_gu[slot * 32 + jj] = gu;
@@ -1149,9 +1171,12 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
         }
       }
     }
-    if (own) {   // the constant-1 unit: head biases
-      tile[(H * NTMP + g) * TS + slot] = RSa;
-      tile[(H * NTMP + S + g) * TS + slot] = RSd;
+    {   // the constant-1 unit: head biases (both groups' samples)
+      const float ra = RSa + __uint_as_float(dpp_u<0x128>(__float_as_uint(RSa))), rd = RSd + __uint_as_float(dpp_u<0x128>(__float_as_uint(RSd)));
+      if (own && e == 0) {
+        tile[(H * NTMP + g) * TS + slot] = ra;
+        tile[(H * NTMP + S + g) * TS + slot] = rd;
+      }
     }
     __syncthreads();
     for (int col = tid; col < (H + 1) * NTMP; col += BNT) {
@@ -1200,29 +1225,29 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
     __syncthreads();
     // latent gradient of this trajectory: through the init net and (exact mode) through u = W_z z + b_h; the scorer's share it is
     // added to (and eps) is fetched up front, eight latent dims at a time
-    for (int l0 = g; l0 < L; l0 += G * 8) {
-      float gl_[8], gs_[8], ep_[8];
+    for (int l0 = tid & (LB - 1); l0 < L; l0 += LB * 4) {   // (sixteen lanes per trajectory: four latent dims per lane and pass)
+      float gl_[4], gs_[4], ep_[4];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const long long i = bb * L + min(l0 + q * G, L - 1);
+      for (int q = 0; q < 4; ++q) {
+        const long long i = bb * L + min(l0 + q * LB, L - 1);
         gl_[q] = k.g_loc[i]; gs_[q] = k.g_scale[i]; ep_[q] = k.eps[i];
       }
       __builtin_amdgcn_sched_barrier(0);
-      float a1[8], a2[8];   // through the init net / through the dynamics' hidden layer: 16 independent chains, unit-major
+      float a1[4], a2[4];   // through the init net / through the dynamics' hidden layer: 8 independent chains, unit-major
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { a1[q] = 0.f; a2[q] = 0.f; }
+      for (int q = 0; q < 4; ++q) { a1[q] = 0.f; a2[q] = 0.f; }
       for (int jj = 0; jj < H; ++jj) {
         const float gp = s_gp[slot * 32 + jj], gu = s_gu[slot * 32 + jj];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int l = min(l0 + q * G, L - 1);
+        for (int q = 0; q < 4; ++q) {
+          const int l = min(l0 + q * LB, L - 1);
           a1[q] = fmaf(s_w1[jj * L + l], gp, a1[q]);
           a2[q] = fmaf(s_wz[jj * L + l], gu, a2[q]);
         }
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int l = l0 + q * G;
+      for (int q = 0; q < 4; ++q) {
+        const int l = l0 + q * LB;
         if (l < L && live) {
           const float gl = a1[q] + (k.drop_z ? 0.f : a2[q]);
           const long long i = bb * L + l;
@@ -1299,9 +1324,9 @@ __global__ void __launch_bounds__(BNT) dopri5_bwd_kernel(const DpBK k) {
         s_g[(2 * r + 1) * L + l] = gs;
       }
       __syncthreads();
-      // item (hidden unit mm, half rq of the trajectories): the unit's two weights per latent dim are read once for eight trajectories
-      constexpr int RQ = BTP / 2;
-      for (int item = tid; item < 2 * Hc; item += BNT) {
+      // item (hidden unit mm, part rq of the trajectories): the unit's two weights per latent dim are read once for RQ trajectories
+      constexpr int NQ = BNT / 64, RQ = BTP / NQ;
+      for (int item = tid; item < NQ * Hc; item += BNT) {
         const int rq = item / Hc, mm = item - rq * Hc;
         float g0[RQ];
 #pragma unroll

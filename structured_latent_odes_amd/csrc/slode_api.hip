@@ -295,7 +295,7 @@ static Workspace carve(slode_handle h, const slode_shape& s_in, const slode_layo
     w.dp_z = take((size_t)s.B * s.L);
     w.dp_nrec = reinterpret_cast<int*>(take((size_t)s.B));
     w.dp_rec = take((size_t)w.dp_kmax * s.B * (s.S + 2));
-    w.dp_snap = take((size_t)s.B * s.H * 4 * s.S);   // running sums parked at the hidden units' switching times (dopri5_kernel.hip)
+    w.dp_snap = take((size_t)s.B * 2 * s.H * 4 * s.S);   // running sums parked at the hidden units' switching times, per lane group (dopri5_kernel.hip)
     w.dp_eps = take((size_t)s.B * s.L);              // the noise the forward kernel drew (eps == NULL), for the scorer and the reverse sweep
   }
   w.bytes = o * sizeof(float);
