@@ -1225,12 +1225,23 @@ __global__ void __launch_bounds__(BNT) __attribute__((amdgpu_waves_per_eu(2))) d
     __syncthreads();
     // latent gradient of this trajectory: through the init net and (exact mode) through u = W_z z + b_h; the scorer's share it is
     // added to (and eps) is fetched up front, eight latent dims at a time
+    // (the folded encoder path: the finished latent gradient also goes to glat and, as [g_loc | g_scale * scale], to the LDS rows the
+    // encoder-head epilogue reads -- behind W1 | W_z, which this loop still uses; its kernel arguments come through the kernel-argument
+    // pointer, see the epilogue)
+    typedef const __attribute__((address_space(4))) char* kaptr0;
+    kaptr0 ka0 = (kaptr0)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka0));
+    float* const l_glat = *(float* const __attribute__((address_space(4)))*)(ka0 + offsetof(DpBK, glat));
+    const float* const l_scale = *(const float* const __attribute__((address_space(4)))*)(ka0 + offsetof(DpBK, scale));
+    const bool l_enc = *(float* const __attribute__((address_space(4)))*)(ka0 + offsetof(DpBK, g_pre)) != nullptr;
+    float* s_g = s_big + 2 * H * L;   // [BTP][2][L]
     for (int l0 = tid & (LB - 1); l0 < L; l0 += LB * 4) {   // (sixteen lanes per trajectory: four latent dims per lane and pass)
-      float gl_[4], gs_[4], ep_[4];
+      float gl_[4], gs_[4], ep_[4], sc_[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const long long i = bb * L + min(l0 + q * LB, L - 1);
         gl_[q] = k.g_loc[i]; gs_[q] = k.g_scale[i]; ep_[q] = k.eps[i];
+        sc_[q] = l_enc ? l_scale[i] : 0.f;
       }
       __builtin_amdgcn_sched_barrier(0);
       float a1[4], a2[4];   // through the init net / through the dynamics' hidden layer: 8 independent chains, unit-major
@@ -1248,11 +1259,19 @@ __global__ void __launch_bounds__(BNT) __attribute__((amdgpu_waves_per_eu(2))) d
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int l = l0 + q * LB;
-        if (l < L && live) {
-          const float gl = a1[q] + (k.drop_z ? 0.f : a2[q]);
-          const long long i = bb * L + l;
-          k.g_loc[i] = gl_[q] + gl;
-          k.g_scale[i] = fmaf(gl, ep_[q], gs_[q]);
+        if (l < L) {
+          float o_loc = 0.f, o_ls = 0.f;
+          if (live) {
+            const float gl = a1[q] + (k.drop_z ? 0.f : a2[q]);
+            const long long i = bb * L + l;
+            o_loc = gl_[q] + gl;
+            const float o_sc = fmaf(gl, ep_[q], gs_[q]);
+            o_ls = o_sc * sc_[q];
+            k.g_loc[i] = o_loc;
+            k.g_scale[i] = o_sc;
+            if (l_enc) { l_glat[bb * 128 + l] = o_loc; l_glat[bb * 128 + 64 + l] = o_ls; }
+          }
+          if (l_enc) { s_g[(2 * slot) * L + l] = o_loc; s_g[(2 * slot + 1) * L + l] = o_ls; }
         }
       }
     }
@@ -1301,36 +1320,21 @@ __global__ void __launch_bounds__(BNT) __attribute__((amdgpu_waves_per_eu(2))) d
     float* const e_g_pre = DP5_KFIELD(fptr_t, g_pre);
     if (e_g_pre != nullptr) {
       const float* const e_hid = DP5_KFIELD(cfptr_t, enc_hid);
-      const float* const e_scale = DP5_KFIELD(cfptr_t, scale);
-      const float* const e_gloc = DP5_KFIELD(fptr_t, g_loc);
-      const float* const e_gscale = DP5_KFIELD(fptr_t, g_scale);
-      float* const e_glat = DP5_KFIELD(fptr_t, glat);
       const int Hc = DP5_KFIELD(int, Hc), zw_off = DP5_KFIELD(int, zw_off), eB = DP5_KFIELD(int, B);
 #undef DP5_KFIELD
-      __syncthreads();
       const float* s_zw = s_big + zw_off;     // [2][L][Hc]  z_loc.weight | z_scale.0.weight (in place since the prologue)
-      float* s_g = s_big;                     // [BTP][2][L] dLoss/dloc | dLoss/dscale * scale
-      for (int i = tid; i < BTP * L; i += BNT) {
-        const int r = i / L, l = i - r * L;
-        const long long b2 = (long long)blockIdx.x * BTP + r;
-        float gl = 0.f, gs = 0.f;
-        if (b2 < eB) {
-          gl = e_gloc[b2 * L + l];
-          gs = e_gscale[b2 * L + l] * e_scale[b2 * L + l];
-          e_glat[b2 * 128 + l] = gl;
-          e_glat[b2 * 128 + 64 + l] = gs;
-        }
-        s_g[(2 * r) * L + l] = gl;
-        s_g[(2 * r + 1) * L + l] = gs;
-      }
+      const float* s_g = s_big + 2 * H * L;   // [BTP][2][L] dLoss/dloc | dLoss/dscale * scale: written by the latent-gradient loop above
       __syncthreads();
       // item (hidden unit mm, part rq of the trajectories): the unit's two weights per latent dim are read once for RQ trajectories
       constexpr int NQ = BNT / 64, RQ = BTP / NQ;
       for (int item = tid; item < NQ * Hc; item += BNT) {
         const int rq = item / Hc, mm = item - rq * Hc;
-        float g0[RQ];
+        float g0[RQ], hv[RQ];
 #pragma unroll
-        for (int q = 0; q < RQ; ++q) g0[q] = 0.f;
+        for (int q = 0; q < RQ; ++q) {
+          g0[q] = 0.f;
+          hv[q] = e_hid[min((long long)blockIdx.x * BTP + rq * RQ + q, (long long)eB - 1) * Hc + mm];   // (requested ahead of the sums)
+        }
         for (int l = 0; l < L; ++l) {
           const float w0 = s_zw[l * Hc + mm], w1 = s_zw[(L + l) * Hc + mm];
 #pragma unroll
@@ -1342,10 +1346,7 @@ __global__ void __launch_bounds__(BNT) __attribute__((amdgpu_waves_per_eu(2))) d
 #pragma unroll
         for (int q = 0; q < RQ; ++q) {
           const long long b2 = (long long)blockIdx.x * BTP + rq * RQ + q;
-          if (b2 < eB) {
-            const float hv = e_hid[b2 * Hc + mm];
-            e_g_pre[b2 * 64 + mm] = g0[q] * (1.f - hv * hv);
-          }
+          if (b2 < eB) e_g_pre[b2 * 64 + mm] = g0[q] * (1.f - hv[q] * hv[q]);
         }
       }
     }
@@ -1418,7 +1419,7 @@ hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay
     const size_t fixed = (size_t)GroupLds<25>::floats(BTP) + (size_t)BTP * 32 * 3 + BTP * 8 + (size_t)BTP * ((s.L + 3) & ~3) + (size_t)((s.T + 3) & ~3);
     const size_t tile = (size_t)(s.H + 1) * (2 * s.S + 2) * TS, wz = 2 * (size_t)s.H * s.L, gxrows = (size_t)BTP * s.T * s.S;
     size_t big = tile > wz ? tile : wz;
-    const size_t encb = g_pre ? 2 * (size_t)BTP * s.L : 0;   // the rows' latent gradients (epilogue)
+    const size_t encb = g_pre ? 2 * (size_t)s.H * s.L + 2 * (size_t)BTP * s.L : 0;   // the rows' latent gradients (epilogue), behind W1 | W_z
     if (encb > big) big = encb;
     const size_t zwf = g_pre ? 2 * (size_t)s.L * s.Hc : 0;   // dedicated copy of the encoder head weights (fused encoder-head backward)
     k.stage_gx = sizeof(float) * (fixed + zwf + (gxrows > big ? gxrows : big)) <= 160 * 1024 ? 1 : 0;   // dL/dx rows in LDS when they fit
