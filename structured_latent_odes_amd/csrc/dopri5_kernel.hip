@@ -44,6 +44,7 @@ struct DpK {
   int kmax;
   float rtol, atol;
   int max_steps;
+  float* tabs;       // [workgroup][TABF] or nullptr: the set-up's tables (GroupLds block + init-net pre-activations) for the reverse sweep
   RngK rng;          // on: eps is drawn here (Philox, slode_common.h) and written to eps_out for the scorer and the reverse sweep
   float* eps_out;
 };
@@ -464,6 +465,23 @@ template <int S>
 __device__ __forceinline__ float group_rms_fast(float v, bool own) { return __builtin_amdgcn_sqrtf(group_add(own ? v * v : 0.f) * (1.0f / S)); }
 #endif
 
+// The set-up's result -- the workgroup's whole GroupLds block (segment tables, switching times, their order, head tables) and the init
+// net's pre-activations -- goes to global memory for the reverse sweep, which rebuilds exactly these tables for exactly these sixteen
+// trajectories otherwise (18 k cycles of its set-up): sixteen bytes per lane and store, fire and forget.
+template <int H>
+constexpr int tab_floats() { return GroupLds<H>::floats(16) + 16 * 32; }
+template <int H>
+__device__ __forceinline__ void dump_tables(float* tabs, const float* smem, const float (&pre0)[JL], int slot, int g, bool writer, int tid, int nthreads) {
+  float* dst = tabs + (size_t)blockIdx.x * tab_floats<H>();
+  constexpr int n4 = GroupLds<H>::floats(16) / 4;
+  const float4* src = reinterpret_cast<const float4*>(smem);
+  for (int i = tid; i < n4; i += nthreads) reinterpret_cast<float4*>(dst)[i] = src[i];
+  if (writer) {
+#pragma unroll
+    for (int i = 0; i < JL; ++i) dst[4 * n4 + slot * 32 + g + G * i] = pre0[i];
+  }
+}
+
 // z = loc + scale * eps (or the given z) of one trajectory -> LDS row [LP] (and z_out / eps_out), LPT lanes per trajectory: all the loads
 // first, then the stores (a load-use-store loop pays one memory round trip per latent dim and lane)
 template <int LPT>
@@ -516,6 +534,7 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
   Units w;
   float pre0[JL];
   load_units<S, H>(ur, k.bg, k.bd, s_z + slot * LP, L, tid, DNT, s_times, T, m, w, pre0);
+  if (k.tabs) dump_tables<H>(k.tabs, smem, pre0, slot, g, true, tid, DNT);
   // The controller only integrates forward in time: a grid that is not strictly increasing (torchdiffeq accepts a decreasing one by
   // integrating in -t; this engine rejects it -- Engine.set_times raises, and a caller that comes through the bare C ABI gets NaN
   // trajectories, hence a NaN loss, instead of a quietly extrapolated dense output) fails the solve for the whole workgroup.
@@ -662,6 +681,7 @@ __global__ void __launch_bounds__(WNTH) dopri5_lpt_kernel(const DpK k) {
   Units w;
   float pre0[JL];
   load_units<S, H, LPT>(ur, k.bg, k.bd, s_z + slot * LP, L, tid, WNTH, s_times, T, m, w, pre0);
+  if (LPT == 16 && k.tabs) dump_tables<H>(k.tabs, smem, pre0, slot, g, e == 0, tid, WNTH);   // (sixteen trajectories per workgroup, as the reverse sweep)
   int bad_grid = 0;
   for (int i = tid; i + 1 < T; i += WNTH) bad_grid |= !(s_times[i + 1] > s_times[i]);
   bad_grid = __syncthreads_or(bad_grid);
@@ -824,6 +844,7 @@ struct DpBK {
   const float *w1, *b1, *w2, *b2, *wh, *bh, *wg, *bg, *wd, *bd;
   float *g_loc, *g_scale, *slabs;   // the latent gradient through the solver is ADDED to the scorer's dLoss/dloc, dLoss/dscale [B][L]
   const float* eps;                 // (z = loc + scale eps);  slabs: one row per workgroup, slot 0 = loss (0 / NaN on a failed solve), then the ode segment
+  const float* tabs;           // the forward kernel's tables of this workgroup's trajectories (dump_tables) or nullptr: rebuilt here
   float* snap;                 // [B][2][H][4S] running sums parked when the sweep passes a switching time, by lane group and RANK (see grp::sweep_sample)
   int slab_stride, nseg, stage_gx;
   int o_w1, o_b1, o_w2, o_b2, o_wh, o_bh, o_wg, o_bg, o_wd, o_bd;
@@ -901,7 +922,21 @@ __global__ void __launch_bounds__(BNT) __attribute__((amdgpu_waves_per_eu(2))) d
   float* row = k.slabs + (long long)blockIdx.x * k.slab_stride;
   float* prm = row + 1;
   UnitRegs<H> ur;   // the set-up's operands are requested first (its wait also covers the two larger DMA transfers below)
-  units_request<S, H>(k.wh, k.bh, k.wg, k.wd, k.w1, k.b1, k.times, T, s_times, L, tid, BNT, m, ur);
+  float pre0[JL];
+  if (k.tabs) {   // the forward kernel's tables of the same sixteen trajectories: one 16-byte LDS-DMA pass instead of the set-up
+    const float* src = k.tabs + (size_t)blockIdx.x * tab_floats<H>();
+    constexpr int n = GroupLds<H>::floats(BTP);
+    static_assert(BTP == 16 && n % 4 == 0, "the forward kernels dump the tables of sixteen trajectories");
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, NW = BNT >> 6;
+    for (int b0 = wv * 256; b0 < n; b0 += NW * 256)
+      if (b0 + lane * 4 < n)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + b0 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(smem + b0), 16, 0, 0);
+    dma_flat(s_times, k.times, T, wv, NW, lane);
+#pragma unroll
+    for (int i = 0; i < JL; ++i) pre0[i] = src[n + slot * 32 + g + G * i];
+  } else
+    units_request<S, H>(k.wh, k.bh, k.wg, k.wd, k.w1, k.b1, k.times, T, s_times, L, tid, BNT, m, ur);
   {   // encoder head weights for the epilogue: LDS-DMA now, awaited with the dL/dx rows (the sweep hides both).  (These kernel arguments
       // are read through an opaque copy of the kernel-argument pointer, here and in the epilogue: see there.)
     typedef const __attribute__((address_space(4))) char* kaptr;
@@ -955,8 +990,23 @@ __global__ void __launch_bounds__(BNT) __attribute__((amdgpu_waves_per_eu(2))) d
       if (g + G * q < LP) s_z[slot * LP + g + G * q] = (live && g + G * q < L) ? zv[q] : 0.f;
   }
   Units w;
-  float pre0[JL];
-  const unsigned dirmask = load_units<S, H, LB>(ur, k.bg, k.bd, s_z + slot * LP, L, tid, BNT, s_times, T, m, w, pre0);
+  unsigned dirmask;
+  if (k.tabs) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA has landed; the barrier covers the others'
+    __syncthreads();
+    unsigned dm = 0u;
+#pragma unroll
+    for (int i = 0; i < JL; ++i) {   // this lane's units, as load_units leaves them
+      const int j = g + G * i;
+      const bool valid = j < H;
+      w.wt[i] = valid ? m.wt[j] : 0.f;
+      w.u[i] = m.u[slot * 32 + j];
+      w.th[i] = m.th[slot * 32 + j];
+      dm |= (w.wt[i] >= 0.f || !valid) ? (1u << j) : 0u;
+    }
+    dirmask = group_or(dm);
+  } else
+    dirmask = load_units<S, H, LB>(ur, k.bg, k.bd, s_z + slot * LP, L, tid, BNT, s_times, T, m, w, pre0);
   const float* s_us = m.u + slot * 32;
   const int* s_rnk = m.rnk + slot * 32;
   const float4* tab = m.tab + slot * (H + 1) * G;
@@ -1357,6 +1407,7 @@ __global__ void __launch_bounds__(BNT) __attribute__((amdgpu_waves_per_eu(2))) d
 
 }  // namespace
 
+size_t slode_dopri5_tab_floats(const slode_shape& s) { (void)s; return (size_t)tab_floats<25>(); }   // per workgroup of sixteen trajectories (H = 25)
 int slode_dopri5_rows(const slode_shape& s) { return (s.B + grp::BTP - 1) / grp::BTP; }   // slab rows of the reverse sweep: one per workgroup
 
 int slode_dopri5_kmax(const slode_shape& s) {
@@ -1370,9 +1421,9 @@ hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, co
   DpK k;
   k.B = s.B; k.T = s.T; k.L = s.L; k.times = times; k.z = z; k.x = x;
   k.loc = k.scale = k.eps = nullptr; k.z_out = nullptr; k.rec = nullptr; k.nrec = nullptr; k.kmax = 0;
-  k.rng = RngK{}; k.eps_out = nullptr;
+  k.rng = RngK{}; k.eps_out = nullptr; k.tabs = nullptr;
   if (rec) { k.loc = rec->loc; k.scale = rec->scale; k.eps = rec->eps; k.z_out = rec->z_out; k.rec = rec->rec; k.nrec = rec->nrec; k.kmax = rec->kmax;
-             k.rng = rec->rng; k.eps_out = rec->eps_out; }
+             k.rng = rec->rng; k.eps_out = rec->eps_out; k.tabs = rec->tabs; }
   k.w1 = p + lay.init_w1; k.b1 = p + lay.init_b1; k.w2 = p + lay.init_w2; k.b2 = p + lay.init_b2;
   k.wh = p + lay.dyn_wh; k.bh = p + lay.dyn_bh; k.wg = p + lay.dyn_wg; k.bg = p + lay.dyn_bg; k.wd = p + lay.dyn_wd; k.bd = p + lay.dyn_bd;
   k.rtol = s.rtol > 0.f ? s.rtol : 1e-7f;
@@ -1403,6 +1454,7 @@ hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay
   DpBK k;
   k.scale = rec.scale; k.enc_hid = enc_hid; k.g_pre = g_pre; k.glat = glat; k.Hc = s.Hc;
   k.enc_zloc_w = p + lay.zloc_w; k.enc_zls_w = p + lay.zls_w;
+  k.tabs = rec.tabs;
   k.snap = snap; k.g_loc = g_loc; k.g_scale = g_scale; k.eps = rec.eps;
   k.B = s.B; k.T = s.T; k.L = s.L; k.kmax = rec.kmax; k.drop_z = drop_z;
   k.times = times; k.z = rec.z_out; k.gx = gx; k.rec = rec.rec; k.nrec = rec.nrec;

@@ -203,7 +203,7 @@ struct Workspace {
   float *weff, *rowsum, *wprime, *beff, *gslabs, *conv_slabs, *glat, *gslabs2, *gslabs3;  // folded encoder path
   unsigned int* counter;
   // dopri5 training: solution, dLoss/dx, external latent gradient, latent sample, step records
-  float *dp_x, *dp_gx, *dp_gz, *dp_z, *dp_rec, *dp_snap, *dp_eps;
+  float *dp_x, *dp_gx, *dp_gz, *dp_z, *dp_rec, *dp_snap, *dp_eps, *dp_tabs;
   float* sigtab;   // [4][C*T] likelihood-scale table of the step (OdeLaunch::sigtab)
   int* dp_nrec;
   int dp_kmax, dp_rows;
@@ -295,6 +295,7 @@ static Workspace carve(slode_handle h, const slode_shape& s_in, const slode_layo
     w.dp_z = take((size_t)s.B * s.L);
     w.dp_nrec = reinterpret_cast<int*>(take((size_t)s.B));
     w.dp_rec = take((size_t)w.dp_kmax * s.B * (s.S + 2));
+    w.dp_tabs = take((size_t)slode_dopri5_rows(s) * slode_dopri5_tab_floats(s));   // the forward kernel's set-up tables, handed to the reverse sweep
     w.dp_snap = take((size_t)s.B * 2 * s.H * 4 * s.S);   // running sums parked at the hidden units' switching times, per lane group (dopri5_kernel.hip)
     w.dp_eps = take((size_t)s.B * s.L);              // the noise the forward kernel drew (eps == NULL), for the scorer and the reverse sweep
   }
@@ -617,6 +618,8 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
       // unfused encoder tail below
       DopriRec rc{w.loc, w.scale, eps, w.dp_z, bwd ? w.dp_rec : nullptr, w.dp_nrec, w.dp_kmax};
       rc.w64 = dp5_lanes(h, s->B);
+      const bool hand_over = bwd && (rc.w64 == 8 || rc.w64 == 16);   // forward workgroups of sixteen trajectories, as the reverse sweep's
+      rc.tabs = hand_over ? w.dp_tabs : nullptr;
       if (rng.on) {   // the forward kernel draws the noise once and materialises it: the scorer and the reverse sweep read the same values
         rc.rng = rng; rc.eps_out = w.dp_eps;
         a.rng = RngK{}; a.eps = w.dp_eps; eps = w.dp_eps;
@@ -634,6 +637,7 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     HIP_TRY(h, e);
     if (dp5 && bwd) {
       DopriRec rc{w.loc, w.scale, eps, w.dp_z, w.dp_rec, w.dp_nrec, w.dp_kmax};
+      { const int l5 = dp5_lanes(h, s->B); rc.tabs = (l5 == 8 || l5 == 16) ? w.dp_tabs : nullptr; }
       HIP_TRY(h, slode_launch_dopri5_bwd(*s, *lay, params, times, rc, w.dp_gx, w.g_loc, w.g_scale, w.ode_slabs + (size_t)w.ode_grid * w.ode_stride,
                                          w.ode_stride, s->grad_mode == SLODE_GRAD_REFERENCE_ADJOINT ? 1 : 0, w.dp_snap, st,
                                          folded ? w.hid : nullptr, folded ? w.g_pre : nullptr, folded ? w.glat : nullptr));

@@ -531,14 +531,16 @@ hipError_t slode_launch_dynamics_eval(const slode_shape& s, const slode_layout& 
 // rng.on: eps is drawn by the forward kernel and written to eps_out, which the scorer and the reverse sweep then read as `eps`
 struct DopriRec { const float *loc, *scale, *eps; float* z_out; float* rec; int* nrec; int kmax; RngK rng{}; float* eps_out = nullptr;
                   int w64 = 8;   // lanes per trajectory of the forward solve: 8 (dopri5_kernel), 16 / 32 / 64 (dopri5_lpt_kernel); SLODE_DP5_LPT
+                  float* tabs = nullptr;   // [rows][slode_dopri5_tab_floats]: the forward kernel's per-workgroup tables, handed to the reverse sweep
 };
+size_t slode_dopri5_tab_floats(const slode_shape& s);
 int slode_dopri5_kmax(const slode_shape& s);
 int slode_dopri5_rows(const slode_shape& s);
 hipError_t slode_launch_dopri5(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const float* z,
                                float* x, hipStream_t stream, const DopriRec* rec = nullptr);
 hipError_t slode_launch_dopri5_bwd(const slode_shape& s, const slode_layout& lay, const float* params, const float* times, const DopriRec& rec,
                                    const float* gx, float* g_loc, float* g_scale, float* slabs, int slab_stride, int drop_z, float* snap, hipStream_t stream,
-                                   const float* enc_hid = nullptr, float* g_pre = nullptr, float* glat = nullptr);
+                                   const float* enc_hid = nullptr, float* g_pre = nullptr, float* glat = nullptr);   // (rec.tabs: tables of the forward kernel)
 hipError_t slode_launch_adam_k(int64_t n, const float* g, const AdamHost& a, hipStream_t stream);
 hipError_t slode_launch_adam(int64_t n, float* p, const float* g, float* m, float* v, float lr, float b1, float b2,
                              float eps, int64_t step, hipStream_t stream);

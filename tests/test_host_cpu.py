@@ -53,8 +53,8 @@ def test_layout_matches_hand_count_and_rejects_bad_shapes():
 def test_workspace_accounts_for_the_dopri5_step_records():
     """slode_workspace_bytes (host arithmetic, no device needed): the adaptive solver's training path needs, on top of the fixed-grid
     workspace, the solution and dLoss/dx ([B,T,S] each), two [B,L] latent buffers, the per-trajectory step counts and the accepted-step
-    records [kmax][B][S+2] with kmax = 2^26 / (B*(S+2)) clamped to [64, 2048], and the [B][H][4S] running sums parked at the hidden
-    units' switching times (include/slode.h)."""
+    records [kmax][B][S+2] with kmax = 2^26 / (B*(S+2)) clamped to [64, 2048], the [B][2][H][4S] running sums parked at the hidden
+    units' switching times and the forward kernel's set-up tables per sixteen trajectories (include/slode.h)."""
     from structured_latent_odes_amd import _lib as L
     lib = L.load()
     lib.slode_workspace_bytes.restype = C.c_size_t
@@ -63,7 +63,9 @@ def test_workspace_accounts_for_the_dopri5_step_records():
         adaptive = lib.slode_workspace_bytes(None, C.byref(_shape(B=B, method=L.DOPRI5)))
         s = _shape(B=B)
         kmax = max(64, min(2048, (1 << 26) // (B * (s.S + 2))))
-        need = 4 * (2 * B * s.T * s.S + 2 * B * s.L + B + kmax * B * (s.S + 2) + 2 * B * s.H * 4 * s.S)   # (snapshots: one set per lane group of the reverse sweep)
+        tabf = (32 + 25 * 16 + 16 * 32 * 5 + 16 * 26 * 8 * 4) + 16 * 32       # the forward kernel's tables of sixteen trajectories, handed to the reverse sweep
+        need = 4 * (2 * B * s.T * s.S + 2 * B * s.L + B + kmax * B * (s.S + 2) + 2 * B * s.H * 4 * s.S   # (snapshots: one set per lane group of the reverse sweep)
+                    + ((B + 15) // 16) * tabf)
         assert fixed > 0 and adaptive >= fixed + need, (B, fixed, adaptive, need)
         assert adaptive <= fixed + need + 4 * (64 * 8 + ((B + 15) // 16) * 8192), (B, fixed, adaptive, need)   # + alignment and slab rows
 
