@@ -261,15 +261,6 @@ hipError_t slode_launch_stage_times(const slode_shape& s, const float* times, fl
   return hipGetLastError();
 }
 
-hipError_t slode_launch_slab_stage1(const float* slabs, int stride, int n, int count, float* part, int zr_rows, int zr_lo, int zr_hi, int* n_out,
-                                    hipStream_t stream) {
-  const int per = (n + SLODE_REDUCE_GROUPS - 1) / SLODE_REDUCE_GROUPS;
-  const Stage1 f{slabs, stride, n, count, per, part, zr_rows, zr_lo, zr_hi}, none{nullptr, 0, 0, 0, 0, nullptr, 0, 0, 0};
-  *n_out = (n + per - 1) / per;
-  SLODE_LAUNCH("slab_stage1", slab_stage1_kernel, dim3((count + 63) / 64, SLODE_REDUCE_GROUPS, 1), dim3(256), 0, stream, f, none);
-  return hipGetLastError();
-}
-
 hipError_t slode_launch_reduce(const ReduceLaunch& a_in, hipStream_t stream) {
   ReduceLaunch a = a_in;
   ReduceK k{};

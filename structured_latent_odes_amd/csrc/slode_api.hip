@@ -112,7 +112,6 @@ int slode_create(slode_handle* out, int device_id) {
   c->fold_on = getenv("SLODE_FOLD_NEXT") ? atoi(getenv("SLODE_FOLD_NEXT")) : 0;
   c->fold_valid = 0; c->fold_tmajor = 0; c->fold_ws = nullptr; c->fold_params = nullptr; c->fold_gen = 0;
   // (measured arms: 16 / 32 / 64 lanes per trajectory give the same bits and the same time, profiles/r04_f_ab11_*: the shipped form stays 8)
-  c->side_on = getenv("SLODE_DP5_SIDE") ? atoi(getenv("SLODE_DP5_SIDE")) : 1;
   c->dp5_w64 = getenv("SLODE_DP5_LPT") ? atoi(getenv("SLODE_DP5_LPT")) : 0;   // 0: chosen per batch (dp5_lanes)
   c->chain_resident = 0; memset(c->chain_resident_sig, 0, sizeof(c->chain_resident_sig));
   // diagnostics and test hooks: the environment is read here, once per handle, never at launch time
@@ -130,7 +129,6 @@ int slode_create(slode_handle* out, int device_id) {
 int slode_destroy(slode_handle h) {
   if (h && h->ev_ready)
     for (int i = 0; i < SLODE_CLOCK_MAX; ++i) { (void)hipEventDestroy(h->clk.ev[i][0]); (void)hipEventDestroy(h->clk.ev[i][1]); }
-  if (h && h->side) { (void)hipStreamSynchronize(h->side); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipStreamDestroy(h->side); }
   delete h;
   return SLODE_OK;
 }
@@ -273,7 +271,7 @@ static Workspace carve(slode_handle h, const slode_shape& s_in, const slode_layo
   w.g_scale = take((size_t)s.B * s.L);
   w.g_pre = take((size_t)s.B * 64);
   w.ode_slabs = take((size_t)(w.ode_grid + w.dp_rows) * w.ode_stride);   // dopri5: its backward kernel's rows follow the scorer's
-  w.ode_part = take((size_t)(dp5 ? 2 : 1) * SLODE_REDUCE_GROUPS * w.ode_stride);   // (dopri5: the scorer's rows and the reverse sweep's are reduced by two launches)
+  w.ode_part = take((size_t)SLODE_REDUCE_GROUPS * w.ode_stride);
   w.small_slabs = take((size_t)w.small_grid * w.small_stride);
   w.small_part = take((size_t)SLODE_REDUCE_GROUPS * w.small_stride);
   w.lin_slabs = take((size_t)w.lin_splitk * s.Hc * FQ);
@@ -558,8 +556,6 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
   int n_slabs = w.ode_grid;
   int part_lo = lay->ode_begin, part_hi = lay->n_params;   // flat range the slab rows carry (after the loss slot)
   int zr_rows = 0, zr_lo = 0, zr_hi = 0;                   // rows [0, zr_rows) carry nothing in slab columns [zr_lo, zr_hi) (dopri5 scorer)
-  bool side_rows = false;   // dopri5: the scorer's slab rows are reduced on the side stream (below)
-  int side_parts = 0;
   if (phase == 2) {
     if (aux_mode) { part_lo = lay->aux_w1[0]; part_hi = lay->cstd; }
   } else if (aux_mode) {
@@ -615,7 +611,6 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
       a.ext_skip = 1;
       zr_rows = w.ode_grid; zr_lo = 1 + (lay->init_w1 - lay->ode_begin); zr_hi = 1 + (lay->dyn_bd + s->S - lay->ode_begin);
     }
-    side_rows = dp5 && bwd && folded && h->side_on && w.ode_grid > 2 * SLODE_REDUCE_GROUPS && w.dp_rows > 2 * SLODE_REDUCE_GROUPS;
     if (dp5) {
       // adaptive solve (per-trajectory controller, accepted steps recorded) -> ONE scorer pass (loss terms, dLoss/dx, every gradient
       // that does not flow through the solver, its own share of the latent gradient into g_loc / g_scale) -> reverse mode over the
@@ -640,21 +635,6 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     e = slode_launch_ode(a, st, h->err, sizeof(h->err));
     if (e == hipErrorInvalidValue) return SLODE_EINVAL;
     HIP_TRY(h, e);
-    if (dp5 && bwd && side_rows) {
-      // Stage 1 of the slab reduction over the scorer's rows -- 52 MB of HBM reads at BASELINE config[2], which wait for nothing but the
-      // scorer -- runs on the handle's side stream beside the reverse sweep (a latency-bound kernel that leaves the memory system idle);
-      // the main stream picks its partial rows up before the GEMM launch.
-      if (!h->side) {
-        HIP_TRY(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-      }
-      HIP_TRY(h, hipEventRecord(h->ev_fork, st));
-      HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-      HIP_TRY(h, slode_launch_slab_stage1(w.ode_slabs, w.ode_stride, w.ode_grid, (part_hi - part_lo) + 1, w.ode_part, zr_rows, zr_lo, zr_hi, &side_parts,
-                                          h->side));
-      HIP_TRY(h, hipEventRecord(h->ev_join, h->side));
-    }
     if (dp5 && bwd) {
       DopriRec rc{w.loc, w.scale, eps, w.dp_z, w.dp_rec, w.dp_nrec, w.dp_kmax};
       { const int l5 = dp5_lanes(h, s->B); rc.tabs = (l5 == 8 || l5 == 16) ? w.dp_tabs : nullptr; }
@@ -677,18 +657,10 @@ static int elbo_step_impl(slode_handle h, const slode_shape* s, const slode_layo
     const float* ode_part = nullptr;
     int ode_pn = 0;
     const PayloadMap pm = payload_map(*s, part_hi - part_lo);
-    if (phase != 2) {
-      if (side_rows) {
-        HIP_TRY(h, hipStreamWaitEvent(st, h->ev_join, 0));   // (long done: the reverse sweep takes several times as long)
-        HIP_TRY(h, slode_launch_gemm_tail(w.g_pre, obs, w.gslabs, s->Hc, (int)CT, w.glat, w.hid, w.gslabs2, w.gslabs3, s->L, s->B, w.gsplit,
-                                          w.ode_slabs + (size_t)w.ode_grid * w.ode_stride, w.ode_stride, w.dp_rows, (part_hi - part_lo) + 1,
-                                          w.ode_part + (size_t)side_parts * w.ode_stride, &ode_part, &ode_pn, st, 0, 0, 0));
-        ode_part = w.ode_part; ode_pn += side_parts;   // [the scorer's partial rows | the reverse sweep's]
-      } else
+    if (phase != 2)
       HIP_TRY(h, slode_launch_gemm_tail(w.g_pre, obs, w.gslabs, s->Hc, (int)CT, w.glat, w.hid, w.gslabs2, w.gslabs3, s->L, s->B, w.gsplit,
                                         w.ode_slabs, w.ode_stride, n_slabs, (part_hi - part_lo) + 1, w.ode_part, &ode_part, &ode_pn, st,
                                         zr_rows, zr_lo, zr_hi));
-    }
     if (phase == 1) {   // split-K partials and partial slab rows, summed in fixed order, into the contiguous payload
       HIP_TRY(h, slode_launch_pack_payload(w.gslabs, w.gslabs2, w.gslabs3, w.gsplit, s->Hc, (int)CT, s->L, ode_part, w.ode_stride, ode_pn,
                                            (part_hi - part_lo) + 1, payload, pm.g_loc, pm.g_ls, pm.ode, pm.total, st));

@@ -60,9 +60,6 @@ struct slode_ctx {
   int fold_on, fold_valid, fold_tmajor;
   const void* fold_ws; const void* fold_params;
   unsigned int fold_gen;
-  hipStream_t side = nullptr;   // dopri5 training: stage 1 of the slab reduction over the scorer's rows runs beside the reverse sweep
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int side_on;            // SLODE_DP5_SIDE=0 switches the side stream off (A/B)
   int dp5_w64;            // SLODE_DP5_LPT: lanes per trajectory of the forward adaptive solve (8, 16, 32, 64; 0 = by batch size)
   int chain_resident; int chain_resident_sig[8];   // cached occupancy answer for the shape (T, C, F, K, P, Hc, L, n_params)
 };
@@ -477,8 +474,6 @@ hipError_t slode_launch_fold_chain(const FoldLaunch& a, hipStream_t stream);
 //   glat[:, 64:64+L]   (g_pre: [B][64], glat: [B][128] = [g_loc | pad | g_scale * scale | pad])
 // Extra blocks of the same launch run stage 1 of the ODE-slab reduction (ode_n slabs -> *ode_n_out partial slabs in ode_part;
 // with few slabs stage 1 is skipped and *ode_part_out = ode_slabs).
-hipError_t slode_launch_slab_stage1(const float* slabs, int stride, int n, int count, float* part, int zr_rows, int zr_lo, int zr_hi, int* n_out,
-                                    hipStream_t stream);   // n slab rows -> *n_out <= SLODE_REDUCE_GROUPS partial rows (fixed order)
 hipError_t slode_launch_gemm_tail(const float* g_pre, const float* x, float* gslabs, int Hc, int CT, const float* glat, const float* hid,
                                   float* gslabs_loc, float* gslabs_ls, int L, int B, int splitk, const float* ode_slabs, int ode_stride,
                                   int ode_n, int ode_count, float* ode_part, const float** ode_part_out, int* ode_n_out,
