@@ -568,7 +568,9 @@ __host__ __device__ constexpr int ode_block_bound(int S, int T_, int C_, int Q_,
 // (soft_barrier) -- not in lockstep.
 template <int S, int H, bool BWD, int T_ = 0, int C_ = 0, int L_ = 0, int Q_ = 0, int M_ = -1, bool RA = false, bool ONE = false, int ALG = 0, int PK = 1,
           bool ENCF = false, bool SOFTB = false>
-__global__ void __launch_bounds__(ode_block_bound(S, T_, C_, Q_, ONE, BWD, PK)) __attribute__((amdgpu_waves_per_eu(PK == 2 ? 4 : 1)))
+// (waves per SIMD asked of the register allocator: the solver-free scorer (ALG 3) is a throughput kernel that waits 56 % of its wave cycles --
+// with the hint it compiles to 79 instead of 101 VGPRs, six waves per SIMD = eight workgroups per CU instead of five: 76 -> 71 us at config[2])
+__global__ void __launch_bounds__(ode_block_bound(S, T_, C_, Q_, ONE, BWD, PK)) __attribute__((amdgpu_waves_per_eu(ALG == 3 ? 5 : (PK == 2 ? 4 : 1))))
 ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ pl_pseg, const float* __restrict__ pl_loc,
                 const float* __restrict__ pl_scale, const float* __restrict__ pl_eps, const float* __restrict__ pl_u,
                 const float* __restrict__ pl_sigtab, const OdeK k) {
