@@ -482,20 +482,25 @@ __device__ __forceinline__ void dump_tables(float* tabs, const float* smem, cons
   }
 }
 
-// z = loc + scale * eps (or the given z) of one trajectory -> LDS row [LP] (and z_out / eps_out), LPT lanes per trajectory: all the loads
-// first, then the stores (a load-use-store loop pays one memory round trip per latent dim and lane)
+// z = loc + scale * eps (or the given z) of one trajectory -> LDS row [LP] (and z_out / eps_out), LPT lanes per trajectory.  Two parts: the
+// loads are the kernel's FIRST requests (their round trip -- the first touch of three arrays, ~8 k cycles in the stamps -- passes while the
+// set-up's other requests are issued), the stores follow those.
 template <int LPT>
-__device__ __forceinline__ void stage_latent(const DpK& k, long long bb, bool live, int lg, int L, int LP, float* s_zrow) {
+struct LatentRegs { float lo[(SLODE_MAX_L + LPT - 1) / LPT], sc[(SLODE_MAX_L + LPT - 1) / LPT], ep[(SLODE_MAX_L + LPT - 1) / LPT]; };
+template <int LPT>
+__device__ __forceinline__ void latent_request(const DpK& k, long long bb, int lg, int L, LatentRegs<LPT>& r) {
   constexpr int ZQ = (SLODE_MAX_L + LPT - 1) / LPT;
-  float lo[ZQ], sc[ZQ], ep[ZQ];
 #pragma unroll
   for (int q = 0; q < ZQ; ++q) {
     const int l = min(lg + LPT * q, L - 1);
     const long long i = bb * L + l;
-    if (k.z) { lo[q] = k.z[i]; sc[q] = 0.f; ep[q] = 0.f; }
-    else { lo[q] = k.loc[i]; sc[q] = k.scale[i]; ep[q] = slode_eps_at(k.rng, k.eps, bb, L, l); }
+    if (k.z) { r.lo[q] = k.z[i]; r.sc[q] = 0.f; r.ep[q] = 0.f; }
+    else { r.lo[q] = k.loc[i]; r.sc[q] = k.scale[i]; r.ep[q] = slode_eps_at(k.rng, k.eps, bb, L, l); }
   }
-  __builtin_amdgcn_sched_barrier(0);
+}
+template <int LPT>
+__device__ __forceinline__ void latent_store(const DpK& k, long long bb, bool live, int lg, int L, int LP, float* s_zrow, const LatentRegs<LPT>& r) {
+  constexpr int ZQ = (SLODE_MAX_L + LPT - 1) / LPT;
 #pragma unroll
   for (int q = 0; q < ZQ; ++q) {
     const int l = lg + LPT * q;
@@ -503,10 +508,10 @@ __device__ __forceinline__ void stage_latent(const DpK& k, long long bb, bool li
       float zl = 0.f;
       if (l < L && live) {
         const long long i = bb * L + l;
-        if (k.z) zl = lo[q];
+        if (k.z) zl = r.lo[q];
         else {
-          if (k.rng.on && k.eps_out) k.eps_out[i] = ep[q];
-          zl = fmaf(sc[q], ep[q], lo[q]);
+          if (k.rng.on && k.eps_out) k.eps_out[i] = r.ep[q];
+          zl = fmaf(r.sc[q], r.ep[q], r.lo[q]);
         }
         if (k.z_out) k.z_out[i] = zl;
       }
@@ -526,11 +531,13 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
   float* s_times = s_z + TPB * LP;      // [T]
   const bool live = b < k.B, own = g < S;
   const long long bb = live ? b : 0;
+  LatentRegs<G> zr;
+  latent_request<G>(k, bb, g, L, zr);
   UnitRegs<H> ur;
   units_request<S, H>(k.wh, k.bh, k.wg, k.wd, k.w1, k.b1, k.times, T, s_times, L, tid, DNT, m, ur);   // every set-up operand: one round trip
   InitRegs<S, H> ir;
   init_request<S, H>(k.w2, k.b2, g, ir);
-  stage_latent<G>(k, bb, live, g, L, LP, s_z + slot * LP);
+  latent_store<G>(k, bb, live, g, L, LP, s_z + slot * LP, zr);
   Units w;
   float pre0[JL];
   load_units<S, H>(ur, k.bg, k.bd, s_z + slot * LP, L, tid, DNT, s_times, T, m, w, pre0);
@@ -673,11 +680,13 @@ __global__ void __launch_bounds__(WNTH) dopri5_lpt_kernel(const DpK k) {
   float* s_times = s_z + WTP * LP;      // [T]
   const bool live = b < k.B, own = g < S;
   const long long bb = live ? b : 0;
+  LatentRegs<LPT> zr;
+  latent_request<LPT>(k, bb, lane & (LPT - 1), L, zr);
   UnitRegs<H> ur;
   units_request<S, H>(k.wh, k.bh, k.wg, k.wd, k.w1, k.b1, k.times, T, s_times, L, tid, WNTH, m, ur);
   InitRegs<S, H> ir;
   init_request<S, H>(k.w2, k.b2, g, ir);
-  stage_latent<LPT>(k, bb, live, lane & (LPT - 1), L, LP, s_z + slot * LP);
+  latent_store<LPT>(k, bb, live, lane & (LPT - 1), L, LP, s_z + slot * LP, zr);
   Units w;
   float pre0[JL];
   load_units<S, H, LPT>(ur, k.bg, k.bd, s_z + slot * LP, L, tid, WNTH, s_times, T, m, w, pre0);

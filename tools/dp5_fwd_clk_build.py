@@ -29,16 +29,18 @@ def rep_pre(old, new):
     assert old in pre, old[:70]
     pre = pre.replace(old, new, 1)
 rep_pre("template <int S, int H, int LPT = G>\n__device__ __forceinline__ unsigned load_units(",
-        "__device__ unsigned long long g_clk[8];\n#define CLK(i) if (blockIdx.x == 0 && threadIdx.x == 0) g_clk[i] = __builtin_readcyclecounter()\n"
+        "__device__ unsigned long long g_clk[12];\n#define CLK(i) if (blockIdx.x == 0 && threadIdx.x == 0) g_clk[i] = __builtin_readcyclecounter()\n"
         "template <int S, int H, int LPT = G>\n__device__ __forceinline__ unsigned load_units(")
 rep_pre("  asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");              // this wave's LDS-DMA has landed; the barrier covers the others'\n  __syncthreads();",
         "  CLK(0);\n  asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n  __syncthreads();\n  CLK(1);")
 rep_pre("  const unsigned dirmask = group_or(dm);\n  __syncthreads();", "  const unsigned dirmask = group_or(dm);\n  __syncthreads();\n  CLK(2);")
 rep_pre("  __syncthreads();\n  // segment table, event by event", "  __syncthreads();\n  CLK(3);\n  // segment table, event by event")
 rep_pre("  __syncthreads();\n  return dirmask;", "  __syncthreads();\n  CLK(4);\n  return dirmask;")
+rep("  InitRegs<S, H> ir;\n  init_request<S, H>(k.w2, k.b2, g, ir);\n  latent_store<G>(k, bb, live, g, L, LP, s_z + slot * LP, zr);",
+    "  CLK(7);\n  InitRegs<S, H> ir;\n  init_request<S, H>(k.w2, k.b2, g, ir);\n  asm volatile(\"\" ::: \"memory\"); CLK(8);\n  latent_store<G>(k, bb, live, g, L, LP, s_z + slot * LP, zr);")
 rep("  float y = init_state<S, H>(ir, pre0, g, own);", "  float y = init_state<S, H>(ir, pre0, g, own);\n  asm volatile(\"\" :: \"v\"(y)); CLK(5);")
 rep("  unsigned long long c_set = __builtin_readcyclecounter()", "  asm volatile(\"\" :: \"v\"(dt)); CLK(6);\n  unsigned long long c_set = __builtin_readcyclecounter()")
-rep("  if ((blockIdx.x == 0 || blockIdx.x == 100) && tid == 0) printf(", "  if (blockIdx.x == 0 && tid == 0) printf(\"dp5fwd set-up (cycles from kernel start): requests issued, latent rows staged %llu, all set-up operands landed %llu, unit sums %llu, rank %llu, segment table %llu, init state %llu, initial step %llu\\n\","
+rep("  if ((blockIdx.x == 0 || blockIdx.x == 100) && tid == 0) printf(", "  if (blockIdx.x == 0 && tid == 0) printf(\"dp5fwd first phase: units_request issued %llu, init_request issued %llu\\n\", g_clk[7] - c_begin, g_clk[8] - c_begin);\n  if (blockIdx.x == 0 && tid == 0) printf(\"dp5fwd set-up (cycles from kernel start): requests issued, latent rows staged %llu, all set-up operands landed %llu, unit sums %llu, rank %llu, segment table %llu, init state %llu, initial step %llu\\n\","
     " g_clk[0] - c_begin, g_clk[1] - c_begin, g_clk[2] - c_begin, g_clk[3] - c_begin, g_clk[4] - c_begin, g_clk[5] - c_begin, g_clk[6] - c_begin);\n"
     "  if ((blockIdx.x == 0 || blockIdx.x == 100) && tid == 0) printf(")
 s = pre + body + s[i1:]
