@@ -713,8 +713,8 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
   float e_hw[4] = {0.f, 0.f, 0.f, 0.f}, e_hb = 0.f;   // ENCF: this lane's head weights and bias, from the set-up's loads to the head layers
   // packed form with the shared encoder pass: this wave's first batch of W_eff rows is the kernel's FIRST request (the longest wait of the
   // set-up: everything else is issued behind it)
-  constexpr int ECT0 = (C_ ? C_ : 1) * (T_ ? T_ : 1), ENU0 = (ECT0 + 255) / 256, EBP0 = 2;   // (16 bytes per lane and request, as the shipped form)
-  f32x4 w_first[(ENCF && PK > 1) ? EBP0 : 1][(ENCF && PK > 1) ? ENU0 : 1];
+  constexpr int ECT0 = (C_ ? C_ : 1) * (T_ ? T_ : 1), ENU0 = (ECT0 + 127) / 128, EBP0 = 4;
+  f32x2 w_first[(ENCF && PK > 1) ? EBP0 : 1][(ENCF && PK > 1) ? ENU0 : 1];
   if (ENCF && PK > 1) {
     constexpr int EWG0 = PK * 4, ERWP0 = (52 + EWG0 - 1) / EWG0, NRB0 = (52 + ERWP0 - 1) / ERWP0;
     const int rblk = wave_wg < NRB0 ? (wave_wg + (int)blockIdx.x) % NRB0 : wave_wg, lane = (int)(threadIdx.x & 63);
@@ -723,7 +723,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
 #pragma unroll
       for (int u = 0; u < ENU0; ++u) {
         const int row = min(rblk * ERWP0 + r, k.Hc - 1);
-        w_first[r][u] = (r < ERWP0) ? *reinterpret_cast<const f32x4*>(k.enc_weff + (long long)row * ECT0 + min(4 * lane + 256 * u, ECT0 - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        w_first[r][u] = (r < ERWP0) ? *reinterpret_cast<const f32x2*>(k.enc_weff + (long long)row * ECT0 + min(2 * lane + 128 * u, ECT0 - 2)) : f32x2{0.f, 0.f};
       }
     asm volatile("" ::: "memory");
   }
@@ -777,19 +777,18 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
     STAMP(23);   // (set-up: LDS-DMA and per-thread loads requested)
     if (ENCF && PK > 1) {
       static_assert(!(ENCF && PK > 1) || (ERWP * PK <= 16 && ode_threads_for(T_ ? T_ : 1, Q_ ? Q_ : 1, C_ ? C_ : 1, S) == 256), "one wave_sum16 per wave");
-      static_assert(!(ENCF && PK > 1) || ((ECT & 3) == 0 && 2 * (L_ ? L_ : 1) * 16 <= 256), "C*T a multiple of 4, 16 lanes per head output");
+      static_assert(!(ENCF && PK > 1) || ((ECT & 1) == 0 && 2 * (L_ ? L_ : 1) * 16 <= 256), "even C*T, 16 lanes per head output");
       if (SOFTB && tid == 0) *s_sbar = 0u;
       // (the row block a wave takes rotates with the workgroup index: at any instant the chip's workgroups ask for different lines)
       constexpr int NRB = (52 + ERWP - 1) / ERWP;   // row blocks that hold rows (13 of 4 rows, 8 of 7)
       const int rblk = wave_wg < NRB ? (wave_wg + (int)blockIdx.x) % NRB : wave_wg;
       const int lane = (int)(threadIdx.x & 63), Hc = k.Hc, row0 = rblk * ERWP;
-      constexpr int ENUP = (ECT + 255) / 256;   // float4 requests per row
-      f32x4 xv[PK][ENUP];
+      f32x2 xv[PK][ENU];
 #pragma unroll
       for (int t = 0; t < PK; ++t) {
         const float* xrow = k.obs + (long long)min((int)blockIdx.x * PK + t, k.B - 1) * ECT;
 #pragma unroll
-        for (int u = 0; u < ENUP; ++u) xv[t][u] = *reinterpret_cast<const f32x4*>(xrow + min(4 * lane + 256 * u, ECT - 4));
+        for (int u = 0; u < ENU; ++u) xv[t][u] = *reinterpret_cast<const f32x2*>(xrow + min(2 * lane + 128 * u, ECT - 2));
       }
       {   // this trajectory's head weights and bias (as in the unpacked form); b_eff of the row whose sum this lane will finish
         const int o = tid >> 4, l16 = tid & 15, which = o / L, l = o - which * L;
@@ -801,28 +800,27 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) e_acc[r] = 0.f;
-      constexpr int EBP = 2;   // rows per batch: 2 x ENUP float4 = 24 registers in flight beside the PK x ENUP float4 of the observations
+      constexpr int EBP = 4;   // rows per batch: 4 x ENU float2 = 40 registers in flight beside the PK x ENU float2 of the observations
 #pragma unroll
       for (int r0 = 0; r0 < ERWP; r0 += EBP) {
-        f32x4 w[EBP][ENUP];
+        f32x2 w[EBP][ENU];
 #pragma unroll
         for (int r = 0; r < EBP; ++r)
 #pragma unroll
-          for (int u = 0; u < ENUP; ++u) {
+          for (int u = 0; u < ENU; ++u) {
             const int row = min(row0 + r0 + r, Hc - 1);   // (rows past Hc: a valid address, never used)
             if (r0 == 0) w[r][u] = w_first[r][u];   // (requested at the top of the kernel)
-            else w[r][u] = (r0 + r < ERWP) ? *reinterpret_cast<const f32x4*>(k.enc_weff + (long long)row * ECT + min(4 * lane + 256 * u, ECT - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            else w[r][u] = (r0 + r < ERWP) ? *reinterpret_cast<const f32x2*>(k.enc_weff + (long long)row * ECT + min(2 * lane + 128 * u, ECT - 2)) : f32x2{0.f, 0.f};
           }
 #pragma unroll
         for (int r = 0; r < EBP; ++r)
 #pragma unroll
-          for (int u = 0; u < ENUP; ++u) {
+          for (int u = 0; u < ENU; ++u) {
             if (r0 + r < ERWP) {
-              const bool in = 4 * lane + 256 * u < ECT;
-              const f32x4 wv4 = in ? w[r][u] : f32x4{0.f, 0.f, 0.f, 0.f};
+              const bool in = 2 * lane + 128 * u < ECT;
+              const float wx = in ? w[r][u].x : 0.f, wy = in ? w[r][u].y : 0.f;
 #pragma unroll
-              for (int t = 0; t < PK; ++t)
-                e_acc[(r0 + r) * PK + t] = fmaf(wv4.w, xv[t][u].w, fmaf(wv4.z, xv[t][u].z, fmaf(wv4.y, xv[t][u].y, fmaf(wv4.x, xv[t][u].x, e_acc[(r0 + r) * PK + t]))));
+              for (int t = 0; t < PK; ++t) e_acc[(r0 + r) * PK + t] = fmaf(wy, xv[t][u].y, fmaf(wx, xv[t][u].x, e_acc[(r0 + r) * PK + t]));
             }
           }
 #pragma unroll
@@ -833,6 +831,7 @@ ode_elbo_kernel(const float* __restrict__ pl_stage_t, const float* __restrict__ 
           }
       }
     }
+    STAMP(24);   // (packed form: this wave's W_eff x observation products done, i.e. its loads have returned)
     if (ENCF && PK == 1) {
       static_assert(!ENCF || ode_threads_for(T_ ? T_ : 1, Q_ ? Q_ : 1, C_ ? C_ : 1, S) == 256, "fused encoder forward: four waves");
       static_assert(!ENCF || ((ECT & 3) == 0 && 2 * (L_ ? L_ : 1) * 16 <= 256), "fused encoder forward: C*T a multiple of 4, 16 lanes per head output");
