@@ -211,7 +211,9 @@ int slode_decode_heads_bwd(slode_handle h, const slode_shape* s, const slode_lay
  * (rtol / atol of the shape); the gradient is the reverse mode of the accepted steps and of the dense output, step sizes held fixed
  * (grad_mode SLODE_GRAD_REFERENCE_ADJOINT: without the z -> dynamics path, as odeint_adjoint).  stage_t is ignored.  At most 65,536
  * trajectories per call; a trajectory whose accepted steps exceed the record capacity (256 MB / (B*(S+2)) floats, clamped to
- * [64, 2048] steps) or that exhausts 20,000 attempted steps turns the loss into NaN.  slode_workspace_bytes accounts for the records. */
+ * [64, 2048] steps) or that exhausts 20,000 attempted steps turns the loss into NaN.  slode_workspace_bytes accounts for the records, for
+ * the running sums the reverse sweep parks at the hidden units' switching times ([B][2][H][4S]: one set per lane group of a trajectory) and
+ * for the forward kernel's set-up tables of every sixteen trajectories, which the reverse sweep reads back instead of rebuilding them. */
 int slode_elbo_step(slode_handle h, const slode_shape* s, const slode_layout* lay, const float* params,
                     const float* times, const float* stage_t, const float* obs, const int64_t obs_strides[3],
                     const float* u, const float* eps, float* loss_out, float* grads, float* x_out, float* z_out,
