@@ -1253,20 +1253,22 @@ __global__ void __launch_bounds__(BNT) __attribute__((amdgpu_waves_per_eu(2))) d
   {
     float* s_w1 = s_big;            // [H][L]
     float* s_wz = s_big + H * L;    // [H][L]  z-columns of the dynamics net's hidden layer
-    stage_to_lds(s_w1, k.w1, H * L, tid, BNT);
-    for (int i0 = tid; i0 < H * L; i0 += 8 * BNT) {   // z-columns of the hidden layer: row pitch 1 + L
-      float v[8];
+    InitRegs<S, H> ir;   // the init net's output layer: requested with the batch below (one round trip for everything this section reads)
+    init_request<S, H>(k.w2, k.b2, g, ir);
+    for (int i0 = tid; i0 < H * L; i0 += 8 * BNT) {   // W1 and the z-columns of the hidden layer (row pitch 1 + L): ONE batch of loads, then the stores
+      float v[8], u1[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int i = min(i0 + q * BNT, H * L - 1), jj = i / L;
+        u1[q] = k.w1[i];
         v[q] = k.wh[i + jj + 1];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 8; ++q)
-        if (i0 + q * BNT < H * L) s_wz[i0 + q * BNT] = v[q];
+        if (i0 + q * BNT < H * L) { s_w1[i0 + q * BNT] = u1[q]; s_wz[i0 + q * BNT] = v[q]; }
     }
-    const float x0 = init_state<S, H>(k.w2, k.b2, pre0, g, own);
+    const float x0 = init_state<S, H>(ir, pre0, g, own);
     const float g0 = (live && !bad && own) ? lam + gxb[0] : 0.f;
     s_go[slot * 8 + g] = g0 * x0 * (1.f - x0);
 #pragma unroll
@@ -1276,8 +1278,10 @@ __global__ void __launch_bounds__(BNT) __attribute__((amdgpu_waves_per_eu(2))) d
     for (int i = 0; i < JL; ++i) {
       const int jj = g + G * i;
       float gh = 0.f;
-      if (jj < H)
-        for (int s = 0; s < S; ++s) gh = fmaf(k.w2[s * H + jj], s_go[slot * 8 + s], gh);
+      if (jj < H) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) gh = fmaf(ir.w2[i][s], s_go[slot * 8 + s], gh);
+      }
       s_gp[slot * 32 + jj] = pre0[i] > 0.f ? gh : 0.f;
       if (jj >= H) s_gu[slot * 32 + jj] = 0.f;
     }
