@@ -11,7 +11,7 @@
  *   - all tensors are fp32, device (HBM) pointers owned by the CALLER; the library never allocates device
  *     memory, never synchronises the stream, and launches on the hipStream_t passed as `void* stream`;
  *   - the environment is read once per handle, in slode_create (diagnostic switches SLODE_NO_FOLD, SLODE_ODE_LOOP, SLODE_ODE_GRID,
- *     SLODE_ODE_GENERIC, SLODE_ODE_ALG, SLODE_ODE_PACK, SLODE_ENC_FUSE); nothing about a launch depends on the environment at call time;
+ *     SLODE_ODE_GENERIC, SLODE_ODE_ALG, SLODE_ODE_PACK, SLODE_ENC_FUSE, SLODE_DP5_LPT); nothing about a launch depends on the environment at call time;
  *   - `times` must be strictly monotone (torchdiffeq's precondition); a table that is not turns the fused kernel's loss into NaN;
  *   - every call returns SLODE_OK (0) or a negative slode_status; slode_last_error() gives the text;
  *   - all model parameters live in ONE flat fp32 vector whose segment offsets are given by slode_layout
