@@ -446,7 +446,7 @@ struct GemmProbs { GemmProb p[3]; int n_gemm_x; Stage1 rider; int rider_bx; int 
 // pl_A0 / pl_X0 = ps.p[0].A / .X (the big product's operands) as leading, SGPR-preloaded arguments (see ode_elbo_kernel)
 __global__ void __launch_bounds__(256) enc_bwd_lin_kernel(const float* __restrict__ pl_A0, const float* __restrict__ pl_X0, const GemmProbs ps, int B,
                                                           int per_wave, int ones_col) {
-  __shared__ float s_part[4 * 32 * 64];
+  __shared__ __attribute__((aligned(16))) float s_part[4 * 32 * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // One-dimensional grid, the products' blocks FIRST: they are dispatched to CUs of their own before the rider blocks fill in (with the
   // riders interleaved in dispatch order the two kinds delayed each other: products alone 5.3 us, riders alone 4.7, together 6.6).
@@ -559,7 +559,7 @@ hipError_t slode_launch_gemm_tail(const float* g_pre, const float* x, float* gsl
   if (ode_part && ode_n > 2 * SLODE_REDUCE_GROUPS) {
     const int per = (ode_n + SLODE_REDUCE_GROUPS - 1) / SLODE_REDUCE_GROUPS;
     ps.rider = Stage1{ode_slabs, ode_stride, ode_n, ode_count, per, ode_part, zr_rows, zr_lo, zr_hi};
-    ps.rider_bx = (ode_count + 63) / 64;
+    ps.rider_bx = (ode_count + SLODE_S1_COLS - 1) / SLODE_S1_COLS;
     rider_x = (ps.rider_bx * SLODE_REDUCE_GROUPS + splitk - 1) / splitk;
     *ode_part_out = ode_part; *ode_n_out = (ode_n + per - 1) / per;
   }

@@ -32,9 +32,9 @@ struct ReduceK {
 };
 
 __global__ void __launch_bounds__(256) slab_stage1_kernel(const Stage1 fam0, const Stage1 fam1) {
-  __shared__ float s_p[4 * 64];
+  __shared__ __attribute__((aligned(16))) float s_p[4 * SLODE_S1_COLS];
   const Stage1 f = blockIdx.z == 0 ? fam0 : fam1;  // two slab families reduced by one launch
-  if (f.slabs == nullptr || blockIdx.x * 64 >= f.count) return;
+  if (f.slabs == nullptr || blockIdx.x * SLODE_S1_COLS >= f.count) return;
   slab_stage1_block(f, blockIdx.x, blockIdx.y, s_p);
 }
 
@@ -281,7 +281,7 @@ hipError_t slode_launch_reduce(const ReduceLaunch& a_in, hipStream_t stream) {
   const int small_count = a.folded ? slode_fold_small_count(s) : slode_enc_small_count(s);
   stage1(1, a.small_slabs, a.small_stride, a.small_n, small_count, a.small_part);
   if (maxcount > 0)
-    SLODE_LAUNCH("slab_stage1", slab_stage1_kernel, dim3((maxcount + 63) / 64, SLODE_REDUCE_GROUPS, 2), dim3(256), 0, stream, fam[0], fam[1]);
+    SLODE_LAUNCH("slab_stage1", slab_stage1_kernel, dim3((maxcount + SLODE_S1_COLS - 1) / SLODE_S1_COLS, SLODE_REDUCE_GROUPS, 2), dim3(256), 0, stream, fam[0], fam[1]);
   k.ode_slabs = a.ode_slabs; k.ode_stride = a.ode_stride; k.ode_n = a.ode_n;
   k.nseg = a.lay.ode_end - a.lay.ode_begin; k.ode_begin = a.lay.ode_begin;
   k.small_slabs = a.small_slabs; k.small_stride = a.small_stride; k.small_n = a.small_n;

@@ -321,27 +321,45 @@ __device__ __forceinline__ void tail_element(const TailK& k, int i) {
 // zr_*: rows [0, zr_rows) carry nothing in columns [zr_lo, zr_hi) (dopri5 training: the scorer's rows and the solver-side range, which only
 // the reverse sweep's rows fill) -- those reads are skipped (4096 x 12.8 KB of zeros at BASELINE config[2])
 struct Stage1 { const float* slabs; int stride, n, count, per; float* out; int zr_rows, zr_lo, zr_hi; };
+// One block = SLODE_S1_COLS columns x one group of rows; wave q takes rows w0 + q, w0 + q + 4, ...; a lane reads FOUR consecutive columns per
+// row (16 bytes: a wave's request is 1 KB of one row -- with 4 bytes per lane the 52 MB of config[2]'s scorer rows were 203 k requests of
+// 256 B; the sums per column run in the same order as before).  s_p: 4 x SLODE_S1_COLS floats.  stride: a multiple of 4, rows 16-byte aligned.
+#define SLODE_S1_COLS 256
 __device__ __forceinline__ void slab_stage1_block(const Stage1& f, int bx, int g, float* s_p) {
+  typedef float f4_t __attribute__((ext_vector_type(4)));
   const int lane64 = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int e = bx * 64 + lane64;
+  const int e = bx * SLODE_S1_COLS + lane64 * 4;
   const int w0 = g * f.per, w1 = min(f.n, w0 + f.per);
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  f4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
   if (e < f.count) {
     const float* p = f.slabs + e;
-    int w = w0 + q;
-    if (e >= f.zr_lo && e < f.zr_hi && w < f.zr_rows) w += ((f.zr_rows - w + 3) >> 2) << 2;   // this sub-group's first row that carries the column
-    for (; w + 12 < w1; w += 16) {
-      a0 += p[(long long)w * f.stride];
-      a1 += p[(long long)(w + 4) * f.stride];
-      a2 += p[(long long)(w + 8) * f.stride];
-      a3 += p[(long long)(w + 12) * f.stride];
+    // first row of this sub-group that carries column e + c: rows below zr_rows hold nothing (not even zeros) in columns [zr_lo, zr_hi)
+    int st[4], w = 0x7fffffff;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      st[c] = w0 + q;
+      if (e + c >= f.zr_lo && e + c < f.zr_hi && st[c] < f.zr_rows) st[c] += ((f.zr_rows - st[c] + 3) >> 2) << 2;
+      w = min(w, st[c]);
     }
-    for (; w < w1; w += 4) a0 += p[(long long)w * f.stride];
+    auto row = [&](int r) __attribute__((always_inline)) {
+      f4_t v = *reinterpret_cast<const f4_t*>(p + (long long)r * f.stride);
+      v.x = r >= st[0] ? v.x : 0.f; v.y = r >= st[1] ? v.y : 0.f; v.z = r >= st[2] ? v.z : 0.f; v.w = r >= st[3] ? v.w : 0.f;   // (selects: what is masked may be anything)
+      return v;
+    };
+    for (; w + 12 < w1; w += 16) {
+      const f4_t v0 = row(w), v1 = row(w + 4), v2 = row(w + 8), v3 = row(w + 12);
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; w < w1; w += 4) a0 += row(w);
   }
-  s_p[q * 64 + lane64] = (a0 + a1) + (a2 + a3);
+  const f4_t t = (a0 + a1) + (a2 + a3);
+  *reinterpret_cast<f4_t*>(s_p + q * SLODE_S1_COLS + lane64 * 4) = t;
   __syncthreads();
-  if (q == 0 && e < f.count)
-    f.out[(long long)g * f.stride + e] = (s_p[lane64] + s_p[64 + lane64]) + (s_p[128 + lane64] + s_p[192 + lane64]);
+  for (int c = threadIdx.x; c < SLODE_S1_COLS; c += 256) {
+    const int ec = bx * SLODE_S1_COLS + c;
+    if (ec < f.count)
+      f.out[(long long)g * f.stride + ec] = (s_p[c] + s_p[SLODE_S1_COLS + c]) + (s_p[2 * SLODE_S1_COLS + c] + s_p[3 * SLODE_S1_COLS + c]);
+  }
 }
 
 // Deterministic block-wide sum (fixed tree).  `scratch` needs blockDim.x/64 floats.  Result valid in every thread.
