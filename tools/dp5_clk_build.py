@@ -11,7 +11,7 @@ def rep(old, new):
     s = s.replace(old, new, 1)
 rep("  GroupLds<H> m;\n  float* s_gu = m.carve(smem, BTP);", "  unsigned long long clk[12]; int nclk = 0;\n#define CLK() clk[nclk++] = __builtin_readcyclecounter()\n  CLK();\n  GroupLds<H> m;\n  float* s_gu = m.carve(smem, BTP);")
 rep("  {\n    constexpr int ZQ = SLODE_MAX_L / G;\n    float zv[ZQ];", "  unsigned long long c_a = __builtin_readcyclecounter();\n  {\n    constexpr int ZQ = SLODE_MAX_L / G;\n    float zv[ZQ];")
-rep("  Units w;\n  float pre0[JL];\n  const unsigned dirmask = load_units<S, H, LB>(ur,", "  unsigned long long c_b = __builtin_readcyclecounter(), c_c = c_b;\n  CLK();\n  Units w;\n  float pre0[JL];\n  const unsigned dirmask = load_units<S, H, LB>(ur,")
+rep("  Units w;\n  unsigned dirmask;\n  if (k.tabs) {", "  unsigned long long c_b = __builtin_readcyclecounter(), c_c = c_b;\n  CLK();\n  Units w;\n  unsigned dirmask;\n  if (k.tabs) {")
 rep("  const float* s_us = m.u + slot * 32;\n  const int* s_rnk", "  CLK();\n  const float* s_us = m.u + slot * 32;\n  const int* s_rnk")
 rep("  const bool any_bad = __syncthreads_or(live && bad) != 0;", "  CLK();\n  const bool any_bad = __syncthreads_or(live && bad) != 0;\n  CLK();")
 rep("    __syncthreads();\n    for (int col = tid; col < (H + 1) * NTMP; col += BNT) {", "    CLK();\n    __syncthreads();\n    for (int col = tid; col < (H + 1) * NTMP; col += BNT) {")
