@@ -296,7 +296,9 @@ int slode_grad_apply(slode_handle h, const slode_shape* s, const slode_layout* l
  * start without a fold launch.  Bitwise the same results; on MI355X the hand-offs inside the launch cost 6.0 us where the fold launch costs
  * 5.5, hence off.  When it is on, the workspace carries state from step to step and the library notices every weight change IT
  * makes; a caller that writes the parameter vector (or the workspace) itself between two steps -- checkpoint load, `load_state_dict`, its
- * own optimizer -- calls slode_fold_invalidate first.  With the arm off the call is a no-op. */
+ * own optimizer -- calls slode_fold_invalidate first.  With the arm off the call is a no-op.  The waits inside the launch are bounded: when
+ * one fires, W_eff is NaN-poisoned and the next loss is NaN (one bench run of a B = 128 shape averaged 308 instead of 46 us per step --
+ * profiles/r04_h_ab24_fold_next_all_configs.log); a diagnostic form, not for production runs. */
 int slode_fold_invalidate(slode_handle h);
 
 /* The handle's noise generator (replaces torch's global generator behind `rsample`): Philox-4x32-10 keyed by `seed`; the draw of
