@@ -211,12 +211,14 @@ __global__ void __launch_bounds__(WNT) weff_kernel(const float* __restrict__ pl_
 // VW floats per lane and request: 2 (8-byte requests, any even C*T) or 4 (16-byte requests -- global_load_dwordx4 / ds_read_b128, the width the
 // memory pipeline is built for: C*T a multiple of 4, rows 16-byte aligned); a tile of a row is 64 * VW * IUV columns
 template <int VW> struct EncVec { typedef __attribute__((ext_vector_type(VW))) float T; static constexpr int IUV = VW == 4 ? 3 : IU; };
-template <int NSET, int VW>
-__device__ __forceinline__ void enc_tile_fma(const typename EncVec<VW>::T (&w)[RB][EncVec<VW>::IUV], const float* s_x, int CT, int i0,
+// NP: pieces of 64 * VW columns a row has (VW = 4: two for C*T <= 512 -- 400 and 300 among the BASELINE shapes -- else three; a third piece that
+// no lane has a column in is a third of the multiply-adds, of the LDS reads and of the W_eff requests for nothing)
+template <int NSET, int VW, int NP = EncVec<VW>::IUV>
+__device__ __forceinline__ void enc_tile_fma(const typename EncVec<VW>::T (&w)[RB][NP], const float* s_x, int CT, int i0,
                                              float (&acc)[NSET][RB * TBE]) {
   typedef typename EncVec<VW>::T V;
 #pragma unroll
-  for (int u = 0; u < EncVec<VW>::IUV; ++u) {
+  for (int u = 0; u < NP; ++u) {
     const bool in = i0 + 64 * VW * u < CT;
     const int i = min(i0 + 64 * VW * u, CT - VW);
 #pragma unroll
@@ -254,7 +256,7 @@ __device__ __forceinline__ void enc_group_finish(float (&acc)[NSET][RB * TBE], i
 // on them and both are cold misses (W_eff was written by the fold launch a moment ago, from other CUs): one round trip instead of two.
 // BIGL (latent dim >= 32: the proc family's 50): the 2 * L * Hc head weights are staged in one batch of eight loads per thread and TRANSPOSED
 // ([which][mm][l]: the head threads of consecutive latent dims read consecutive words), one lane per head output.
-template <int TB, bool ONE, bool BIGL, int VW = 2>
+template <int TB, bool ONE, bool BIGL, int VW = 2, int NP = EncVec<VW>::IUV>
 __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__ pl_x, const float* __restrict__ pl_zloc_w, const float* __restrict__ pl_zls_w,
                                                        const float* __restrict__ pl_beff, const float* __restrict__ pl_weff, const FoldK k) {
   static_assert(TB % TBE == 0, "sets of four trajectories (wave_sum16 reduces RB x 4 partial sums)");
@@ -271,7 +273,7 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = NT >> 6;   // wave-uniform => row pointers in SGPRs
   const int ngroups = (Hc + RB - 1) / RB;
   typedef typename EncVec<VW>::T WV;
-  constexpr int IUV = EncVec<VW>::IUV;
+  constexpr int IUV = NP;
   static_assert(VW == 2 || ONE, "16-byte requests: the one-tile form only");
   WV w1[RB][IUV];
   if (ONE && wave < ngroups) {
@@ -338,7 +340,7 @@ __global__ void __launch_bounds__(FNT) enc_fwd2_kernel(const float* __restrict__
         float acc[1][RB * TBE];   // [r][tb] flattened: wave_sum16 reduces it in place
 #pragma unroll
         for (int i = 0; i < RB * TBE; ++i) acc[0][i] = 0.f;
-        enc_tile_fma<1, VW>(w1, s_x + st * TBE * CT, CT, VW * lane, acc);
+        enc_tile_fma<1, VW, NP>(w1, s_x + st * TBE * CT, CT, VW * lane, acc);
         __builtin_amdgcn_sched_barrier(0);   // keep the reduction's temporaries out of the load/FMA phase (spills otherwise)
         if (st == 0) STAMP(12);
         enc_group_finish<1>(acc, lane, wave * RB, b0 + st * TBE, k, s_be, s_hid + st * TBE * 64);
@@ -888,12 +890,13 @@ hipError_t slode_launch_fold_fwd(const FoldLaunch& a, hipStream_t stream) {
     SLODE_LAUNCH("enc_fwd2", (enc_fwd2_kernel<TT, OO, LL>), dim3((k.B + TB - 1) / TB), dim3(FNT), lds, stream, k.x, k.zloc_w, k.zls_w, k.beff, k.weff, k); \
   } while (0)
 #define SLODE_ENC_FWD2_L(TT, OO) do { if (k.L >= 32) SLODE_ENC_FWD2(TT, OO, true); else SLODE_ENC_FWD2(TT, OO, false); } while (0)
-#define SLODE_ENC_FWD2_W(TT, LL)                                                                                                        \
+#define SLODE_ENC_FWD2_W(TT, LL, PP)                                                                                                    \
   do {                                                                                                                                \
-    (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel<TT, true, LL, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
-    SLODE_LAUNCH("enc_fwd2", (enc_fwd2_kernel<TT, true, LL, 4>), dim3((k.B + TB - 1) / TB), dim3(FNT), lds, stream, k.x, k.zloc_w, k.zls_w, k.beff, k.weff, k); \
+    (void)hipFuncSetAttribute((const void*)enc_fwd2_kernel<TT, true, LL, 4, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    SLODE_LAUNCH("enc_fwd2", (enc_fwd2_kernel<TT, true, LL, 4, PP>), dim3((k.B + TB - 1) / TB), dim3(FNT), lds, stream, k.x, k.zloc_w, k.zls_w, k.beff, k.weff, k); \
   } while (0)
-#define SLODE_ENC_FWD2_WL(TT) do { if (k.L >= 32) SLODE_ENC_FWD2_W(TT, true); else SLODE_ENC_FWD2_W(TT, false); } while (0)
+#define SLODE_ENC_FWD2_WP(TT, LL) do { if (k.CT <= 512) SLODE_ENC_FWD2_W(TT, LL, 2); else SLODE_ENC_FWD2_W(TT, LL, 3); } while (0)
+#define SLODE_ENC_FWD2_WL(TT) do { if (k.L >= 32) SLODE_ENC_FWD2_WP(TT, true); else SLODE_ENC_FWD2_WP(TT, false); } while (0)
   if (wide && TB == 4 * TBE) SLODE_ENC_FWD2_WL(4 * TBE);
   else if (wide && TB == TBE) SLODE_ENC_FWD2_WL(TBE);
   else if (wide) SLODE_ENC_FWD2_WL(2 * TBE);
