@@ -573,6 +573,8 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
     const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
     dt = fminf(100.f * h0, h1);
   }
+  float* rrec = k.rec + bb * (S + 2);                      // this trajectory's record of the next accepted step
+  const long long rstride = (long long)k.B * (S + 2);
   int j = 1;
   int steps = bad_grid ? k.max_steps : 0, nacc = 0;
   float tj = s_times[j < T ? j : T - 1];   // the next output time, read ahead of its use
@@ -602,10 +604,10 @@ __global__ void __launch_bounds__(DNT) dopri5_kernel(const DpK k) {
     if (accept) {
       const float t1 = t + dt;
       if (k.rec && nacc < k.kmax) {
-        float* r = k.rec + ((long long)nacc * k.B + b) * (S + 2);
-        if (g == 0) { r[0] = t; r[1] = dt; }
-        if (own) r[2 + gs] = y;
+        if (g == 0) { rrec[0] = t; rrec[1] = dt; }
+        if (own) rrec[2 + gs] = y;
       }
+      rrec += rstride;   // (the record of step nacc sits at rec + (nacc B + b)(S + 2): advanced, not multiplied out, per accepted step)
       ++nacc;
       if (j < T && tj <= t1) {
         const float ymid = fmaf(dt, (6025192743.f / 30085553152.f / 2) * fcur + (51252292925.f / 65400821598.f / 2) * k3 +
@@ -719,6 +721,8 @@ __global__ void __launch_bounds__(WNTH) dopri5_lpt_kernel(const DpK k) {
     const float h1 = (d1 <= 1e-15f && d2 <= 1e-15f) ? fmaxf(1e-6f, h0 * 1e-3f) : powf(0.01f / fmaxf(d1, d2), 0.2f);
     dt = fminf(100.f * h0, h1);
   }
+  float* rrec = k.rec + bb * (S + 2);                      // this trajectory's record of the next accepted step
+  const long long rstride = (long long)k.B * (S + 2);
   int j = 1;
   int steps = bad_grid ? k.max_steps : 0, nacc = 0;
   float tj = s_times[j < T ? j : T - 1];   // the next output time, read ahead of its use
@@ -776,10 +780,10 @@ __global__ void __launch_bounds__(WNTH) dopri5_lpt_kernel(const DpK k) {
     if (accept) {
       const float t1 = t + dt;
       if (k.rec && nacc < k.kmax && e == 0) {
-        float* r = k.rec + ((long long)nacc * k.B + b) * (S + 2);
-        if (g == 0) { r[0] = t; r[1] = dt; }
-        if (own) r[2 + gs] = y;
+        if (g == 0) { rrec[0] = t; rrec[1] = dt; }
+        if (own) rrec[2 + gs] = y;
       }
+      rrec += rstride;
       ++nacc;
       if (j < T && tj <= t1) {
         const float ymid = fmaf(dt, (6025192743.f / 30085553152.f / 2) * fcur + (51252292925.f / 65400821598.f / 2) * k3 +
