@@ -1054,7 +1054,10 @@ __global__ void __launch_bounds__(BNT) __attribute__((amdgpu_waves_per_eu(2))) d
   SLODE_LDREC(0, ta, dta, ya)
   SLODE_LDREC(1, tb, dtb, yb)
   // every lane leaves the loop after max(K) <= kmax iterations; the butterflies sit at the top level of the body (all lanes run them)
-  auto step = [&](const float t, const float dt, const float y, const bool act) __attribute__((always_inline)) {
+  // `request`: the read-ahead of the step record after next.  It goes out BEHIND the loop over the step's output samples: that loop may read
+  // dL/dx from global memory (rows that do not fit in LDS), so it waits with s_waitcnt vmcnt(0) -- which, counting in order, also waits for
+  // whatever was requested before it; requested at the top of the step the records were a memory round trip per step on the critical path
+  auto step = [&](const float t, const float dt, const float y, const bool act, auto&& request) __attribute__((always_inline)) {
     const float te0 = t, te1 = t + dt * (1.f / 5), te2 = t + dt * (3.f / 10), te3 = t + dt * (4.f / 5), te4 = t + dt * (8.f / 9), te5 = t + dt;
     // ---- forward recomputation of the stages from the recorded (t, dt, y) ------------------------------------------------------
     // this lane group's three stage times: three independent table look-ups, their LDS reads in one batch; the other group's
@@ -1099,6 +1102,7 @@ __global__ void __launch_bounds__(BNT) __attribute__((amdgpu_waves_per_eu(2))) d
       gy += gq;
       Gd = fmaf(q, gq, Gd); Gc = fmaf(q2, gq, Gc); Gb = fmaf(q3, gq, Gb); Ga = fmaf(q4, gq, Ga);
     }
+    request();
     // ---- reverse mode of the step ------------------------------------------------------------------------------------------------
     const float gf0 = dt * (-2.f * Ga + 5.f * Gb - 4.f * Gc + Gd);
     const float gf1 = dt * (2.f * Ga - 3.f * Gb + Gc);
@@ -1174,14 +1178,11 @@ __global__ void __launch_bounds__(BNT) __attribute__((amdgpu_waves_per_eu(2))) d
     lam = act ? gy : lam;
   };
   for (int it = 0; __any(it < K); it += 3) {
-    SLODE_LDREC(it + 2, tc, dtc, yc)
-    step(ta, dta, ya, it < K);
+    step(ta, dta, ya, it < K, [&]() __attribute__((always_inline)) { SLODE_LDREC(it + 2, tc, dtc, yc) });
     if (!__any(it + 1 < K)) break;
-    SLODE_LDREC(it + 3, ta, dta, ya)
-    step(tb, dtb, yb, it + 1 < K);
+    step(tb, dtb, yb, it + 1 < K, [&]() __attribute__((always_inline)) { SLODE_LDREC(it + 3, ta, dta, ya) });
     if (!__any(it + 2 < K)) break;
-    SLODE_LDREC(it + 4, tb, dtb, yb)
-    step(tc, dtc, yc, it + 2 < K);
+    step(tc, dtc, yc, it + 2 < K, [&]() __attribute__((always_inline)) { SLODE_LDREC(it + 4, tb, dtb, yb) });
   }
 #undef SLODE_LDREC
   const bool any_bad = __syncthreads_or(live && bad) != 0;   // (also: every wave is done with the staged dL/dx rows)
