@@ -73,3 +73,49 @@ try:
     print("loss after the replays: %.4f (finite: %s)" % (float(svi.loss.item()) / 1024, bool(torch.isfinite(svi.loss).all())))
 except Exception as e:   # a library call that cannot be captured: say which
     print("capture failed: %r" % (e,))
+
+
+# ---- the reference's whole minibatch (main + auxiliary SVI step: nine launches) ----------------------------------------------------
+def probe(name, fn, K, units):
+    """stream launches against a graph of K calls of fn, in blocks of K calls and of 10 K calls; `units` = steps per call"""
+    try:
+        for _ in range(5):
+            for _ in range(30): fn()
+            sync()
+        m1, _ = blocks(lambda: [fn() for _ in range(K)], K * units)
+        m2, _ = blocks(lambda: [fn() for _ in range(10 * K)], 10 * K * units)
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(3): fn()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        sync()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(K): fn()
+        sync()
+        for _ in range(10): g.replay()
+        sync()
+        g1, _ = blocks(lambda: g.replay(), K * units)
+        g2, _ = blocks(lambda: [g.replay() for _ in range(10)], 10 * K * units)
+        print("%s: stream %.2f / %.2f us, graph %.2f / %.2f us (blocks of %d / %d)" % (name, m1, m2, g1, g2, K, 10 * K), flush=True)
+    except Exception as e:
+        print("%s: capture failed: %r" % (name, e), flush=True)
+
+
+from structured_latent_odes_amd.svi import AuxStep
+labels_d = {k: v.to(dev) for k, v in labels.items()}
+aux = AuxStep(m, svi.optimizer)
+probe("run_batch (main + auxiliary step, per minibatch)", lambda: (step(), aux.step_async(obs_d, eps=eps_d, **labels_d)), 20, 1)
+
+# ---- config[2] with its own solver (seven launches, 0.30 ms) -------------------------------------------------------------------------
+import importlib
+from structured_latent_odes_amd import configs as CF
+cfg2 = CF.load_config_proc(); cfg2.update(seq_len=100, solver="dopri5")
+set_seed(12)
+mod = importlib.import_module("structured_latent_odes_amd.models.mechanistic_proc")
+obs2, labels2, times2 = synthetic_batch("proc", 4096, 100, cfg2.obs_dim)
+m2 = mod.MechanisticModel(cfg2, dev, times2.to(dev)); b2 = m2._bind()
+obs2_d = obs2.to(dev); u2_d = m2.labels_to_u(**{k: v.to(dev) for k, v in labels2.items()}); eps2_d = torch.randn(4096, m2.latent_dim, device=dev)
+svi2 = ELBOStep(b2.engine, b2.flat, FlatAdam(b2.engine, b2.flat, lr=1e-4))
+probe("config[2] dopri5 step", lambda: svi2.step_async(obs2_d, eps=eps2_d, u=u2_d), 20, 1)
